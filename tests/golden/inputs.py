@@ -1,0 +1,92 @@
+"""Seeded input builders shared by make_golden.py (which feeds them to the reference) and the parity tests
+(which feed them to the oracle / HIP path).  torch's CPU generator is deterministic for a fixed torch build;
+each fixture also stores a sha256 of the inputs so RNG drift is detected instead of silently mis-compared."""
+import hashlib
+
+import numpy as np
+import torch
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def tensor_sha(t):
+    if t.dtype == torch.bfloat16:
+        return sha(t.contiguous().view(torch.uint16).numpy())
+    return sha(t.contiguous().numpy())
+
+
+def peaky_qk(gen, B, H, nb_img, nb_all, D, temp):
+    """Clustered block means so that the p-rule keeps few blocks (top_k-dominated regime).
+    Returns q [B,H,nb_img*128,D], k [B,H,nb_all*128,D] fp32."""
+    cent = torch.randn(B, H, nb_all, 1, D, generator=gen) * temp
+    k = cent + torch.randn(B, H, nb_all, 128, D, generator=gen)
+    pick = torch.randint(0, nb_img, (B, H, nb_img), generator=gen)
+    qc = torch.gather(cent[:, :, :nb_img], 2, pick[..., None, None].expand(-1, -1, -1, 1, D))
+    q = qc + torch.randn(B, H, nb_img, 128, D, generator=gen)
+    return q.reshape(B, H, nb_img * 128, D), k.reshape(B, H, nb_all * 128, D)
+
+
+# name, flavour, dtype, H, nb_img, text_blocks, top_k, p, peaky_temp, first_frame_blocks
+SELECT_SPECS = [
+    ("hy_flat_p03", "hy", "bfloat16", 3, 20, 2, 5, 0.3, 0.0, 0),
+    ("hy_flat_p09", "hy", "bfloat16", 2, 20, 2, 3, 0.9, 0.0, 0),
+    ("hy_peaky_p03", "hy", "bfloat16", 3, 20, 2, 5, 0.3, 1.5, 0),
+    ("hy_peaky_p05_fp16", "hy", "float16", 2, 20, 2, 4, 0.5, 1.0, 0),
+    ("hy_topk_all", "hy", "bfloat16", 2, 20, 2, 20, 0.3, 0.5, 0),
+    ("i2v_text4", "hy", "bfloat16", 2, 20, 4, 6, 0.3, 0.7, 0),
+    ("wan_ff2", "wan", "bfloat16", 2, 20, 0, 6, 0.8, 0.7, 2),
+    ("wan_flat", "wan", "bfloat16", 2, 20, 0, 4, 0.5, 0.0, 3),
+]
+SELECT_GRID = (4, 8, 80)  # 2560 tokens = 20 blocks of 128
+
+
+def select_inputs(index):
+    """-> q [1,H,nb_img*128,128], k [1,H,nb_all*128,128] in the case dtype."""
+    name, flav, dt, H, nb_img, tb, top_k, p, temp, ffb = SELECT_SPECS[index]
+    dt = getattr(torch, dt)
+    gen = torch.Generator().manual_seed(1000 + index)
+    nb_all = nb_img + tb
+    if temp > 0:
+        q, k = peaky_qk(gen, 1, H, nb_img, nb_all, 128, temp)
+    else:
+        q = torch.randn(1, H, nb_img * 128, 128, generator=gen)
+        k = torch.randn(1, H, nb_all * 128, 128, generator=gen)
+    return q.to(dt), k.to(dt)
+
+
+# H, nb_img, text_blocks, valid text tokens, text_amp, seed
+KERNEL_SPECS = [(2, 4, 2, 70, 0.0, 7), (2, 5, 2, 256, 0.431, 8), (1, 3, 1, 1, 0.25, 9)]
+
+
+def kernel_inputs(index):
+    """-> q [1,H,nb_img*128,128], k, v [1,H,S,128] fp16, mask bool [1,H,nb_img,nb_all], seqlen, text_amp."""
+    H, nb_img, tb, seqlen_txt, amp, seed = KERNEL_SPECS[index]
+    gen = torch.Generator().manual_seed(seed)
+    S = (nb_img + tb) * 128
+    q = (torch.randn(1, H, nb_img * 128, 128, generator=gen) * 1.2).half()
+    k = (torch.randn(1, H, S, 128, generator=gen) * 1.2).half()
+    v = torch.randn(1, H, S, 128, generator=gen).half()
+    mask = torch.rand(1, H, nb_img, nb_img + tb, generator=gen) < 0.5
+    mask[..., nb_img:] = True
+    for i in range(nb_img):
+        mask[:, :, i, i] = True
+    return q, k, v, mask, nb_img * 128 + seqlen_txt, amp
+
+
+OP_SPEC = dict(H=2, nb_img=6, text_blocks=2, top_k=2, p=0.3, text_amp=0.3, valid_text=100, grid=(2, 8, 48), seed=21)
+
+
+def op_inputs():
+    """Whole-op case: q,k,v [1,S,H,128] fp16 (peaky), cu_seqlens int32 [3]."""
+    s = OP_SPEC
+    gen = torch.Generator().manual_seed(s["seed"])
+    nb = s["nb_img"] + s["text_blocks"]
+    S = nb * 128
+    q, k = peaky_qk(gen, 1, s["H"], nb, nb, 128, 0.8)
+    q = q.transpose(1, 2).half().contiguous()
+    k = k.transpose(1, 2).half().contiguous()
+    v = torch.randn(1, S, s["H"], 128, generator=gen).half()
+    cu = torch.tensor([0, s["nb_img"] * 128 + s["valid_text"], S], dtype=torch.int32)
+    return q, k, v, cu

@@ -1,0 +1,237 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures under tests/golden/ by IMPORTING the reference.
+
+Run in the build container only (the reference lives at /root/reference and does
+not travel to the GPU box):
+
+    MPLBACKEND=Agg TRITON_INTERPRET=1 python tests/golden/make_golden.py [--big]
+
+Only DATA is written (npz/json): inputs, the reference's outputs, and digests of
+the large permutations.  No reference source is copied.  What is called:
+
+  gilbert.py                      gilbert_mapping, gilbert_block_neighbor_mapping,
+                                  sliced_gilbert_mapping, sliced_gilbert_block_neighbor_mapping
+  hyvideo/modules/attention_block_triton_diffres.py
+                                  _build_block_index_with_importance_optimized (torch, CPU)
+                                  _triton_block_sparse_attn_fwd_kernel_onehot via the launcher
+                                  (TRITON_INTERPRET=1, fp16 only -- the interpreter has no bf16)
+                                  block_sparse_attention (whole op, fp16; the text rows go through a
+                                  flash_attn stand-in = torch SDPA, flagged `text_rows_stub` in the npz)
+  wan/modules/attention_block_triton_diffres.py
+                                  _build_block_index_with_importance_optimized (first_frame_blocks)
+  hyvideo/modules/posemb_layers.py  get_nd_rotary_pos_embed, apply_rotary_emb
+  hyvideo/modules/norm_layers.py    RMSNorm
+"""
+import argparse
+import contextlib
+import hashlib
+import importlib.util
+import json
+import os
+import sys
+import types
+
+os.environ.setdefault("MPLBACKEND", "Agg")
+os.environ.setdefault("TRITON_INTERPRET", "1")
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import inputs  # noqa: E402  (tests/golden/inputs.py)
+
+REF = "/root/reference"
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+
+def _load(name, relpath):
+    spec = importlib.util.spec_from_file_location(name, os.path.join(REF, relpath))
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules[name] = mod
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def _install_flash_stub():
+    """flash_attn is absent here; the op module imports it unguarded.  SDPA stand-in (oracle harness only)."""
+    m = types.ModuleType("flash_attn")
+
+    def flash_attn_func(q, k, v, causal=False, softmax_scale=None):
+        # [B,S,H,D] in, [B,S,H,D] out
+        o = torch.nn.functional.scaled_dot_product_attention(
+            q.transpose(1, 2).float(), k.transpose(1, 2).float(), v.transpose(1, 2).float(),
+            is_causal=causal, scale=softmax_scale)
+        return o.transpose(1, 2).to(q.dtype)
+
+    m.flash_attn_func = flash_attn_func
+    sys.modules["flash_attn"] = m
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def gen_gilbert(big):
+    g = _load("ref_gilbert", "gilbert.py")
+    small = {}
+    # (t,h,w,block) small grids stored verbatim, incl. odd sizes and degenerate axes
+    for (t, h, w, bs) in [(2, 4, 6, 8), (4, 6, 8, 16), (3, 5, 7, 8), (1, 4, 4, 4), (5, 16, 16, 128),
+                          (4, 8, 80, 128), (2, 2, 2, 2), (1, 1, 9, 4), (6, 3, 2, 6)]:
+        l2h, h2l = g.gilbert_mapping(t, h, w)
+        nb = g.gilbert_block_neighbor_mapping(t, h, w, block_size=bs)
+        small[f"g_{t}_{h}_{w}_l2h"] = np.asarray(l2h, dtype=np.int64)
+        small[f"g_{t}_{h}_{w}_h2l"] = np.asarray(h2l, dtype=np.int64)
+        small[f"g_{t}_{h}_{w}_nb{bs}"] = nb.numpy()
+    for (t, h, w, bs) in [(3, 4, 6, 8), (5, 6, 4, 16), (2, 5, 7, 8), (4, 16, 16, 128)]:
+        l2h, h2l = g.sliced_gilbert_mapping(t, h, w)
+        nb = g.sliced_gilbert_block_neighbor_mapping(t, h, w, block_size=bs)
+        small[f"s_{t}_{h}_{w}_l2h"] = np.asarray(l2h, dtype=np.int64)
+        small[f"s_{t}_{h}_{w}_h2l"] = np.asarray(h2l, dtype=np.int64)
+        small[f"s_{t}_{h}_{w}_nb{bs}"] = nb.numpy()
+    np.savez_compressed(os.path.join(OUT, "gilbert_small.npz"), **small)
+
+    if not big:
+        return
+    digests = {}
+    for (t, h, w) in [(32, 45, 80), (32, 33, 60), (32, 22, 40)]:
+        l2h, h2l = g.gilbert_mapping(t, h, w)
+        nb = g.gilbert_block_neighbor_mapping(t, h, w, block_size=128)
+        digests[f"g_{t}_{h}_{w}"] = {
+            "l2h_sha256": sha(np.asarray(l2h, dtype=np.int64)),
+            "h2l_sha256": sha(np.asarray(h2l, dtype=np.int64)),
+            "h2l_head": [int(x) for x in h2l[:8]],
+            "nb128_sha256": sha(nb.numpy().astype(np.uint8)),
+            "nb128_rowsum_max": int(nb.sum(1).max()), "nb128_total": int(nb.sum()),
+        }
+    for (t, h, w) in [(21, 30, 52), (21, 45, 80)]:
+        l2h, h2l = g.sliced_gilbert_mapping(t, h, w)
+        nb = g.sliced_gilbert_block_neighbor_mapping(t, h, w, block_size=128)
+        digests[f"s_{t}_{h}_{w}"] = {
+            "l2h_sha256": sha(np.asarray(l2h, dtype=np.int64)),
+            "h2l_sha256": sha(np.asarray(h2l, dtype=np.int64)),
+            "h2l_head": [int(x) for x in h2l[:8]],
+            "nb128_sha256": sha(nb.numpy().astype(np.uint8)),
+            "nb128_rowsum_max": int(nb.sum(1).max()), "nb128_total": int(nb.sum()),
+        }
+    with open(os.path.join(OUT, "gilbert_big_digests.json"), "w") as f:
+        json.dump(digests, f, indent=1, sort_keys=True)
+
+
+def gen_select():
+    _install_flash_stub()
+    hy = _load("ref_hy_attn", "hyvideo/modules/attention_block_triton_diffres.py")
+    wan = _load("ref_wan_attn", "wan/modules/attention_block_triton_diffres.py")
+    g = sys.modules["ref_gilbert"]
+    cases = {}
+    meta = {}
+    nbm = g.gilbert_block_neighbor_mapping(*inputs.SELECT_GRID, block_size=128)
+    for i, (name, flav, dt, H, nb_img, tb, top_k, p, temp, ffb) in enumerate(inputs.SELECT_SPECS):
+        q, k = inputs.select_inputs(i)
+        nb_all = nb_img + tb
+        kw = dict(text_start_block=nb_img, num_blocks=nb_all, prob_threshold=p, text_blocks=tb,
+                  block_neighbor_list=nbm)
+        if flav == "wan":
+            mask = wan._build_block_index_with_importance_optimized(q, k, top_k, 128, 128,
+                                                                    first_frame_blocks=ffb, **kw)
+        else:
+            mask = hy._build_block_index_with_importance_optimized(q, k, top_k, 128, 128, **kw)
+        # diagnostics recomputed with plain torch ops (NOT reference code): pooled probs and the per-row count,
+        # so a test can accept any tie order the reference's unstable sort happened to pick.
+        qp = q.reshape(1, H, nb_img, 128, 128).mean(-2)
+        kp = k.reshape(1, H, nb_all, 128, 128).mean(-2)
+        sc = torch.bmm(qp[0], kp[0].transpose(1, 2)) * (128 ** -0.5)
+        pr = torch.softmax(sc[..., :nb_img], -1)
+        sp, _ = torch.sort(pr, -1, descending=True)
+        n = torch.clamp(((torch.cumsum(sp, -1) <= p).sum(-1) + 1), min=top_k)
+        cases[f"{name}_mask"] = mask.numpy()
+        cases[f"{name}_probs_f32"] = pr.float().numpy()
+        cases[f"{name}_n"] = n.numpy().astype(np.int32)
+        meta[name] = dict(flavour=flav, dtype=dt, H=H, nb_img=nb_img, text_blocks=tb, top_k=top_k, p=p,
+                          first_frame_blocks=ffb, grid=list(inputs.SELECT_GRID), q_sha256=inputs.tensor_sha(q),
+                          k_sha256=inputs.tensor_sha(k))
+    cases["neighbors"] = nbm.numpy()
+    np.savez_compressed(os.path.join(OUT, "select_cases.npz"), **cases)
+    with open(os.path.join(OUT, "select_cases.json"), "w") as f:
+        json.dump(meta, f, indent=1, sort_keys=True)
+
+
+def gen_attn():
+    """Reference Triton kernel under the CPU interpreter (fp16) + the whole HY op."""
+    hy = sys.modules["ref_hy_attn"]
+    torch.cuda.device = lambda *_a, **_k: contextlib.nullcontext()  # launcher uses `with torch.cuda.device(...)`
+    g = sys.modules["ref_gilbert"]
+    out = {}
+    meta = {}
+    # --- kernel-only cases: explicit mask, seqlen inside the text blocks, text_amp on/off
+    for ci, (H, nb_img, tb, seqlen_txt, amp, seed) in enumerate(inputs.KERNEL_SPECS):
+        q, k, v, mask, seqlen, amp = inputs.kernel_inputs(ci)
+        seqlens = torch.tensor([seqlen], dtype=torch.int32)
+        o = hy._triton_block_sparse_attention_onehot(q, k, v, seqlens, mask, 128 ** -0.5, 128, 128,
+                                                     text_amp=amp, text_block_start=nb_img)
+        n = f"k{ci}"
+        out[f"{n}_o"] = o.numpy()
+        meta[n] = dict(H=H, nb_img=nb_img, text_blocks=tb, seqlen=seqlen, text_amp=amp, dtype="float16",
+                       q_sha256=inputs.tensor_sha(q), k_sha256=inputs.tensor_sha(k), v_sha256=inputs.tensor_sha(v),
+                       mask_sha256=inputs.sha(mask.numpy()))
+    # --- whole op (HY flavour), fp16, real curve + neighbours; text rows via the SDPA stand-in
+    s = inputs.OP_SPEC
+    nbm = g.gilbert_block_neighbor_mapping(*s["grid"], block_size=128)
+    q, k, v, cu = inputs.op_inputs()
+    o = hy.block_sparse_attention(q, k, v, top_k=s["top_k"], cu_seqlens_q=cu, cu_seqlens_kv=cu,
+                                  text_blocks=s["text_blocks"], text_amp=s["text_amp"],
+                                  block_neighbor_list=nbm, p_remain_rates=s["p"])
+    out["op_o"] = o.numpy()
+    out["op_neighbors"] = nbm.numpy()
+    meta["op"] = dict(s, dtype="float16", q_sha256=inputs.tensor_sha(q), k_sha256=inputs.tensor_sha(k),
+                      v_sha256=inputs.tensor_sha(v),
+                      text_rows_stub="torch SDPA fp32 stand-in for flash_attn_func (not reference code)")
+    np.savez_compressed(os.path.join(OUT, "attn_cases.npz"), **out)
+    with open(os.path.join(OUT, "attn_cases.json"), "w") as f:
+        json.dump(meta, f, indent=1, sort_keys=True)
+
+
+def gen_norm_rope():
+    pe = _load("ref_posemb", "hyvideo/modules/posemb_layers.py")
+    nl = _load("ref_norm", "hyvideo/modules/norm_layers.py")
+    out = {}
+    cos, sin = pe.get_nd_rotary_pos_embed([16, 56, 56], [3, 4, 6], theta=256, use_real=True, theta_rescale_factor=1)
+    out["rope_3_4_6_cos"], out["rope_3_4_6_sin"] = cos.numpy(), sin.numpy()
+    cos2, sin2 = pe.get_nd_rotary_pos_embed([16, 56, 56], [32, 45, 80], theta=256, use_real=True,
+                                            theta_rescale_factor=1)
+    meta = {"rope_32_45_80_cos_sha256": sha(cos2.numpy()), "rope_32_45_80_sin_sha256": sha(sin2.numpy()),
+            "rope_32_45_80_cos_row12345": [float(x) for x in cos2[12345, ::16]]}
+    gen = torch.Generator().manual_seed(5)
+    S, H, D = 72, 3, 128
+    for dt, tag in [(torch.bfloat16, "bf16"), (torch.float16, "fp16")]:
+        x_q = (torch.randn(1, S, H, D, generator=gen) * 2.0).to(dt)
+        x_k = (torch.randn(1, S, H, D, generator=gen) * 0.5).to(dt)
+        nq = nl.RMSNorm(D, elementwise_affine=True, eps=1e-6, dtype=dt)
+        nk = nl.RMSNorm(D, elementwise_affine=True, eps=1e-6, dtype=dt)
+        with torch.no_grad():
+            nq.weight.copy_((1 + 0.1 * torch.randn(D, generator=gen)).to(dt))
+            nk.weight.copy_((1 + 0.1 * torch.randn(D, generator=gen)).to(dt))
+            yq, yk = nq(x_q), nk(x_k)
+            rq, rk = pe.apply_rotary_emb(yq, yk, (cos, sin), head_first=False)
+        view = (lambda t: t.view(torch.uint16).numpy()) if dt == torch.bfloat16 else (lambda t: t.numpy())
+        for nme, t in [("xq", x_q), ("xk", x_k), ("wq", nq.weight.data), ("wk", nk.weight.data), ("nq", yq),
+                       ("nk", yk), ("rq", rq), ("rk", rk)]:
+            out[f"{tag}_{nme}"] = view(t)
+    np.savez_compressed(os.path.join(OUT, "norm_rope_cases.npz"), **out)
+    with open(os.path.join(OUT, "norm_rope_cases.json"), "w") as f:
+        json.dump(meta, f, indent=1, sort_keys=True)
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--big", action="store_true", help="also hash the full-size curves (about 1 min)")
+    ap.add_argument("--only", default="")
+    a = ap.parse_args()
+    torch.set_grad_enabled(False)
+    gen_gilbert(a.big)
+    if a.only in ("", "select", "attn"):
+        gen_select()
+    if a.only in ("", "attn"):
+        gen_attn()
+    if a.only in ("", "rope"):
+        gen_norm_rope()
+    print("golden fixtures written to", OUT)

@@ -1,0 +1,58 @@
+"""Shared test helpers (conversion between torch low-precision tensors and the oracle's fp32 arrays)."""
+import numpy as np
+import torch
+
+
+def to_np(t):
+    """torch tensor (bf16/fp16/fp32) -> float32 numpy array with the same values."""
+    return t.detach().float().cpu().numpy()
+
+
+def from_bits(a, dtype):
+    """golden arrays: bf16 stored as uint16 bit patterns, fp16 stored natively."""
+    if dtype in ("bfloat16", "bf16"):
+        return torch.from_numpy(a.astype(np.uint16)).view(torch.bfloat16)
+    return torch.from_numpy(a)
+
+
+def tie_tolerant_mask_equal(mask, ref_mask, probs, n, nb_img, forced):
+    """The reference's torch.sort is unstable, so inside a group of equal probabilities ANY members may be the
+    ones selected.  Accept `mask` iff, per row: columns forced by neighbours/text/first-frame agree, the count of
+    sort-selected-or-forced columns is consistent, and no unselected image column has a strictly larger
+    probability than a selected non-forced one.  Returns (ok, message)."""
+    B, H, nq, _ = mask.shape
+    if not np.array_equal(mask[..., nb_img:], ref_mask[..., nb_img:]):
+        return False, "text columns differ"
+    for b in range(B):
+        for h in range(H):
+            for r in range(nq):
+                m, rm = mask[b, h, r, :nb_img], ref_mask[b, h, r, :nb_img]
+                f = forced[b, h, r, :nb_img]
+                if not np.all(m[f]) or not np.all(rm[f]):
+                    return False, f"forced column missing at {(b, h, r)}"
+                pr = probs[b, h, r]
+                k = int(min(n[b, h, r], nb_img))
+                cutoff = np.sort(pr)[::-1][k - 1]
+                # everything strictly above the cutoff must be in, everything strictly below must be out unless forced
+                if not np.all(m[pr > cutoff]):
+                    return False, f"row {(b, h, r)}: a block above the cutoff is missing"
+                if np.any(m[(pr < cutoff) & ~f]):
+                    return False, f"row {(b, h, r)}: a block below the cutoff was selected"
+                # number taken from the tie group must match what n requires
+                need = k - int((pr > cutoff).sum())
+                tie = (pr == cutoff)
+                got_min = int((m & tie & ~f).sum())
+                if int((m & tie).sum()) < min(need, int(tie.sum())) or got_min > need:
+                    return False, f"row {(b, h, r)}: wrong number of tie-group members"
+    return True, ""
+
+
+def assert_ulp_close(a, b, dtype, max_frac=1e-3):
+    """a, b float32 arrays of `dtype`-representable values: equal except <= 1 ulp flips on <= max_frac of elements."""
+    mant = 7 if dtype in ("bfloat16", "bf16") else 10
+    diff = a != b
+    frac = diff.mean()
+    assert frac <= max_frac, f"{frac:.2e} of elements differ"
+    if diff.any():
+        ulp = np.exp2(np.floor(np.log2(np.maximum(np.abs(b[diff]), 1e-30))) - mant)
+        assert np.all(np.abs(a[diff] - b[diff]) <= ulp * 1.001), "difference above one ulp"
