@@ -1,0 +1,143 @@
+/*
+ * jenga_amd.h -- C ABI of libjenga_amd.so: the MI355X (gfx950) AttenCarve hot path.
+ *
+ * The reference (dvlab-research/Jenga) is 100 % Python and has no FFI; its "native" code is one Triton
+ * kernel plus calls into flash-attn / NCCL.  This header is the boundary a maintainer would bind instead
+ * (ctypes stub: INTEGRATION.md, shipped binding: jenga_amd/_capi.py).  Every entry point names the
+ * reference interface it replaces (paths relative to the reference checkout).
+ *
+ * Conventions
+ *   - all tensor pointers are DEVICE pointers; `stream` is a hipStream_t passed as void* (NULL = default
+ *     stream); every call only enqueues work on that stream, never synchronises, never allocates.
+ *   - strides are in ELEMENTS; the innermost (head_dim) stride is always 1.
+ *   - dtype: JENGA_BF16 or JENGA_FP16 (the reference kernel accepts both, ...diffres.py:167-170).
+ *   - return value: JENGA_OK or an error code; jenga_last_error() gives the message for this thread.
+ *   - head_dim must be 128, block size 128 (the only configuration the reference runs: HunyuanVideo,
+ *     HunyuanVideo-I2V, Wan2.1 all use D=128 and BLOCK_M=BLOCK_N=128).
+ */
+#ifndef JENGA_AMD_H
+#define JENGA_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define JENGA_ABI_VERSION 1
+
+enum { JENGA_OK = 0, JENGA_EINVAL = 1, JENGA_ELAUNCH = 2, JENGA_EUNSUPPORTED = 3 };
+enum { JENGA_BF16 = 0, JENGA_FP16 = 1 };
+#define JENGA_BLOCK 128
+#define JENGA_HEAD_DIM 128
+
+int jenga_abi_version(void);
+const char* jenga_last_error(void);
+
+/* ---------------------------------------------------------------------------------------------------
+ * Static geometry.  Replaces gilbert.py: gilbert_mapping :442-488 (sliced=0), sliced_gilbert_mapping
+ * :332-440 (sliced=1): one thread per voxel evaluates the generalized-Hilbert index iteratively
+ * (gilbert_xyz2d :12-38 / _r :68-272).  linear index = z*h*w + y*w + x.
+ * l2h[linear] = curve index, h2l[curve index] = linear  (int64, length t*h*w each, device). */
+int jenga_gilbert_map(void* stream, int t, int h, int w, int sliced, int64_t* l2h, int64_t* h2l);
+
+/* Replaces gilbert_block_neighbor_mapping :597-677 and sliced_gilbert_block_neighbor_mapping :679-766:
+ * out[nb*nb] bytes (0/1), nb = ceil(t*h*w / block); out[a][b] = 1 iff some voxel of curve-block a has a
+ * 26-neighbour (or itself) in curve-block b.  `out` must be zero-filled by the caller. */
+int jenga_gilbert_neighbors(void* stream, int t, int h, int w, int block, const int64_t* l2h, uint8_t* out);
+
+/* ---------------------------------------------------------------------------------------------------
+ * Hilbert gather / scatter.  Replaces `img[:, hilbert_order]` / `img[:, linear_to_hilbert]`
+ * (jenga_hyvideo.py:116-118,226; jenga_hyvideo_multigpu.py:163-165,195; jenga_wan.py:559,655):
+ * dst[b, i, :] = src[b, index[i], :] for i < n_rows; rows of row_bytes bytes (multiple of 16). */
+int jenga_gather_rows(void* stream, const void* src, void* dst, const int64_t* index, int64_t batch,
+                      int64_t n_rows, int64_t row_bytes, int64_t src_batch_stride_bytes,
+                      int64_t dst_batch_stride_bytes);
+
+/* ---------------------------------------------------------------------------------------------------
+ * Fused per-head RMSNorm (+ optional RoPE) for one of Q/K.  Replaces RMSNorm.forward
+ * (hyvideo/modules/norm_layers.py:43,56-59) followed by apply_rotary_emb's real branch
+ * (hyvideo/modules/posemb_layers.py:206-212) as called at models_mul_block_gc_ha_multigpu.py:205-214,
+ * 226-227, 420-435.  x/out: [B,S,H,128] with the given strides (out may alias x); weight: [128] in dtype
+ * or NULL; cos/sin: [S_rope,128] fp32 or NULL (RoPE is applied to tokens s < s_rope only).
+ * Rounding points are the reference's: fp32 normalise -> dtype -> * weight -> dtype -> fp32 rotate
+ * (two products, one add, no FMA contraction) -> dtype.  eps < 0 skips the normalisation (RoPE only). */
+int jenga_rmsnorm_rope(void* stream, const void* x, void* out, const void* weight, const float* cos,
+                       const float* sin, int64_t B, int64_t S, int64_t H, int64_t x_sb, int64_t x_ss,
+                       int64_t x_sh, int64_t o_sb, int64_t o_ss, int64_t o_sh, int64_t s_rope, float eps,
+                       int dtype);
+
+/* ---------------------------------------------------------------------------------------------------
+ * Block selection.  Replaces _build_block_index_with_importance_optimized
+ * (hyvideo/modules/attention_block_triton_diffres.py:198-295; Wan first_frame_blocks rule
+ * wan/modules/attention_block_triton_diffres.py:400-406).
+ *
+ * jenga_block_pool: mean over each 128-token block (:216-217). x [B,S,H,128] strided, n_blocks*128 <= S
+ * tokens are pooled; pooled [B,H,n_blocks,128] contiguous in dtype (fp32 accumulate, one rounding). */
+int jenga_block_pool(void* stream, const void* x, void* pooled, int64_t B, int64_t H, int64_t n_blocks,
+                     int64_t x_sb, int64_t x_ss, int64_t x_sh, int dtype);
+
+/* jenga_block_select: scores = dtype(dtype(qpool.kpool^T) * 128^-0.5) (:221-232); softmax over the
+ * first nk_img columns in fp32 -> dtype (:235-238); descending sort (ties: lower index first; the
+ * reference's sort is unstable, any tie order is legal there); cumulative sum accumulated sequentially in
+ * fp32 with each partial rounded to dtype, compared with p rounded to dtype (:241-247);
+ * n = max(#(cumsum <= p) + 1, top_k) (:245-250); keep the first n sorted columns (:253-276); OR the static
+ * neighbour rows (:280-289); first_frame rule (Wan); all text columns [nk_img, nk_img+text_blocks) (:292-293).
+ *   qpool [B,H,nq,128], kpool [B,H,nk_all,128] (from jenga_block_pool), nk_all = nk_img + text_blocks
+ *   neighbors: uint8 [nb_rows, nb_cols] row-major (row stride nb_cols) or NULL
+ * Outputs (either may be NULL):
+ *   mask  uint8 [B,H,nq,nk_all]            the reference's one-hot layout (for parity checks)
+ *   idx   int32 [B,H,nq,nk_all], cnt int32 [B,H,nq]   ascending kept-column lists for jenga_bsattn_fwd */
+int jenga_block_select(void* stream, const void* qpool, const void* kpool, const uint8_t* neighbors,
+                       int64_t nb_rows, int64_t nb_cols, uint8_t* mask, int32_t* idx, int32_t* cnt,
+                       int64_t B, int64_t H, int64_t nq, int64_t nk_img, int64_t text_blocks, int64_t top_k,
+                       float p, int64_t first_frame_blocks, int dtype);
+
+/* ---------------------------------------------------------------------------------------------------
+ * Block-sparse attention forward.  Replaces _triton_block_sparse_attn_fwd_kernel_onehot + launcher
+ * (hyvideo/modules/attention_block_triton_diffres.py:38-136, 139-196) for the image query blocks and the
+ * flash_attn_func call for the text query blocks (:371-380), in ONE launch.
+ *
+ * Step 1, jenga_pack_v: re-tiles V into the MFMA operand order used by the P.V product
+ *   vt workspace bytes = B*H*n_blocks*128*128*2; n_blocks = S/128.
+ * Step 2, jenga_bsattn_fwd:
+ *   q,k,o [B,S,H,128] strided (S = n_blocks*128), vt from step 1, seqlens int32 [B] (device),
+ *   image query blocks m < nq_img use idx/cnt (layout of jenga_block_select, row stride = n_blocks):
+ *       q~ = dtype(q * (sm_scale*log2 e)); s = q~.k^T (fp32) [+ text_amp if kv block >= text_block_start];
+ *       kv columns >= seqlens[b] masked; base-2 online softmax; P rounded to dtype before P.V; o = acc/l.
+ *       Rows >= seqlens[b] are written as zeros (the reference leaves its pre-zeroed output untouched).
+ *   text query blocks m >= nq_img attend to every kv block with plain softmax(q.k^T*sm_scale), no length
+ *   mask and no text_amp (flash_attn_func semantics).
+ *   idx/cnt may be NULL when nq_img == 0 (fully dense: sa_drop_rate == 0 for a single segment). */
+size_t jenga_pack_v_bytes(int64_t B, int64_t H, int64_t n_blocks);
+int jenga_pack_v(void* stream, const void* v, void* vt, int64_t B, int64_t H, int64_t n_blocks, int64_t v_sb,
+                 int64_t v_ss, int64_t v_sh, int dtype);
+int jenga_bsattn_fwd(void* stream, const void* q, const void* k, const void* vt, void* o,
+                     const int32_t* seqlens, const int32_t* idx, const int32_t* cnt, int64_t B, int64_t H,
+                     int64_t n_blocks, int64_t nq_img, int64_t q_sb, int64_t q_ss, int64_t q_sh, int64_t k_sb,
+                     int64_t k_ss, int64_t k_sh, int64_t o_sb, int64_t o_ss, int64_t o_sh, float sm_scale,
+                     float text_amp, int64_t text_block_start, int dtype, int flags);
+/* flags */
+#define JENGA_ATTN_XCD_REMAP 1 /* contiguous q-block ranges per XCD (L2 locality); 0 = plain head-major order */
+
+/* ---------------------------------------------------------------------------------------------------
+ * Ulysses head pack/unpack: the local halves of xFuserLongContextAttention.forward's SeqAllToAll4D calls
+ * (hyvideo/modules/xdit_ring_atten.py:118-131 scatter heads / gather sequence, :212-217 the reverse).
+ * The exchange itself is one RCCL all_to_all_single issued from the host (torch.distributed); these
+ * kernels produce / consume its peer-major buffers, replacing yunchang's permute+contiguous copies.
+ *   pack:   x [B, S_loc, H, 128] strided -> send [N][B][S_loc][H/N][128]: chunk r holds heads
+ *           [r*H/N, (r+1)*H/N) and goes to rank r.  After the all-to-all, chunk r of the receive buffer is
+ *           rank r's S_loc tokens for MY heads, i.e. for B == 1 the receive buffer already IS the gathered
+ *           [1, N*S_loc, H/N, 128] tensor (rank-major sequence) and needs no unpack.
+ *   unpack: recv [N][B][S_loc][H/N][128] -> y [B, S_loc, H, 128] strided (inverse map; used after the
+ *           reverse all-to-all, whose send buffer for B == 1 is the attention output as it stands). */
+int jenga_ulysses_pack_heads(void* stream, const void* x, void* send, int64_t B, int64_t S_loc, int64_t H,
+                             int64_t N, int64_t x_sb, int64_t x_ss, int64_t x_sh);
+int jenga_ulysses_unpack_heads(void* stream, const void* recv, void* y, int64_t B, int64_t S_loc, int64_t H,
+                               int64_t N, int64_t y_sb, int64_t y_ss, int64_t y_sh);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* JENGA_AMD_H */

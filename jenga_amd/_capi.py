@@ -1,0 +1,255 @@
+"""ctypes binding of libjenga_amd.so (include/jenga_amd.h).  No compute happens in Python: every function
+enqueues HIP kernels on torch's current stream and raises if the library is missing or a call fails.
+There is NO CPU fallback on purpose: the product path must fail loudly when the HIP extension is absent."""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libjenga_amd.so")
+
+JENGA_BF16, JENGA_FP16 = 0, 1
+ATTN_XCD_REMAP = 1
+
+_vp, _i64, _i32, _f32 = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_float
+
+# name -> (restype, argtypes): every symbol the header declares
+SIGNATURES = {
+    "jenga_abi_version": (_i32, []),
+    "jenga_last_error": (ctypes.c_char_p, []),
+    "jenga_gilbert_map": (_i32, [_vp, _i32, _i32, _i32, _i32, _vp, _vp]),
+    "jenga_gilbert_neighbors": (_i32, [_vp, _i32, _i32, _i32, _i32, _vp, _vp]),
+    "jenga_gather_rows": (_i32, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64]),
+    "jenga_rmsnorm_rope": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp] + [_i64] * 10 + [_f32, _i32]),
+    "jenga_block_pool": (_i32, [_vp, _vp, _vp] + [_i64] * 6 + [_i32]),
+    "jenga_block_select": (_i32, [_vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp] + [_i64] * 6 + [_f32, _i64, _i32]),
+    "jenga_pack_v_bytes": (ctypes.c_size_t, [_i64, _i64, _i64]),
+    "jenga_pack_v": (_i32, [_vp, _vp, _vp] + [_i64] * 6 + [_i32]),
+    "jenga_bsattn_fwd": (_i32, [_vp] * 8 + [_i64] * 13 + [_f32, _f32, _i64, _i32, _i32]),
+    "jenga_ulysses_pack_heads": (_i32, [_vp, _vp, _vp] + [_i64] * 7),
+    "jenga_ulysses_unpack_heads": (_i32, [_vp, _vp, _vp] + [_i64] * 7),
+}
+
+_lib = None
+
+
+class JengaError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load the shared library (once).  Raises JengaError with build instructions if it is not there."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise JengaError(
+                f"{LIB_PATH} is missing: build it with `python -m jenga_amd.build` (hipcc --offload-arch=gfx950). "
+                "jenga_amd has no CPU fallback.")
+        L = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)
+            fn.restype, fn.argtypes = res, args
+        if L.jenga_abi_version() != 1:
+            raise JengaError("libjenga_amd.so ABI version mismatch; rebuild")
+        _lib = L
+    return _lib
+
+
+def _check(rc, what):
+    if rc != 0:
+        raise JengaError(f"{what} failed (code {rc}): {lib().jenga_last_error().decode()}")
+
+
+def _stream(dev):
+    return ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+
+
+def _need_gpu(t, what):
+    if not t.is_cuda:
+        raise JengaError(f"{what}: tensors must live on the GPU (got {t.device}); jenga_amd has no CPU path")
+
+
+def dtype_code(dt):
+    if dt == torch.bfloat16:
+        return JENGA_BF16
+    if dt == torch.float16:
+        return JENGA_FP16
+    raise ValueError(f"jenga_amd supports bfloat16 and float16 only, got {dt}")
+
+
+def _p(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+
+
+def _bshd_strides(t):
+    """[B,S,H,D] tensor with unit innermost stride -> (sb, ss, sh) in elements."""
+    if t.dim() != 4 or t.stride(3) != 1:
+        raise ValueError("expected a [B,S,H,D] tensor with contiguous head_dim")
+    return t.stride(0), t.stride(1), t.stride(2)
+
+
+# ------------------------------------------------------------------------------------------------ geometry
+def gilbert_map(t, h, w, sliced, device):
+    n = t * h * w
+    l2h = torch.empty(n, dtype=torch.int64, device=device)
+    h2l = torch.empty(n, dtype=torch.int64, device=device)
+    _need_gpu(l2h, "gilbert_map")
+    with torch.cuda.device(l2h.device):
+        _check(lib().jenga_gilbert_map(_stream(l2h.device), t, h, w, int(bool(sliced)), _p(l2h), _p(h2l)),
+               "jenga_gilbert_map")
+    return l2h, h2l
+
+
+def gilbert_neighbors(t, h, w, block, l2h):
+    _need_gpu(l2h, "gilbert_neighbors")
+    n = t * h * w
+    nb = (n + block - 1) // block
+    out = torch.zeros((nb, nb), dtype=torch.uint8, device=l2h.device)
+    with torch.cuda.device(l2h.device):
+        _check(lib().jenga_gilbert_neighbors(_stream(l2h.device), t, h, w, block, _p(l2h), _p(out)),
+               "jenga_gilbert_neighbors")
+    return out.view(torch.bool)
+
+
+# ------------------------------------------------------------------------------------------------ row ops
+def gather_rows(src, index, out=None):
+    """src [B, N, C] contiguous rows; index int64 [M] on the same device -> out [B, M, C] = src[:, index]."""
+    _need_gpu(src, "gather_rows")
+    if src.dim() != 3 or not src.is_contiguous():
+        raise ValueError("gather_rows expects a contiguous [B, N, C] tensor")
+    if index.dtype != torch.int64 or index.device != src.device:
+        raise ValueError("index must be an int64 tensor on the same device")
+    B, N, C = src.shape
+    M = index.numel()
+    if out is None:
+        out = torch.empty((B, M, C), dtype=src.dtype, device=src.device)
+    rb = C * src.element_size()
+    with torch.cuda.device(src.device):
+        _check(lib().jenga_gather_rows(_stream(src.device), _p(src), _p(out), _p(index), B, M, rb, N * rb, M * rb),
+               "jenga_gather_rows")
+    return out
+
+
+def rmsnorm_rope(x, weight, cos, sin, s_rope=None, eps=1e-6, out=None):
+    """x [B,S,H,128] (any B/S/H strides); weight [128] or None; cos/sin fp32 [>=s_rope,128] or None."""
+    _need_gpu(x, "rmsnorm_rope")
+    if x.shape[-1] != 128:
+        raise ValueError("head_dim must be 128")
+    B, S, H, _ = x.shape
+    if out is None:
+        out = torch.empty((B, S, H, 128), dtype=x.dtype, device=x.device)
+    xs, os_ = _bshd_strides(x), _bshd_strides(out)
+    if weight is not None:
+        weight = weight.to(device=x.device, dtype=x.dtype).contiguous()
+    if cos is not None:
+        if cos.dtype != torch.float32 or sin.dtype != torch.float32 or cos.shape[-1] != 128:
+            raise ValueError("cos/sin must be float32 [S,128]")
+        cos, sin = cos.contiguous(), sin.contiguous()
+        if s_rope is None:
+            s_rope = cos.shape[0]
+        if s_rope > cos.shape[0] or s_rope > S:
+            raise ValueError("s_rope exceeds the table / sequence length")
+    else:
+        s_rope = 0
+    with torch.cuda.device(x.device):
+        _check(lib().jenga_rmsnorm_rope(_stream(x.device), _p(x), _p(out), _p(weight), _p(cos), _p(sin), B, S, H,
+                                        *xs, *os_, s_rope, float(eps), dtype_code(x.dtype)), "jenga_rmsnorm_rope")
+    return out
+
+
+def block_pool(x, n_blocks):
+    """x [B,S,H,128] -> [B,H,n_blocks,128] means over 128-token blocks."""
+    _need_gpu(x, "block_pool")
+    B, S, H, D = x.shape
+    if D != 128 or n_blocks * 128 > S:
+        raise ValueError("block_pool: head_dim must be 128 and n_blocks*128 <= S")
+    out = torch.empty((B, H, n_blocks, 128), dtype=x.dtype, device=x.device)
+    with torch.cuda.device(x.device):
+        _check(lib().jenga_block_pool(_stream(x.device), _p(x), _p(out), B, H, n_blocks, *_bshd_strides(x),
+                                      dtype_code(x.dtype)), "jenga_block_pool")
+    return out
+
+
+def block_select(qpool, kpool, neighbors, nk_img, text_blocks, top_k, p, first_frame_blocks=0, want_mask=False,
+                 want_lists=True):
+    """-> (mask uint8 [B,H,nq,nk_all] | None, idx int32 [B,H,nq,nk_all] | None, cnt int32 [B,H,nq] | None)."""
+    _need_gpu(qpool, "block_select")
+    B, H, nq, _ = qpool.shape
+    nk_all = nk_img + text_blocks
+    if kpool.shape != (B, H, nk_all, 128):
+        raise ValueError(f"kpool shape {tuple(kpool.shape)} != {(B, H, nk_all, 128)}")
+    dev = qpool.device
+    mask = torch.empty((B, H, nq, nk_all), dtype=torch.uint8, device=dev) if want_mask else None
+    idx = torch.empty((B, H, nq, nk_all), dtype=torch.int32, device=dev) if want_lists else None
+    cnt = torch.empty((B, H, nq), dtype=torch.int32, device=dev) if want_lists else None
+    nbr, nbc = 0, 0
+    if neighbors is not None:
+        if neighbors.dtype == torch.bool:
+            neighbors = neighbors.view(torch.uint8)
+        neighbors = neighbors.to(dev).contiguous()
+        nbr, nbc = neighbors.shape
+    with torch.cuda.device(dev):
+        _check(lib().jenga_block_select(_stream(dev), _p(qpool.contiguous()), _p(kpool.contiguous()), _p(neighbors),
+                                        nbr, nbc, _p(mask), _p(idx), _p(cnt), B, H, nq, nk_img, text_blocks,
+                                        int(top_k), float(p), int(first_frame_blocks), dtype_code(qpool.dtype)),
+               "jenga_block_select")
+    return mask, idx, cnt
+
+
+def pack_v(v, n_blocks):
+    """v [B,S,H,128] -> opaque re-tiled workspace for bsattn_fwd."""
+    _need_gpu(v, "pack_v")
+    B, S, H, D = v.shape
+    if D != 128 or n_blocks * 128 != S:
+        raise ValueError("pack_v: S must equal n_blocks*128 and head_dim 128")
+    vt = torch.empty((B, H, n_blocks * 2, 128, 64), dtype=v.dtype, device=v.device)
+    with torch.cuda.device(v.device):
+        _check(lib().jenga_pack_v(_stream(v.device), _p(v), _p(vt), B, H, n_blocks, *_bshd_strides(v),
+                                  dtype_code(v.dtype)), "jenga_pack_v")
+    return vt
+
+
+def bsattn_fwd(q, k, vt, seqlens, idx, cnt, nq_img, sm_scale, text_amp, text_block_start, out=None, xcd_remap=True):
+    """q,k [B,S,H,128]; vt from pack_v; seqlens int32 [B] device; idx/cnt from block_select -> o [B,S,H,128]."""
+    _need_gpu(q, "bsattn_fwd")
+    B, S, H, D = q.shape
+    if D != 128 or S % 128:
+        raise ValueError("bsattn_fwd: head_dim must be 128 and S a multiple of 128")
+    n_blocks = S // 128
+    if out is None:
+        out = torch.empty((B, S, H, 128), dtype=q.dtype, device=q.device)
+    if seqlens is not None and (seqlens.dtype != torch.int32 or seqlens.device != q.device):
+        seqlens = seqlens.to(device=q.device, dtype=torch.int32)
+    if idx is not None and idx.shape[-1] != n_blocks:
+        raise ValueError("idx row length must equal the number of kv blocks")
+    with torch.cuda.device(q.device):
+        _check(lib().jenga_bsattn_fwd(_stream(q.device), _p(q), _p(k), _p(vt), _p(out), _p(seqlens), _p(idx), _p(cnt),
+                                      B, H, n_blocks, nq_img, *_bshd_strides(q), *_bshd_strides(k),
+                                      *_bshd_strides(out), float(sm_scale), float(text_amp), int(text_block_start),
+                                      dtype_code(q.dtype), ATTN_XCD_REMAP if xcd_remap else 0), "jenga_bsattn_fwd")
+    return out
+
+
+def ulysses_pack_heads(x, n_ranks, out=None):
+    """x [B,S_loc,H,128] -> [N,B,S_loc,H/N,128] (peer-major send buffer)."""
+    _need_gpu(x, "ulysses_pack_heads")
+    B, S, H, D = x.shape
+    if out is None:
+        out = torch.empty((n_ranks, B, S, H // n_ranks, D), dtype=x.dtype, device=x.device)
+    with torch.cuda.device(x.device):
+        _check(lib().jenga_ulysses_pack_heads(_stream(x.device), _p(x), _p(out), B, S, H, n_ranks,
+                                              *_bshd_strides(x)), "jenga_ulysses_pack_heads")
+    return out
+
+
+def ulysses_unpack_heads(recv, n_ranks, out=None):
+    """recv [N,B,S_loc,H/N,128] -> [B,S_loc,H,128]."""
+    _need_gpu(recv, "ulysses_unpack_heads")
+    N, B, S, Hn, D = recv.shape
+    if out is None:
+        out = torch.empty((B, S, Hn * N, D), dtype=recv.dtype, device=recv.device)
+    with torch.cuda.device(recv.device):
+        _check(lib().jenga_ulysses_unpack_heads(_stream(recv.device), _p(recv.contiguous()), _p(out), B, S, Hn * N, N,
+                                                *_bshd_strides(out)), "jenga_ulysses_unpack_heads")
+    return out

@@ -1,0 +1,365 @@
+// Block-sparse attention forward for gfx950 (CDNA4), head_dim 128, 128-token blocks.
+//
+// Work decomposition
+//   workgroup = 256 threads = 4 waves = one 128-row query block of one (batch, head);
+//   wave w owns query rows [32w, 32w+32); every lane owns ONE query row (q = lane&31), the two half-waves
+//   (hi = lane>>5) split the key / head-dim index inside every MFMA.
+//   KV is consumed in 64-key tiles (two per kept 128-block) staged through LDS and shared by the 4 waves:
+//   K tile [64][128] (XOR-swizzled 16-B chunks), V tile pre-tiled by jenga_pack_v as [128 d][64 pos].
+//
+// MFMA formulation (v_mfma_f32_32x32x16_{bf16,f16}; C layout col = lane&31, row = (r&3)+8(r>>2)+4hi):
+//   S^T[key][q] = sum_d K[key][d] Q[q][d]     A = K rows (ds_read_b128), B = Q (registers, loaded once)
+//     -> lane holds the scores of ITS query row for 16 keys per 32-key group: softmax is lane-local
+//        (31 fmax + one cross-half exchange per tile), no LDS round trip for P.
+//   O^T[d][q]  += sum_k V[k][d] P[q][k]       A = V^T rows (ds_read_b128 of the pre-tiled image),
+//                                             B = P packed to 16-bit straight from the S registers:
+//     the key order inside a k-step is whatever the S registers hold (pv_key_of_pos) -- V was tiled to match,
+//     so P never moves between lanes.
+//   -> lane holds O[q][16 d per 32-d block]: the online-softmax rescale and the final 1/l are lane-local too.
+//
+// Numerics follow the reference Triton kernel (attention_block_triton_diffres.py:38-136): q is scaled by
+// sm_scale*log2(e) and ROUNDED to the storage dtype before QK^T; scores/softmax in fp32 base 2; text_amp is
+// added to the logits of kv blocks >= text_block_start; kv columns >= seqlen are -inf; P is rounded to the
+// storage dtype before P.V; l accumulates the unrounded P; o = acc / l.  Text query blocks (TEXT=true) follow
+// flash_attn_func instead (:371-380): unrounded q, scores * sm_scale, no mask, no amp.
+#include "common.h"
+
+namespace jenga {
+namespace {
+
+struct AttnParams {
+    const uint16_t* q;
+    const uint16_t* k;
+    const uint16_t* vt;
+    uint16_t* o;
+    const int32_t* seqlens;
+    const int32_t* idx;
+    const int32_t* cnt;
+    long long q_sb, q_ss, q_sh, k_sb, k_ss, k_sh, o_sb, o_ss, o_sh;
+    int B, H, n_blocks, nq_img;
+    int text_block_start;
+    float qk_scale;   // sm_scale * log2(e), fp32
+    float text_amp;
+    int n_text_wg_pad;  // text workgroups (padded to a multiple of 8) come first in the grid
+    int img_per_head;   // grid slots per (b,h) for image blocks (8*C with XCD remap, nq_img otherwise)
+    int xcd_chunk;      // C, or 0 = plain order
+};
+
+constexpr int KT = 64;                      // keys per LDS tile
+constexpr int K_TILE_BYTES = KT * 128 * 2;  // 16 KiB
+constexpr int V_TILE_BYTES = 128 * KT * 2;  // 16 KiB
+constexpr int BUF_BYTES = K_TILE_BYTES + V_TILE_BYTES;
+
+struct Stage {
+    uint4 k[4];
+    uint4 v[4];
+};
+
+__device__ __forceinline__ void stage_load(Stage& st, const uint16_t* kbase, long long k_ss, const uint16_t* vtile,
+                                           int tid) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = i * 16 + (tid >> 4), c = tid & 15;
+        st.k[i] = *reinterpret_cast<const uint4*>(kbase + (long long)row * k_ss + c * 8);
+        st.v[i] = *reinterpret_cast<const uint4*>(vtile + (i * 256 + tid) * 8);
+    }
+}
+__device__ __forceinline__ void stage_store(const Stage& st, unsigned char* buf, int tid) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = i * 16 + (tid >> 4), c = tid & 15;
+        *reinterpret_cast<uint4*>(buf + row * 256 + ((c ^ (row & 15)) << 4)) = st.k[i];
+        const int d = (i * 256 + tid) >> 3, vc = tid & 7;
+        *reinterpret_cast<uint4*>(buf + K_TILE_BYTES + d * 128 + ((vc ^ ((d >> 1) & 7)) << 4)) = st.v[i];
+    }
+}
+
+template <typename T, bool TEXT>
+__device__ __forceinline__ void attn_block(const AttnParams& P, unsigned char* smem, int b, int h, int m) {
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int lq = lane & 31, hi = lane >> 5;
+    const int seqlen = P.seqlens ? P.seqlens[b] : P.n_blocks * 128;
+
+    // ---- kept-block list ----
+    const int32_t* list = nullptr;
+    int nkept;
+    if (TEXT) {
+        nkept = P.n_blocks;
+    } else {
+        const long long row = ((long long)b * P.H + h) * P.nq_img + m;
+        list = P.idx + row * P.n_blocks;
+        nkept = P.cnt[row];
+    }
+    const int ntiles = nkept * 2;
+
+    // ---- Q fragments: lane (q, hi) keeps Q[q][ds*16 + hi*8 .. +7] for ds = 0..7 ----
+    const long long qrow = (long long)m * 128 + wave * 32 + lq;
+    uint4 qf[8];
+    {
+        const uint16_t* qp = P.q + b * P.q_sb + qrow * P.q_ss + h * P.q_sh + hi * 8;
+#pragma unroll
+        for (int ds = 0; ds < 8; ++ds) {
+            uint4 raw = *reinterpret_cast<const uint4*>(qp + ds * 16);
+            if (!TEXT) {
+                float f[8];
+                unpack8<T>(raw, f);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) f[e] = f[e] * P.qk_scale;
+                raw = pack8<T>(f);
+            }
+            qf[ds] = raw;
+        }
+    }
+
+    f32x16 oacc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[i][r] = 0.f;
+    float m_i = -INFINITY, l_i = 0.f;
+
+    const uint16_t* kbh = P.k + b * P.k_sb + h * P.k_sh;
+    const uint16_t* vbh = P.vt + ((long long)b * P.H + h) * (long long)P.n_blocks * 2 * (128 * KT);
+
+    // per-lane LDS read offsets
+    const int k_row_off = lq * 256;                 // + g*8192
+    const int k_sw = lq & 15;
+    const int v_row_off = K_TILE_BYTES + lq * 128;  // + db*4096
+    const int v_sw = (lq >> 1) & 7;
+
+    Stage st;
+    if (ntiles > 0) {
+        const int blk0 = TEXT ? 0 : list[0];
+        stage_load(st, kbh + (long long)blk0 * 128 * P.k_ss, P.k_ss, vbh + (long long)blk0 * 2 * (128 * KT), tid);
+        stage_store(st, smem, tid);
+    }
+    __syncthreads();
+
+    for (int t = 0; t < ntiles; ++t) {
+        unsigned char* cur = smem + (t & 1) * BUF_BYTES;
+        const int blk = TEXT ? (t >> 1) : list[t >> 1];
+        const int key0 = blk * 128 + (t & 1) * KT;
+        const bool have_next = (t + 1 < ntiles);
+        if (have_next) {
+            const int nblk = TEXT ? ((t + 1) >> 1) : list[(t + 1) >> 1];
+            const int ntile = nblk * 2 + ((t + 1) & 1);
+            stage_load(st, kbh + ((long long)ntile * KT) * P.k_ss, P.k_ss, vbh + (long long)ntile * (128 * KT), tid);
+        }
+        const bool live = TEXT || (key0 < seqlen);  // a tile entirely past seqlen contributes exp2(-inf) = 0
+        if (live) {
+            // ---------------- S^T = K Q^T ----------------
+            f32x16 s0, s1;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                s0[r] = 0.f;
+                s1[r] = 0.f;
+            }
+#pragma unroll
+            for (int ds = 0; ds < 8; ++ds) {
+                const int c = ((ds * 2 + hi) ^ k_sw) << 4;
+                const uint4 ka = *reinterpret_cast<const uint4*>(cur + k_row_off + c);
+                const uint4 kb = *reinterpret_cast<const uint4*>(cur + k_row_off + 8192 + c);
+                s0 = mfma32<T>(ka, qf[ds], s0);
+                s1 = mfma32<T>(kb, qf[ds], s1);
+            }
+            // ---------------- logits fix-ups ----------------
+            if (TEXT) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    s0[r] *= P.qk_scale;
+                    s1[r] *= P.qk_scale;
+                }
+            } else {
+                if (blk >= P.text_block_start) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        s0[r] += P.text_amp;
+                        s1[r] += P.text_amp;
+                    }
+                }
+                if (key0 + KT > seqlen) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int kk = key0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                        if (kk >= seqlen) s0[r] = -INFINITY;
+                        if (kk + 32 >= seqlen) s1[r] = -INFINITY;
+                    }
+                }
+            }
+            // ---------------- online softmax (lane-local row) ----------------
+            float tmax = fmaxf(s0[0], s1[0]);
+#pragma unroll
+            for (int r = 1; r < 16; ++r) tmax = fmaxf(tmax, fmaxf(s0[r], s1[r]));
+            tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+            const float m_new = fmaxf(m_i, tmax);
+            const float alpha = __builtin_amdgcn_exp2f(m_i - m_new);
+            float psum = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                s0[r] = __builtin_amdgcn_exp2f(s0[r] - m_new);
+                s1[r] = __builtin_amdgcn_exp2f(s1[r] - m_new);
+                psum += s0[r] + s1[r];
+            }
+            l_i = l_i * alpha + psum;
+            m_i = m_new;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) oacc[i][r] *= alpha;
+            // P -> 16-bit operands: k-step ks = 2g + s uses C registers 8s..8s+7 of group g
+            uint4 pf[4];
+            pf[0] = make_uint4(pack2<T>(s0[0], s0[1]), pack2<T>(s0[2], s0[3]), pack2<T>(s0[4], s0[5]),
+                               pack2<T>(s0[6], s0[7]));
+            pf[1] = make_uint4(pack2<T>(s0[8], s0[9]), pack2<T>(s0[10], s0[11]), pack2<T>(s0[12], s0[13]),
+                               pack2<T>(s0[14], s0[15]));
+            pf[2] = make_uint4(pack2<T>(s1[0], s1[1]), pack2<T>(s1[2], s1[3]), pack2<T>(s1[4], s1[5]),
+                               pack2<T>(s1[6], s1[7]));
+            pf[3] = make_uint4(pack2<T>(s1[8], s1[9]), pack2<T>(s1[10], s1[11]), pack2<T>(s1[12], s1[13]),
+                               pack2<T>(s1[14], s1[15]));
+            // ---------------- O^T += V^T P^T ----------------
+#pragma unroll
+            for (int db = 0; db < 4; ++db) {
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    const int c = (((ks >> 1) * 4 + hi * 2 + (ks & 1)) ^ v_sw) << 4;
+                    const uint4 va = *reinterpret_cast<const uint4*>(cur + v_row_off + db * 4096 + c);
+                    oacc[db] = mfma32<T>(va, pf[ks], oacc[db]);
+                }
+            }
+        }
+        if (have_next) stage_store(st, smem + ((t + 1) & 1) * BUF_BYTES, tid);
+        __syncthreads();
+    }
+
+    // ---- epilogue: o = acc / l, rows >= seqlen written as zeros (image rows only) ----
+    const float l_tot = l_i + __shfl_xor(l_i, 32);
+    const bool row_ok = TEXT || (qrow < seqlen);
+    uint16_t* op = P.o + b * P.o_sb + qrow * P.o_ss + h * P.o_sh + hi * 4;
+#pragma unroll
+    for (int db = 0; db < 4; ++db) {
+#pragma unroll
+        for (int rq = 0; rq < 4; ++rq) {
+            uint2 w = make_uint2(0u, 0u);
+            if (row_ok) {
+                w.x = pack2<T>(__fdiv_rn(oacc[db][rq * 4 + 0], l_tot), __fdiv_rn(oacc[db][rq * 4 + 1], l_tot));
+                w.y = pack2<T>(__fdiv_rn(oacc[db][rq * 4 + 2], l_tot), __fdiv_rn(oacc[db][rq * 4 + 3], l_tot));
+            }
+            *reinterpret_cast<uint2*>(op + db * 32 + rq * 8) = w;
+        }
+    }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256, 2) bsattn_fwd_kernel(AttnParams P) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int n_text = P.n_blocks - P.nq_img;
+    const int id = blockIdx.x;
+    if (id < P.n_text_wg_pad) {  // text query blocks first: longest work items start earliest
+        if (id >= P.B * P.H * n_text) return;
+        const int m = P.nq_img + id % n_text;
+        const int bh = id / n_text;
+        attn_block<T, true>(P, smem, bh / P.H, bh % P.H, m);
+        return;
+    }
+    const int li = id - P.n_text_wg_pad;
+    const int bh = li / P.img_per_head;
+    const int r = li % P.img_per_head;
+    int m;
+    if (P.xcd_chunk) {  // workgroup id -> XCD is id % 8: give each XCD a contiguous range of query blocks
+        m = (r & 7) * P.xcd_chunk + (r >> 3);
+        if ((r >> 3) >= P.xcd_chunk || m >= P.nq_img) return;
+    } else {
+        m = r;
+    }
+    attn_block<T, false>(P, smem, bh / P.H, bh % P.H, m);
+}
+
+}  // namespace
+}  // namespace jenga
+
+using namespace jenga;
+
+extern "C" int jenga_bsattn_fwd(void* stream, const void* q, const void* k, const void* vt, void* o,
+                                const int32_t* seqlens, const int32_t* idx, const int32_t* cnt, int64_t B, int64_t H,
+                                int64_t n_blocks, int64_t nq_img, int64_t q_sb, int64_t q_ss, int64_t q_sh,
+                                int64_t k_sb, int64_t k_ss, int64_t k_sh, int64_t o_sb, int64_t o_ss, int64_t o_sh,
+                                float sm_scale, float text_amp, int64_t text_block_start, int dtype, int flags) {
+    if (!q || !k || !vt || !o || B <= 0 || H <= 0 || n_blocks <= 0 || nq_img < 0 || nq_img > n_blocks) {
+        set_error("jenga_bsattn_fwd: bad arguments");
+        return JENGA_EINVAL;
+    }
+    if (nq_img > 0 && (!idx || !cnt)) {
+        set_error("jenga_bsattn_fwd: idx/cnt are required when nq_img > 0");
+        return JENGA_EINVAL;
+    }
+    const int64_t strides[9] = {q_sb, q_ss, q_sh, k_sb, k_ss, k_sh, o_sb, o_ss, o_sh};
+    for (int i = 0; i < 9; ++i)
+        if (strides[i] & 7) {
+            set_error("jenga_bsattn_fwd: strides must be multiples of 8 elements (16-byte rows)");
+            return JENGA_EINVAL;
+        }
+    if (((uintptr_t)q & 15) || ((uintptr_t)k & 15) || ((uintptr_t)vt & 15) || ((uintptr_t)o & 15)) {
+        set_error("jenga_bsattn_fwd: pointers must be 16-byte aligned");
+        return JENGA_EINVAL;
+    }
+    if (dtype != JENGA_BF16 && dtype != JENGA_FP16) {
+        set_error("jenga_bsattn_fwd: dtype must be bf16 or fp16");
+        return JENGA_EUNSUPPORTED;
+    }
+    AttnParams P;
+    P.q = (const uint16_t*)q;
+    P.k = (const uint16_t*)k;
+    P.vt = (const uint16_t*)vt;
+    P.o = (uint16_t*)o;
+    P.seqlens = seqlens;
+    P.idx = idx;
+    P.cnt = cnt;
+    P.q_sb = q_sb; P.q_ss = q_ss; P.q_sh = q_sh;
+    P.k_sb = k_sb; P.k_ss = k_ss; P.k_sh = k_sh;
+    P.o_sb = o_sb; P.o_ss = o_ss; P.o_sh = o_sh;
+    P.B = (int)B; P.H = (int)H; P.n_blocks = (int)n_blocks; P.nq_img = (int)nq_img;
+    P.text_block_start = (int)text_block_start;
+    P.qk_scale = (float)((double)sm_scale * 1.44269504);
+    P.text_amp = text_amp;
+    const long long n_text = n_blocks - nq_img;
+    const long long n_text_wg = B * H * n_text;
+    P.n_text_wg_pad = (int)((n_text_wg + 7) / 8 * 8);
+    if ((flags & JENGA_ATTN_XCD_REMAP) && nq_img >= 64) {
+        P.xcd_chunk = (int)((nq_img + 7) / 8);
+        P.img_per_head = P.xcd_chunk * 8;
+    } else {
+        P.xcd_chunk = 0;
+        P.img_per_head = (int)nq_img;
+    }
+    const long long grid = (long long)P.n_text_wg_pad + B * H * (long long)P.img_per_head;
+    if (grid <= 0 || grid > 0x7fffffffLL) {
+        set_error("jenga_bsattn_fwd: grid size %lld out of range", grid);
+        return JENGA_EINVAL;
+    }
+    const size_t smem = 2 * BUF_BYTES;
+    hipError_t e;
+    if (dtype == JENGA_BF16) {
+        static bool attr_done = false;
+        if (!attr_done) {
+            (void)hipFuncSetAttribute((const void*)bsattn_fwd_kernel<BF16>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      (int)smem);
+            attr_done = true;
+        }
+        hipLaunchKernelGGL(bsattn_fwd_kernel<BF16>, dim3((unsigned)grid), dim3(256), smem, (hipStream_t)stream, P);
+    } else {
+        static bool attr_done16 = false;
+        if (!attr_done16) {
+            (void)hipFuncSetAttribute((const void*)bsattn_fwd_kernel<FP16>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      (int)smem);
+            attr_done16 = true;
+        }
+        hipLaunchKernelGGL(bsattn_fwd_kernel<FP16>, dim3((unsigned)grid), dim3(256), smem, (hipStream_t)stream, P);
+    }
+    e = hipGetLastError();
+    if (e != hipSuccess) {
+        set_error("jenga_bsattn_fwd: %s", hipGetErrorString(e));
+        return JENGA_ELAUNCH;
+    }
+    return JENGA_OK;
+}

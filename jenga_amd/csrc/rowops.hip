@@ -1,0 +1,301 @@
+// HBM-bound row kernels: Hilbert gather/scatter, fused per-head RMSNorm + RoPE, 128-token block pooling,
+// V re-tiling for the P.V product, Ulysses head pack/unpack.  All move 16 bytes per lane per access.
+// Compiled with -ffp-contract=off: the reference's eager fp32 arithmetic has no fused multiply-adds.
+#include "common.h"
+
+namespace jenga {
+namespace {
+
+// ------------------------------------------------------------------------------------------------ gather
+// dst[b, i, :] = src[b, index[i], :]; one workgroup per output row (grid-stride), 16 B per lane.
+__global__ void gather_rows_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst,
+                                   const int64_t* __restrict__ index, long long batch, long long n_rows,
+                                   int vec_per_row, long long src_bs, long long dst_bs) {
+    const long long total = batch * n_rows;
+    for (long long r = blockIdx.x; r < total; r += gridDim.x) {
+        const long long b = r / n_rows, i = r % n_rows;
+        const long long s = index[i];
+        const uint4* sp = src + b * src_bs + s * vec_per_row;
+        uint4* dp = dst + b * dst_bs + i * vec_per_row;
+        for (int v = threadIdx.x; v < vec_per_row; v += blockDim.x) dp[v] = sp[v];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ RMSNorm + RoPE
+// 16 lanes own one (token, head) row of 128 elements (8 each); a wave covers 4 heads of one token, a 256-thread
+// workgroup 16 heads; the cos/sin row of the token is shared by all heads (L1/L2 hits).
+template <typename T>
+__global__ void rmsnorm_rope_kernel(const uint16_t* __restrict__ x, uint16_t* __restrict__ out,
+                                    const uint16_t* __restrict__ weight, const float* __restrict__ cosT,
+                                    const float* __restrict__ sinT, long long B, long long S, long long H,
+                                    long long x_sb, long long x_ss, long long x_sh, long long o_sb, long long o_ss,
+                                    long long o_sh, long long s_rope, float eps) {
+    const int sub = threadIdx.x & 15;          // 8-element slice of the row
+    const int rig = threadIdx.x >> 4;          // row-in-group (0..15)
+    const long long rows = B * S * H;
+    float wv[8];
+    if (weight) {
+        unpack8<T>(*reinterpret_cast<const uint4*>(weight + sub * 8), wv);
+    }
+    for (long long row = (long long)blockIdx.x * 16 + rig; row < rows; row += (long long)gridDim.x * 16) {
+        const long long h = row % H, s = (row / H) % S, b = row / (H * S);
+        float f[8];
+        unpack8<T>(*reinterpret_cast<const uint4*>(x + b * x_sb + s * x_ss + h * x_sh + sub * 8), f);
+        if (eps >= 0.f) {  // eps < 0: RoPE only (apply_rotary_emb on already-normalised tensors)
+            float ss = 0.f;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) ss = __fadd_rn(ss, __fmul_rn(f[i], f[i]));
+            ss += __shfl_xor(ss, 1);
+            ss += __shfl_xor(ss, 2);
+            ss += __shfl_xor(ss, 4);
+            ss += __shfl_xor(ss, 8);
+            const float r = __fdiv_rn(1.0f, __fsqrt_rn(__fadd_rn(__fdiv_rn(ss, 128.0f), eps)));
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                float y = round_to<T>(__fmul_rn(f[i], r));                // ._norm(x.float()).type_as(x)
+                if (weight) y = round_to<T>(__fmul_rn(y, wv[i]));        // * weight (dtype * dtype -> dtype)
+                f[i] = y;
+            }
+        }
+        if (cosT && s < s_rope) {
+            const float4* cp = reinterpret_cast<const float4*>(cosT + s * 128 + sub * 8);
+            const float4* sp = reinterpret_cast<const float4*>(sinT + s * 128 + sub * 8);
+            const float4 c0 = cp[0], c1 = cp[1], s0 = sp[0], s1 = sp[1];
+            const float c[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
+            const float sn[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+            float g[8];
+#pragma unroll
+            for (int i = 0; i < 8; i += 2) {  // rotate_half: (x0,x1) -> (-x1, x0)
+                g[i] = __fadd_rn(__fmul_rn(f[i], c[i]), __fmul_rn(-f[i + 1], sn[i]));
+                g[i + 1] = __fadd_rn(__fmul_rn(f[i + 1], c[i + 1]), __fmul_rn(f[i], sn[i + 1]));
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) f[i] = g[i];
+        }
+        *reinterpret_cast<uint4*>(out + b * o_sb + s * o_ss + h * o_sh + sub * 8) = pack8<T>(f);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ block pooling
+// One workgroup per (b, h, block): 128 tokens x 128 dims.  thread -> (token group tg = t/16, slice = t%16);
+// each thread sums 8 tokens in fp32, LDS tree over the 16 groups, one rounding of mean to dtype.
+template <typename T>
+__global__ void block_pool_kernel(const uint16_t* __restrict__ x, uint16_t* __restrict__ pooled, long long B,
+                                  long long H, long long nb, long long x_sb, long long x_ss, long long x_sh) {
+    __shared__ float red[16][129];
+    const int sub = threadIdx.x & 15, tg = threadIdx.x >> 4;
+    for (long long blk = blockIdx.x; blk < B * H * nb; blk += gridDim.x) {
+        const long long j = blk % nb, h = (blk / nb) % H, b = blk / (nb * H);
+        float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        const uint16_t* base = x + b * x_sb + (j * 128) * x_ss + h * x_sh + sub * 8;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            float f[8];
+            unpack8<T>(*reinterpret_cast<const uint4*>(base + (long long)(tg * 8 + i) * x_ss), f);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] += f[e];
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) red[tg][sub * 8 + e] = acc[e];
+        __syncthreads();
+        if (threadIdx.x < 128) {
+            float s = 0.f;
+#pragma unroll
+            for (int g = 0; g < 16; ++g) s += red[g][threadIdx.x];
+            pooled[((b * H + h) * nb + j) * 128 + threadIdx.x] = from_f32<T>(s / 128.0f);
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ V re-tiling
+// vt[b][h][tile64][d = 0..127][pos = 0..63] with pos -> key = 32*(pos>>5) + pv_key_of_pos(pos&31): each lane
+// of the attention kernel then reads its 8 P.V operand values of one d-row as ONE 16-byte LDS read.
+// One workgroup per (b, h, tile64); transposition through LDS.
+__global__ void pack_v_kernel(const uint16_t* __restrict__ v, uint16_t* __restrict__ vt, long long B, long long H,
+                              long long ntile, long long v_sb, long long v_ss, long long v_sh) {
+    __shared__ uint16_t tile[64][136];  // +8 halfwords: rows stay 16-B aligned, column reads spread over banks
+    for (long long wg = blockIdx.x; wg < B * H * ntile; wg += gridDim.x) {
+        const long long tI = wg % ntile, h = (wg / ntile) % H, b = wg / (ntile * H);
+        const uint16_t* src = v + b * v_sb + (tI * 64) * v_ss + h * v_sh;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = i * 16 + (threadIdx.x >> 4), c = threadIdx.x & 15;
+            *reinterpret_cast<uint4*>(&tile[row][c * 8]) =
+                *reinterpret_cast<const uint4*>(src + (long long)row * v_ss + c * 8);
+        }
+        __syncthreads();
+        uint16_t* dst = vt + wg * (128 * 64);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int chunk = i * 256 + threadIdx.x;   // 1024 chunks of 8 positions
+            const int d = chunk >> 3, pc = chunk & 7;  // row d, positions pc*8 .. pc*8+7
+            uint32_t w[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int p0 = pc * 8 + 2 * e, p1 = p0 + 1;
+                const int k0 = (p0 & 32) + pv_key_of_pos(p0 & 31), k1 = (p1 & 32) + pv_key_of_pos(p1 & 31);
+                w[e] = (uint32_t)tile[k0][d] | ((uint32_t)tile[k1][d] << 16);
+            }
+            *reinterpret_cast<uint4*>(dst + d * 64 + pc * 8) = make_uint4(w[0], w[1], w[2], w[3]);
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ Ulysses pack
+// x[b, s, r*Hn + hl, :]  <->  buf[r][b][s][hl][:]   (Hn = H / N); one 256-byte head row per 16 lanes.
+template <bool PACK>
+__global__ void ulysses_heads_kernel(const uint4* __restrict__ in, uint4* __restrict__ outp, long long B, long long S,
+                                     long long H, long long N, long long sb, long long ss, long long sh) {
+    const long long Hn = H / N, rows = B * S * H;
+    const int sub = threadIdx.x & 15, rig = threadIdx.x >> 4;
+    for (long long row = (long long)blockIdx.x * 16 + rig; row < rows; row += (long long)gridDim.x * 16) {
+        const long long h = row % H, s = (row / H) % S, b = row / (H * S);
+        const long long r = h / Hn, hl = h % Hn;
+        const long long strided = (b * sb + s * ss + h * sh) / 8 + sub;                 // in uint4 units
+        const long long packed = ((((r * B + b) * S + s) * Hn + hl) * 128) / 8 + sub;
+        if (PACK)
+            outp[packed] = in[strided];
+        else
+            outp[strided] = in[packed];
+    }
+}
+
+inline int grid_for(long long work_items, int cap = 16384) {
+    if (work_items < 1) work_items = 1;
+    return (int)(work_items > cap ? cap : work_items);
+}
+
+}  // namespace
+}  // namespace jenga
+
+using namespace jenga;
+
+#define JENGA_CHECK_LAUNCH(name)                          \
+    do {                                                  \
+        hipError_t e_ = hipGetLastError();                \
+        if (e_ != hipSuccess) {                           \
+            set_error(name ": %s", hipGetErrorString(e_)); \
+            return JENGA_ELAUNCH;                         \
+        }                                                 \
+    } while (0)
+
+extern "C" int jenga_gather_rows(void* stream, const void* src, void* dst, const int64_t* index, int64_t batch,
+                                 int64_t n_rows, int64_t row_bytes, int64_t src_bs, int64_t dst_bs) {
+    if (!src || !dst || !index || batch < 0 || n_rows < 0 || row_bytes <= 0 || (row_bytes & 15) || (src_bs & 15) ||
+        (dst_bs & 15) || ((uintptr_t)src & 15) || ((uintptr_t)dst & 15)) {
+        set_error("jenga_gather_rows: rows must be 16-byte multiples and 16-byte aligned (row_bytes=%lld)",
+                  (long long)row_bytes);
+        return JENGA_EINVAL;
+    }
+    if (batch * n_rows == 0) return JENGA_OK;
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(grid_for(batch * n_rows, 65536)), dim3(256), 0, (hipStream_t)stream,
+                       (const uint4*)src, (uint4*)dst, index, (long long)batch, (long long)n_rows,
+                       (int)(row_bytes / 16), (long long)(src_bs / 16), (long long)(dst_bs / 16));
+    JENGA_CHECK_LAUNCH("jenga_gather_rows");
+    return JENGA_OK;
+}
+
+static bool strides_ok(int64_t a, int64_t b, int64_t c) { return !(a & 7) && !(b & 7) && !(c & 7); }
+
+extern "C" int jenga_rmsnorm_rope(void* stream, const void* x, void* out, const void* weight, const float* cosT,
+                                  const float* sinT, int64_t B, int64_t S, int64_t H, int64_t x_sb, int64_t x_ss,
+                                  int64_t x_sh, int64_t o_sb, int64_t o_ss, int64_t o_sh, int64_t s_rope, float eps,
+                                  int dtype) {
+    if (!x || !out || B < 0 || S < 0 || H < 0 || !strides_ok(x_sb, x_ss, x_sh) || !strides_ok(o_sb, o_ss, o_sh) ||
+        ((uintptr_t)x & 15) || ((uintptr_t)out & 15) || ((cosT == nullptr) != (sinT == nullptr))) {
+        set_error("jenga_rmsnorm_rope: bad arguments (strides must be multiples of 8 elements, pointers 16-B aligned)");
+        return JENGA_EINVAL;
+    }
+    if (dtype != JENGA_BF16 && dtype != JENGA_FP16) {
+        set_error("jenga_rmsnorm_rope: dtype must be bf16 or fp16");
+        return JENGA_EUNSUPPORTED;
+    }
+    const long long rows = (long long)B * S * H;
+    if (rows == 0) return JENGA_OK;
+    const int grid = grid_for((rows + 15) / 16, 32768);
+#define LAUNCH_NR(T)                                                                                               \
+    hipLaunchKernelGGL(rmsnorm_rope_kernel<T>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)x,  \
+                       (uint16_t*)out, (const uint16_t*)weight, cosT, sinT, (long long)B, (long long)S,            \
+                       (long long)H, (long long)x_sb, (long long)x_ss, (long long)x_sh, (long long)o_sb,           \
+                       (long long)o_ss, (long long)o_sh, (long long)s_rope, eps)
+    if (dtype == JENGA_BF16) LAUNCH_NR(BF16); else LAUNCH_NR(FP16);
+#undef LAUNCH_NR
+    JENGA_CHECK_LAUNCH("jenga_rmsnorm_rope");
+    return JENGA_OK;
+}
+
+extern "C" int jenga_block_pool(void* stream, const void* x, void* pooled, int64_t B, int64_t H, int64_t n_blocks,
+                                int64_t x_sb, int64_t x_ss, int64_t x_sh, int dtype) {
+    if (!x || !pooled || B < 0 || H < 0 || n_blocks < 0 || !strides_ok(x_sb, x_ss, x_sh) || ((uintptr_t)x & 15)) {
+        set_error("jenga_block_pool: bad arguments");
+        return JENGA_EINVAL;
+    }
+    if (dtype != JENGA_BF16 && dtype != JENGA_FP16) {
+        set_error("jenga_block_pool: dtype must be bf16 or fp16");
+        return JENGA_EUNSUPPORTED;
+    }
+    const long long n = (long long)B * H * n_blocks;
+    if (n == 0) return JENGA_OK;
+#define LAUNCH_BP(T)                                                                                              \
+    hipLaunchKernelGGL(block_pool_kernel<T>, dim3(grid_for(n, 65536)), dim3(256), 0, (hipStream_t)stream,         \
+                       (const uint16_t*)x, (uint16_t*)pooled, (long long)B, (long long)H, (long long)n_blocks,    \
+                       (long long)x_sb, (long long)x_ss, (long long)x_sh)
+    if (dtype == JENGA_BF16) LAUNCH_BP(BF16); else LAUNCH_BP(FP16);
+#undef LAUNCH_BP
+    JENGA_CHECK_LAUNCH("jenga_block_pool");
+    return JENGA_OK;
+}
+
+extern "C" size_t jenga_pack_v_bytes(int64_t B, int64_t H, int64_t n_blocks) {
+    return (size_t)B * H * n_blocks * 128 * 128 * 2;
+}
+
+extern "C" int jenga_pack_v(void* stream, const void* v, void* vt, int64_t B, int64_t H, int64_t n_blocks,
+                            int64_t v_sb, int64_t v_ss, int64_t v_sh, int dtype) {
+    if (!v || !vt || B < 0 || H < 0 || n_blocks < 0 || !strides_ok(v_sb, v_ss, v_sh) || ((uintptr_t)v & 15) ||
+        ((uintptr_t)vt & 15)) {
+        set_error("jenga_pack_v: bad arguments");
+        return JENGA_EINVAL;
+    }
+    (void)dtype;  // pure 16-bit data movement
+    const long long n = (long long)B * H * n_blocks * 2;
+    if (n == 0) return JENGA_OK;
+    hipLaunchKernelGGL(pack_v_kernel, dim3(grid_for(n, 65536)), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)v,
+                       (uint16_t*)vt, (long long)B, (long long)H, (long long)(n_blocks * 2), (long long)v_sb,
+                       (long long)v_ss, (long long)v_sh);
+    JENGA_CHECK_LAUNCH("jenga_pack_v");
+    return JENGA_OK;
+}
+
+static int ulysses_common(bool pack, void* stream, const void* in, void* outp, int64_t B, int64_t S, int64_t H,
+                          int64_t N, int64_t sb, int64_t ss, int64_t sh) {
+    if (!in || !outp || N <= 0 || H % N || !strides_ok(sb, ss, sh) || ((uintptr_t)in & 15) || ((uintptr_t)outp & 15)) {
+        set_error("jenga_ulysses_%s_heads: bad arguments (H=%lld must be divisible by N=%lld)", pack ? "pack" : "unpack",
+                  (long long)H, (long long)N);
+        return JENGA_EINVAL;
+    }
+    const long long rows = (long long)B * S * H;
+    if (rows == 0) return JENGA_OK;
+    const int grid = grid_for((rows + 15) / 16, 32768);
+    if (pack)
+        hipLaunchKernelGGL(ulysses_heads_kernel<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const uint4*)in,
+                           (uint4*)outp, (long long)B, (long long)S, (long long)H, (long long)N, (long long)sb,
+                           (long long)ss, (long long)sh);
+    else
+        hipLaunchKernelGGL(ulysses_heads_kernel<false>, dim3(grid), dim3(256), 0, (hipStream_t)stream,
+                           (const uint4*)in, (uint4*)outp, (long long)B, (long long)S, (long long)H, (long long)N,
+                           (long long)sb, (long long)ss, (long long)sh);
+    JENGA_CHECK_LAUNCH("jenga_ulysses_heads");
+    return JENGA_OK;
+}
+
+extern "C" int jenga_ulysses_pack_heads(void* stream, const void* x, void* send, int64_t B, int64_t S_loc, int64_t H,
+                                        int64_t N, int64_t x_sb, int64_t x_ss, int64_t x_sh) {
+    return ulysses_common(true, stream, x, send, B, S_loc, H, N, x_sb, x_ss, x_sh);
+}
+extern "C" int jenga_ulysses_unpack_heads(void* stream, const void* recv, void* y, int64_t B, int64_t S_loc, int64_t H,
+                                          int64_t N, int64_t y_sb, int64_t y_ss, int64_t y_sh) {
+    return ulysses_common(false, stream, recv, y, B, S_loc, H, N, y_sb, y_ss, y_sh);
+}

@@ -1,0 +1,222 @@
+// Block selection: one workgroup per (batch, head, query block) row.
+//   scores -> softmax (dtype) -> sort (bitonic, LDS) -> cumulative-probability / top-k rule -> bit set
+//   -> OR static neighbours / first-frame / text columns -> ascending index list (+ optional one-hot mask).
+// Rounding points follow the reference's torch code running in the tensor dtype
+// (attention_block_triton_diffres.py:221-250); see include/jenga_amd.h.
+#include <cstring>
+
+#include "common.h"
+
+namespace jenga {
+namespace {
+
+__device__ __forceinline__ float block_reduce_max(float v, float* scratch) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    if ((threadIdx.x & 63) == 0) scratch[threadIdx.x >> 6] = v;
+    __syncthreads();
+    float r = scratch[0];
+    for (int i = 1; i < (int)(blockDim.x >> 6); ++i) r = fmaxf(r, scratch[i]);
+    __syncthreads();
+    return r;
+}
+__device__ __forceinline__ float block_reduce_sum(float v, float* scratch) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    if ((threadIdx.x & 63) == 0) scratch[threadIdx.x >> 6] = v;
+    __syncthreads();
+    float r = scratch[0];
+    for (int i = 1; i < (int)(blockDim.x >> 6); ++i) r += scratch[i];
+    __syncthreads();
+    return r;
+}
+
+constexpr int MAX_PER_THREAD = 8;  // 256 threads x 8 = up to 2048 image key blocks
+
+template <typename T>
+__global__ void __launch_bounds__(256)
+block_select_kernel(const uint16_t* __restrict__ qpool, const uint16_t* __restrict__ kpool,
+                    const uint8_t* __restrict__ neighbors, int nb_rows, int nb_cols, uint8_t* __restrict__ mask,
+                    int32_t* __restrict__ idx, int32_t* __restrict__ cnt, int H, int nq, int nk_img, int text_blocks,
+                    int top_k, float p_thr, int first_frame_blocks, int npow2) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint32_t* keys = reinterpret_cast<uint32_t*>(smem);                 // [npow2]
+    float* qrow = reinterpret_cast<float*>(keys + npow2);               // [128]
+    uint32_t* bits = reinterpret_cast<uint32_t*>(qrow + 128);           // [80]: up to 2048+ columns
+    uint32_t* wpre = bits + 80;                                         // [80] exclusive popcount prefix
+    float* scratch = reinterpret_cast<float*>(wpre + 80);               // [8]
+    int* n_sh = reinterpret_cast<int*>(scratch + 8);                    // [1]
+
+    const int nk_all = nk_img + text_blocks;
+    const long long row = blockIdx.x;  // (b*H + h)*nq + m
+    const int m = (int)(row % nq);
+    const long long bh = row / nq;
+    const int tid = threadIdx.x;
+
+    if (tid < 128) qrow[tid] = to_f32<T>(qpool[row * 128 + tid]);
+    if (tid < 80) bits[tid] = 0u;
+    __syncthreads();
+
+    // ---- pooled scores for the image columns (K3) ----
+    const float scale = 0.08838834764831845f;  // float(128 ** -0.5)
+    float sc[MAX_PER_THREAD];
+    float lmax = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < MAX_PER_THREAD; ++i) {
+        const int j = tid + i * 256;
+        sc[i] = -INFINITY;
+        if (j < nk_img) {
+            const uint4* kr = reinterpret_cast<const uint4*>(kpool + (bh * nk_all + j) * 128);
+            float acc = 0.f;
+#pragma unroll
+            for (int c = 0; c < 16; ++c) {
+                float f[8];
+                unpack8<T>(kr[c], f);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc = fmaf(qrow[c * 8 + e], f[e], acc);
+            }
+            sc[i] = round_to<T>(round_to<T>(acc) * scale);
+            lmax = fmaxf(lmax, sc[i]);
+        }
+    }
+    // ---- softmax over the image columns, rounded to dtype (K4) ----
+    const float rmax = block_reduce_max(lmax, scratch);
+    float lsum = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAX_PER_THREAD; ++i) {
+        const int j = tid + i * 256;
+        if (j < nk_img) {
+            sc[i] = expf(sc[i] - rmax);
+            lsum += sc[i];
+        }
+    }
+    const float rsum = block_reduce_sum(lsum, scratch);
+#pragma unroll
+    for (int i = 0; i < MAX_PER_THREAD; ++i) {
+        const int j = tid + i * 256;
+        if (j < npow2) {
+            uint32_t key = 0u;  // padding sorts last
+            if (j < nk_img) key = ((uint32_t)from_f32<T>(sc[i] / rsum) << 16) | (uint32_t)(0xFFFF - j);
+            keys[j] = key;
+        }
+    }
+    __syncthreads();
+    // ---- bitonic sort, descending on (probability bits, then lower column first) ----
+    for (int k = 2; k <= npow2; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = tid; i < npow2; i += 256) {
+                const int l = i ^ j;
+                if (l > i) {
+                    const uint32_t a = keys[i], b = keys[l];
+                    const bool desc = ((i & k) == 0);
+                    if (desc ? (a < b) : (a > b)) {
+                        keys[i] = b;
+                        keys[l] = a;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    // ---- n = max(#(cumsum <= p) + 1, top_k): sequential fp32 accumulation, each partial rounded to dtype ----
+    if (tid == 0) {
+        float acc = 0.f;
+        int count = 0;
+        for (int i = 0; i < nk_img; ++i) {
+            acc = acc + to_f32<T>((uint16_t)(keys[i] >> 16));
+            if (round_to<T>(acc) <= p_thr)
+                ++count;
+            else
+                break;  // partial sums are non-decreasing
+        }
+        int n = count + 1;
+        if (n < top_k) n = top_k;
+        if (n > nk_img) n = nk_img;
+        *n_sh = n;
+    }
+    __syncthreads();
+    const int n = *n_sh;
+    for (int i = tid; i < n; i += 256) {
+        const int col = 0xFFFF - (int)(keys[i] & 0xFFFFu);
+        atomicOr(&bits[col >> 5], 1u << (col & 31));
+    }
+    if (neighbors && m < nb_rows) {
+        const int lim = nk_img < nb_cols ? nk_img : nb_cols;
+        const uint8_t* nr = neighbors + (long long)m * nb_cols;
+        for (int j = tid; j < lim; j += 256)
+            if (nr[j]) atomicOr(&bits[j >> 5], 1u << (j & 31));
+    }
+    if (m < first_frame_blocks) {
+        const int lim = first_frame_blocks < nk_all ? first_frame_blocks : nk_all;
+        for (int j = tid; j < lim; j += 256) atomicOr(&bits[j >> 5], 1u << (j & 31));
+    }
+    for (int j = nk_img + tid; j < nk_all; j += 256) atomicOr(&bits[j >> 5], 1u << (j & 31));
+    __syncthreads();
+    // ---- ascending compaction ----
+    const int nwords = (nk_all + 31) >> 5;
+    if (tid < nwords) {
+        int pre = 0;
+        for (int w = 0; w < tid; ++w) pre += __popc(bits[w]);
+        wpre[tid] = (uint32_t)pre;
+        if (tid == nwords - 1 && cnt) cnt[row] = pre + __popc(bits[tid]);
+    }
+    __syncthreads();
+    for (int j = tid; j < nk_all; j += 256) {
+        const uint32_t w = bits[j >> 5];
+        const bool on = (w >> (j & 31)) & 1u;
+        if (mask) mask[row * nk_all + j] = on ? 1 : 0;
+        if (on && idx) idx[row * nk_all + (int)wpre[j >> 5] + __popc(w & ((1u << (j & 31)) - 1u))] = j;
+    }
+}
+
+}  // namespace
+}  // namespace jenga
+
+using namespace jenga;
+
+extern "C" int jenga_block_select(void* stream, const void* qpool, const void* kpool, const uint8_t* neighbors,
+                                  int64_t nb_rows, int64_t nb_cols, uint8_t* mask, int32_t* idx, int32_t* cnt,
+                                  int64_t B, int64_t H, int64_t nq, int64_t nk_img, int64_t text_blocks, int64_t top_k,
+                                  float p, int64_t first_frame_blocks, int dtype) {
+    if (!qpool || !kpool || B < 0 || H < 0 || nq < 0 || nk_img <= 0 || text_blocks < 0 || top_k < 0) {
+        set_error("jenga_block_select: bad arguments");
+        return JENGA_EINVAL;
+    }
+    if (nk_img > 256 * MAX_PER_THREAD || nk_img + text_blocks > 80 * 32 || nk_img > 0xFFFF) {
+        set_error("jenga_block_select: at most %d image key blocks supported (got %lld)", 256 * MAX_PER_THREAD,
+                  (long long)nk_img);
+        return JENGA_EUNSUPPORTED;
+    }
+    if (dtype != JENGA_BF16 && dtype != JENGA_FP16) {
+        set_error("jenga_block_select: dtype must be bf16 or fp16");
+        return JENGA_EUNSUPPORTED;
+    }
+    const long long rows = (long long)B * H * nq;
+    if (rows == 0) return JENGA_OK;
+    int npow2 = 2;
+    while (npow2 < nk_img) npow2 <<= 1;
+    const size_t smem = (size_t)npow2 * 4 + 128 * 4 + 80 * 4 * 2 + 8 * 4 + 16;
+    // the reference compares the dtype cumsum with a Python float: the scalar is rounded to the tensor dtype
+    float p_thr;
+    if (dtype == JENGA_BF16) {
+        uint32_t u;
+        std::memcpy(&u, &p, 4);
+        u = (u + 0x7FFFu + ((u >> 16) & 1u)) & 0xFFFF0000u;
+        std::memcpy(&p_thr, &u, 4);
+    } else {
+        p_thr = (float)(_Float16)p;
+    }
+#define LAUNCH_SEL(T)                                                                                                 \
+    hipLaunchKernelGGL(block_select_kernel<T>, dim3((unsigned)rows), dim3(256), smem, (hipStream_t)stream,            \
+                       (const uint16_t*)qpool, (const uint16_t*)kpool, neighbors, (int)nb_rows, (int)nb_cols, mask,   \
+                       idx, cnt, (int)H, (int)nq, (int)nk_img, (int)text_blocks, (int)top_k, p_thr,                   \
+                       (int)first_frame_blocks, npow2)
+    if (dtype == JENGA_BF16) LAUNCH_SEL(BF16); else LAUNCH_SEL(FP16);
+#undef LAUNCH_SEL
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        set_error("jenga_block_select: %s", hipGetErrorString(e));
+        return JENGA_ELAUNCH;
+    }
+    return JENGA_OK;
+}

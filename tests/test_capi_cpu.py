@@ -1,0 +1,56 @@
+"""CPU: the C-ABI library builds, loads, and exports every symbol include/jenga_amd.h declares; host-side
+argument validation; no compute (there is no GPU here)."""
+import os
+import re
+import subprocess
+
+import pytest
+import torch
+
+from jenga_amd import _capi, build
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_builds_and_loads():
+    build.build()
+    L = _capi.lib()
+    assert L.jenga_abi_version() == 1
+
+
+def test_header_symbols_exported():
+    header = open(os.path.join(ROOT, "include", "jenga_amd.h")).read()
+    declared = set(re.findall(r"\b(jenga_[a-z0-9_]+)\s*\(", header))
+    out = subprocess.check_output(["nm", "-D", "--defined-only", _capi.LIB_PATH]).decode()
+    exported = {ln.split()[-1] for ln in out.splitlines() if " T " in ln}
+    assert declared, "no declarations parsed"
+    assert declared <= exported, f"missing: {declared - exported}"
+    assert declared == set(_capi.SIGNATURES), "ctypes binding out of sync with the header"
+
+
+def test_no_cpu_fallback():
+    q = torch.zeros(1, 256, 2, 128, dtype=torch.bfloat16)
+    with pytest.raises(_capi.JengaError):
+        _capi.block_pool(q, 2)
+    from jenga_amd.modules.attention_block_sparse import block_sparse_attention
+    cu = torch.tensor([0, 200, 256], dtype=torch.int32)
+    with pytest.raises(_capi.JengaError):
+        block_sparse_attention(q, q, q, top_k=1, cu_seqlens_q=cu, cu_seqlens_kv=cu, text_blocks=1)
+
+
+def test_argument_errors_mirror_the_reference_contract():
+    from jenga_amd.modules.attention_block_sparse import block_sparse_attention
+    cu = torch.tensor([0, 200, 256], dtype=torch.int32)
+    q32 = torch.zeros(1, 256, 2, 128)
+    with pytest.raises(ValueError):  # dtype not in {bf16, fp16} (reference :167-170 would mis-type it silently)
+        block_sparse_attention(q32, q32, q32, top_k=1, cu_seqlens_q=cu, cu_seqlens_kv=cu)
+    q = torch.zeros(1, 200, 2, 128, dtype=torch.bfloat16)
+    with pytest.raises((ValueError, _capi.JengaError)):  # S % 128 != 0: the reference's reshape would throw (:216)
+        block_sparse_attention(q, q, q, top_k=1, cu_seqlens_q=cu, cu_seqlens_kv=cu)
+    q64 = torch.zeros(1, 256, 2, 64, dtype=torch.bfloat16)
+    with pytest.raises((ValueError, _capi.JengaError)):
+        block_sparse_attention(q64, q64, q64, top_k=1, cu_seqlens_q=cu, cu_seqlens_kv=cu)
+
+
+def test_pack_v_bytes():
+    assert _capi.lib().jenga_pack_v_bytes(1, 24, 902) == 24 * 902 * 128 * 128 * 2
