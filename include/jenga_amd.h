@@ -100,7 +100,9 @@ int jenga_block_select(void* stream, const void* qpool, const void* kpool, const
  * flash_attn_func call for the text query blocks (:371-380), in ONE launch.
  *
  * Step 1, jenga_pack_v: re-tiles V into the MFMA operand order used by the P.V product
- *   vt workspace bytes = B*H*n_blocks*128*128*2; n_blocks = S/128.
+ *   vt workspace bytes = B*H*dst_blocks_total*128*128*2.  v [B, n_blocks*128, H, 128] strided supplies kv blocks
+ *   [dst_block0, dst_block0 + n_blocks) of the workspace, so image and text V (separate GEMM outputs in the
+ *   double-stream blocks) are packed without a torch.cat.
  * Step 2, jenga_bsattn_fwd:
  *   q,k,o [B,S,H,128] strided (S = n_blocks*128), vt from step 1, seqlens int32 [B] (device),
  *   image query blocks m < nq_img use idx/cnt (layout of jenga_block_select, row stride = n_blocks):
@@ -112,7 +114,7 @@ int jenga_block_select(void* stream, const void* qpool, const void* kpool, const
  *   idx/cnt may be NULL when nq_img == 0 (fully dense: sa_drop_rate == 0 for a single segment). */
 size_t jenga_pack_v_bytes(int64_t B, int64_t H, int64_t n_blocks);
 int jenga_pack_v(void* stream, const void* v, void* vt, int64_t B, int64_t H, int64_t n_blocks, int64_t v_sb,
-                 int64_t v_ss, int64_t v_sh, int dtype);
+                 int64_t v_ss, int64_t v_sh, int64_t dst_block0, int64_t dst_blocks_total, int dtype);
 int jenga_bsattn_fwd(void* stream, const void* q, const void* k, const void* vt, void* o,
                      const int32_t* seqlens, const int32_t* idx, const int32_t* cnt, int64_t B, int64_t H,
                      int64_t n_blocks, int64_t nq_img, int64_t q_sb, int64_t q_ss, int64_t q_sh, int64_t k_sb,

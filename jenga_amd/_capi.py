@@ -25,7 +25,7 @@ SIGNATURES = {
     "jenga_block_pool": (_i32, [_vp, _vp, _vp] + [_i64] * 6 + [_i32]),
     "jenga_block_select": (_i32, [_vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp] + [_i64] * 6 + [_f32, _i64, _i32]),
     "jenga_pack_v_bytes": (ctypes.c_size_t, [_i64, _i64, _i64]),
-    "jenga_pack_v": (_i32, [_vp, _vp, _vp] + [_i64] * 6 + [_i32]),
+    "jenga_pack_v": (_i32, [_vp, _vp, _vp] + [_i64] * 8 + [_i32]),
     "jenga_bsattn_fwd": (_i32, [_vp] * 8 + [_i64] * 13 + [_f32, _f32, _i64, _i32, _i32]),
     "jenga_ulysses_pack_heads": (_i32, [_vp, _vp, _vp] + [_i64] * 7),
     "jenga_ulysses_unpack_heads": (_i32, [_vp, _vp, _vp] + [_i64] * 7),
@@ -197,17 +197,23 @@ def block_select(qpool, kpool, neighbors, nk_img, text_blocks, top_k, p, first_f
     return mask, idx, cnt
 
 
-def pack_v(v, n_blocks):
-    """v [B,S,H,128] -> opaque re-tiled workspace for bsattn_fwd."""
+def pack_v(v, n_blocks=None, out=None, dst_block0=0, dst_blocks_total=None):
+    """v [B,S,H,128] -> opaque re-tiled workspace [B,H,2*blocks_total,128,64] for bsattn_fwd.
+    With out/dst_block0/dst_blocks_total a part (e.g. image or text V) fills its slice of a shared workspace."""
     _need_gpu(v, "pack_v")
     B, S, H, D = v.shape
+    if n_blocks is None:
+        n_blocks = S // 128
     if D != 128 or n_blocks * 128 != S:
         raise ValueError("pack_v: S must equal n_blocks*128 and head_dim 128")
-    vt = torch.empty((B, H, n_blocks * 2, 128, 64), dtype=v.dtype, device=v.device)
+    if dst_blocks_total is None:
+        dst_blocks_total = n_blocks if out is None else out.shape[2] // 2
+    if out is None:
+        out = torch.empty((B, H, dst_blocks_total * 2, 128, 64), dtype=v.dtype, device=v.device)
     with torch.cuda.device(v.device):
-        _check(lib().jenga_pack_v(_stream(v.device), _p(v), _p(vt), B, H, n_blocks, *_bshd_strides(v),
-                                  dtype_code(v.dtype)), "jenga_pack_v")
-    return vt
+        _check(lib().jenga_pack_v(_stream(v.device), _p(v), _p(out), B, H, n_blocks, *_bshd_strides(v),
+                                  dst_block0, dst_blocks_total, dtype_code(v.dtype)), "jenga_pack_v")
+    return out
 
 
 def bsattn_fwd(q, k, vt, seqlens, idx, cnt, nq_img, sm_scale, text_amp, text_block_start, out=None, xcd_remap=True):

@@ -113,7 +113,8 @@ __global__ void block_pool_kernel(const uint16_t* __restrict__ x, uint16_t* __re
 // of the attention kernel then reads its 8 P.V operand values of one d-row as ONE 16-byte LDS read.
 // One workgroup per (b, h, tile64); transposition through LDS.
 __global__ void pack_v_kernel(const uint16_t* __restrict__ v, uint16_t* __restrict__ vt, long long B, long long H,
-                              long long ntile, long long v_sb, long long v_ss, long long v_sh) {
+                              long long ntile, long long v_sb, long long v_ss, long long v_sh, long long dst_tile0,
+                              long long dst_ntile) {
     __shared__ uint16_t tile[64][136];  // +8 halfwords: rows stay 16-B aligned, column reads spread over banks
     for (long long wg = blockIdx.x; wg < B * H * ntile; wg += gridDim.x) {
         const long long tI = wg % ntile, h = (wg / ntile) % H, b = wg / (ntile * H);
@@ -125,7 +126,7 @@ __global__ void pack_v_kernel(const uint16_t* __restrict__ v, uint16_t* __restri
                 *reinterpret_cast<const uint4*>(src + (long long)row * v_ss + c * 8);
         }
         __syncthreads();
-        uint16_t* dst = vt + wg * (128 * 64);
+        uint16_t* dst = vt + (((b * H + h) * dst_ntile) + dst_tile0 + tI) * (128 * 64);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int chunk = i * 256 + threadIdx.x;   // 1024 chunks of 8 positions
@@ -253,9 +254,10 @@ extern "C" size_t jenga_pack_v_bytes(int64_t B, int64_t H, int64_t n_blocks) {
 }
 
 extern "C" int jenga_pack_v(void* stream, const void* v, void* vt, int64_t B, int64_t H, int64_t n_blocks,
-                            int64_t v_sb, int64_t v_ss, int64_t v_sh, int dtype) {
+                            int64_t v_sb, int64_t v_ss, int64_t v_sh, int64_t dst_block0, int64_t dst_blocks_total,
+                            int dtype) {
     if (!v || !vt || B < 0 || H < 0 || n_blocks < 0 || !strides_ok(v_sb, v_ss, v_sh) || ((uintptr_t)v & 15) ||
-        ((uintptr_t)vt & 15)) {
+        ((uintptr_t)vt & 15) || dst_block0 < 0 || dst_block0 + n_blocks > dst_blocks_total) {
         set_error("jenga_pack_v: bad arguments");
         return JENGA_EINVAL;
     }
@@ -264,7 +266,7 @@ extern "C" int jenga_pack_v(void* stream, const void* v, void* vt, int64_t B, in
     if (n == 0) return JENGA_OK;
     hipLaunchKernelGGL(pack_v_kernel, dim3(grid_for(n, 65536)), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)v,
                        (uint16_t*)vt, (long long)B, (long long)H, (long long)(n_blocks * 2), (long long)v_sb,
-                       (long long)v_ss, (long long)v_sh);
+                       (long long)v_ss, (long long)v_sh, (long long)(dst_block0 * 2), (long long)(dst_blocks_total * 2));
     JENGA_CHECK_LAUNCH("jenga_pack_v");
     return JENGA_OK;
 }

@@ -89,15 +89,16 @@ def test_rmsnorm_rope_vs_reference_golden(golden_dir, dev, tag, dt):
     nq = RMSNorm(128, dtype=tdt, device=dev)
     nq.weight.data.copy_(wq)
     y = nq(xq)
-    assert_ulp_close(to_np(y), to_np(from_bits(g[f"{tag}_nq"], dt)), dt)
+    # a 1-ulp flip of the normalised value (fp32 order of the 128-term mean) times a weight in [0.7,1.3] -> <= 2 ulp
+    assert_ulp_close(to_np(y), to_np(from_bits(g[f"{tag}_nq"], dt)), dt, max_ulps=2)
     # RoPE alone on the reference's normed tensors: bit-exact
     rq, rk = apply_rotary_emb(from_bits(g[f"{tag}_nq"], dt).to(dev), from_bits(g[f"{tag}_nk"], dt).to(dev), (cos, sin))
     assert np.array_equal(to_np(rq), to_np(from_bits(g[f"{tag}_rq"], dt)))
     assert np.array_equal(to_np(rk), to_np(from_bits(g[f"{tag}_rk"], dt)))
     # fused path: same as the two steps
     fq, fk = qk_norm_rope(xq, xk, wq, wk, (cos, sin))
-    assert_ulp_close(to_np(fq), to_np(from_bits(g[f"{tag}_rq"], dt)), dt, max_frac=2e-3)
-    assert_ulp_close(to_np(fk), to_np(from_bits(g[f"{tag}_rk"], dt)), dt, max_frac=2e-3)
+    assert_ulp_close(to_np(fq), to_np(from_bits(g[f"{tag}_rq"], dt)), dt, max_frac=2e-3, max_ulps=2, rowwise=True)
+    assert_ulp_close(to_np(fk), to_np(from_bits(g[f"{tag}_rk"], dt)), dt, max_frac=2e-3, max_ulps=2, rowwise=True)
 
 
 def test_rmsnorm_rope_strided_qkv_vs_oracle(dev):
@@ -113,7 +114,7 @@ def test_rmsnorm_rope_strided_qkv_vs_oracle(dev):
     out = _capi.rmsnorm_rope(q, w, torch.from_numpy(cos).to(dev), torch.from_numpy(sin).to(dev), s_rope=s_rope)
     ref = onr.rmsnorm(to_np(q), to_np(w), "bfloat16")
     ref[:, :s_rope] = onr.apply_rotary_emb(ref[:, :s_rope], cos, sin, "bfloat16")
-    assert_ulp_close(to_np(out), ref, "bfloat16", max_frac=2e-3)
+    assert_ulp_close(to_np(out), ref, "bfloat16", max_frac=2e-3, max_ulps=2, rowwise=True)
 
 
 # ----------------------------------------------------------------------------------------------- selection

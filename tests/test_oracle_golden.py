@@ -117,9 +117,10 @@ def test_rmsnorm_rope_bit_exact(golden_dir, tag, dt):
     nq, nk = onr.rmsnorm(xq, wq, dt), onr.rmsnorm(xk, wk, dt)
     ref_nq, ref_nk = to_np(from_bits(g[f"{tag}_nq"], dt)), to_np(from_bits(g[f"{tag}_nk"], dt))
     # RMSNorm: the fp32 order of the 128-term mean(x^2) is not specified -> a value sitting on a rounding tie may
-    # flip by one ulp of the storage dtype.  Tolerance: <= 1 ulp, on <= 0.1 % of the elements.
-    assert_ulp_close(nq, ref_nq, dt)
-    assert_ulp_close(nk, ref_nk, dt)
+    # flip by one ulp of the storage dtype, and the following `* weight` rounding can double it.
+    # Tolerance: <= 2 ulp, on <= 0.1 % of the elements.
+    assert_ulp_close(nq, ref_nq, dt, max_ulps=2)
+    assert_ulp_close(nk, ref_nk, dt, max_ulps=2)
     # RoPE on the reference's normed tensors: pure elementwise fp32 with separate roundings -> bit-exact
     rq = onr.apply_rotary_emb(ref_nq, cos, sin, dt)
     rk = onr.apply_rotary_emb(ref_nk, cos, sin, dt)
