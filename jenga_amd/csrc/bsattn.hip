@@ -50,29 +50,35 @@ constexpr int K_TILE_BYTES = KT * 128 * 2;  // 16 KiB
 constexpr int V_TILE_BYTES = 128 * KT * 2;  // 16 KiB
 constexpr int BUF_BYTES = K_TILE_BYTES + V_TILE_BYTES;
 
-struct Stage {
-    uint4 k[4];
-    uint4 v[4];
-};
-
-__device__ __forceinline__ void stage_load(Stage& st, const uint16_t* kbase, long long k_ss, const uint16_t* vtile,
-                                           int tid) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int row = i * 16 + (tid >> 4), c = tid & 15;
-        st.k[i] = *reinterpret_cast<const uint4*>(kbase + (long long)row * k_ss + c * 8);
-        st.v[i] = *reinterpret_cast<const uint4*>(vtile + (i * 256 + tid) * 8);
-    }
-}
-__device__ __forceinline__ void stage_store(const Stage& st, unsigned char* buf, int tid) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int row = i * 16 + (tid >> 4), c = tid & 15;
-        *reinterpret_cast<uint4*>(buf + row * 256 + ((c ^ (row & 15)) << 4)) = st.k[i];
-        const int d = (i * 256 + tid) >> 3, vc = tid & 7;
-        *reinterpret_cast<uint4*>(buf + K_TILE_BYTES + d * 128 + ((vc ^ ((d >> 1) & 7)) << 4)) = st.v[i];
-    }
-}
+// Register-staged prefetch (global -> VGPR early, VGPR -> LDS after the compute of the current tile).  Kept as
+// eight named uint4 registers and macros on purpose: wrapped in a struct behind a conditional, hipcc parks the
+// aggregate in scratch, which drains vmcnt right after the loads and serialises the whole pipeline.
+#define STAGE_LOAD(KPTR, VPTR)                                                                      \
+    do {                                                                                            \
+        const uint16_t* kp_ = (KPTR) + (long long)(tid >> 4) * P.k_ss + (tid & 15) * 8;             \
+        const uint16_t* vp_ = (VPTR) + tid * 8;                                                     \
+        kr0 = *reinterpret_cast<const uint4*>(kp_);                                                 \
+        kr1 = *reinterpret_cast<const uint4*>(kp_ + 16 * P.k_ss);                                   \
+        kr2 = *reinterpret_cast<const uint4*>(kp_ + 32 * P.k_ss);                                   \
+        kr3 = *reinterpret_cast<const uint4*>(kp_ + 48 * P.k_ss);                                   \
+        vr0 = *reinterpret_cast<const uint4*>(vp_);                                                 \
+        vr1 = *reinterpret_cast<const uint4*>(vp_ + 2048);                                          \
+        vr2 = *reinterpret_cast<const uint4*>(vp_ + 4096);                                          \
+        vr3 = *reinterpret_cast<const uint4*>(vp_ + 6144);                                          \
+    } while (0)
+#define STAGE_STORE(BUF)                                                                            \
+    do {                                                                                            \
+        unsigned char* kb_ = (BUF) + st_k_off;                                                      \
+        unsigned char* vb_ = (BUF) + st_v_off;                                                      \
+        *reinterpret_cast<uint4*>(kb_) = kr0;                                                       \
+        *reinterpret_cast<uint4*>(kb_ + 16 * 256) = kr1;                                            \
+        *reinterpret_cast<uint4*>(kb_ + 32 * 256) = kr2;                                            \
+        *reinterpret_cast<uint4*>(kb_ + 48 * 256) = kr3;                                            \
+        *reinterpret_cast<uint4*>(vb_) = vr0;                                                       \
+        *reinterpret_cast<uint4*>(vb_ + 32 * 128) = vr1;                                            \
+        *reinterpret_cast<uint4*>(vb_ + 64 * 128) = vr2;                                            \
+        *reinterpret_cast<uint4*>(vb_ + 96 * 128) = vr3;                                            \
+    } while (0)
 
 template <typename T, bool TEXT>
 __device__ __forceinline__ void attn_block(const AttnParams& P, unsigned char* smem, int b, int h, int m) {
@@ -128,11 +134,15 @@ __device__ __forceinline__ void attn_block(const AttnParams& P, unsigned char* s
     const int v_row_off = K_TILE_BYTES + lq * 128;  // + db*4096
     const int v_sw = (lq >> 1) & 7;
 
-    Stage st;
+    // staging: thread -> K row (tid>>4) + 16i, 16-B chunk tid&15 (rows 16i apart keep the same swizzle key);
+    //          V^T row (tid>>3) + 32i, chunk tid&7 (rows 32i apart keep the same swizzle key)
+    const int st_k_off = (tid >> 4) * 256 + (((tid & 15) ^ ((tid >> 4) & 15)) << 4);
+    const int st_v_off = K_TILE_BYTES + (tid >> 3) * 128 + (((tid & 7) ^ ((tid >> 4) & 7)) << 4);
+    uint4 kr0, kr1, kr2, kr3, vr0, vr1, vr2, vr3;
     if (ntiles > 0) {
         const int blk0 = TEXT ? 0 : list[0];
-        stage_load(st, kbh + (long long)blk0 * 128 * P.k_ss, P.k_ss, vbh + (long long)blk0 * 2 * (128 * KT), tid);
-        stage_store(st, smem, tid);
+        STAGE_LOAD(kbh + (long long)blk0 * 128 * P.k_ss, vbh + (long long)blk0 * 2 * (128 * KT));
+        STAGE_STORE(smem);
     }
     __syncthreads();
 
@@ -140,11 +150,11 @@ __device__ __forceinline__ void attn_block(const AttnParams& P, unsigned char* s
         unsigned char* cur = smem + (t & 1) * BUF_BYTES;
         const int blk = TEXT ? (t >> 1) : list[t >> 1];
         const int key0 = blk * 128 + (t & 1) * KT;
-        const bool have_next = (t + 1 < ntiles);
-        if (have_next) {
-            const int nblk = TEXT ? ((t + 1) >> 1) : list[(t + 1) >> 1];
-            const int ntile = nblk * 2 + ((t + 1) & 1);
-            stage_load(st, kbh + ((long long)ntile * KT) * P.k_ss, P.k_ss, vbh + (long long)ntile * (128 * KT), tid);
+        {   // prefetch tile t+1 (clamped: the last iteration re-fetches its own tile, which is never consumed)
+            const int tn = (t + 1 < ntiles) ? t + 1 : t;
+            const int nblk = TEXT ? (tn >> 1) : list[tn >> 1];
+            const int ntile = nblk * 2 + (tn & 1);
+            STAGE_LOAD(kbh + ((long long)ntile * KT) * P.k_ss, vbh + (long long)ntile * (128 * KT));
         }
         const bool live = TEXT || (key0 < seqlen);  // a tile entirely past seqlen contributes exp2(-inf) = 0
         if (live) {
@@ -228,7 +238,7 @@ __device__ __forceinline__ void attn_block(const AttnParams& P, unsigned char* s
                 }
             }
         }
-        if (have_next) stage_store(st, smem + ((t + 1) & 1) * BUF_BYTES, tid);
+        STAGE_STORE(smem + ((t + 1) & 1) * BUF_BYTES);
         __syncthreads();
     }
 

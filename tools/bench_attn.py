@@ -1,0 +1,86 @@
+#!/usr/bin/env python3
+"""Kernel-level micro-benchmark of the AttenCarve op at the HunyuanVideo 720p x 125f shape
+(S_img = 115200 = 900 blocks, S_txt = 256, H = 24, D = 128, bf16).  Prints one JSON line per stage.
+  python tools/bench_attn.py [--heads 24] [--drop 0.75] [--p 0.3] [--peaky 0] [--iters 5] [--no-xcd]"""
+import argparse
+import json
+import sys
+import os
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from jenga_amd import _capi, gilbert as G  # noqa: E402
+
+
+def timed(fn, iters, warmup=1):
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        out = fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters, out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--heads", type=int, default=24)
+    ap.add_argument("--grid", type=int, nargs=3, default=[32, 45, 80])
+    ap.add_argument("--drop", type=float, default=0.75)
+    ap.add_argument("--p", type=float, default=0.3)
+    ap.add_argument("--peaky", type=float, default=0.0, help=">0: clustered block means with this temperature")
+    ap.add_argument("--iters", type=int, default=5)
+    ap.add_argument("--valid-text", type=int, default=64)
+    ap.add_argument("--no-xcd", action="store_true")
+    a = ap.parse_args()
+    dev = torch.device("cuda:0")
+    t, h, w = a.grid
+    S_img, tb = t * h * w, 2
+    assert S_img % 128 == 0
+    nimg, nb = S_img // 128, S_img // 128 + tb
+    S = nb * 128
+    H = a.heads
+    torch.manual_seed(0)
+    nbm = G.gilbert_block_neighbor_mapping(t, h, w, as_tensor=True)
+    q = torch.randn(1, S, H, 128, device=dev, dtype=torch.bfloat16)
+    k = torch.randn(1, S, H, 128, device=dev, dtype=torch.bfloat16)
+    v = torch.randn(1, S, H, 128, device=dev, dtype=torch.bfloat16)
+    if a.peaky > 0:
+        cent = torch.randn(1, nb, 1, H, 128, device=dev) * a.peaky
+        k = (k.view(1, nb, 128, H, 128).float() + cent).to(torch.bfloat16).view(1, S, H, 128)
+        pick = torch.randint(0, nimg, (nb,), device=dev)
+        q = (q.view(1, nb, 128, H, 128).float() + cent[:, pick]).to(torch.bfloat16).view(1, S, H, 128)
+    top_k = int((1 - a.drop) * nimg)
+    seqlens = torch.tensor([S_img + a.valid_text], dtype=torch.int32, device=dev)
+
+    res = {"shape": dict(S=S, H=H, nb=nb, top_k=top_k, p=a.p, drop=a.drop, peaky=a.peaky)}
+    ms, qpool = timed(lambda: _capi.block_pool(q, nimg), a.iters)
+    ms2, kpool = timed(lambda: _capi.block_pool(k, nb), a.iters)
+    res["pool_ms"] = ms + ms2
+    res["pool_GBps"] = (q.numel() * 2 * (nimg / nb) + k.numel() * 2) / ((ms + ms2) * 1e-3) / 1e9
+    ms, (mask, idx, cnt) = timed(lambda: _capi.block_select(qpool, kpool, nbm, nimg, tb, top_k, a.p), a.iters)
+    res["select_ms"] = ms
+    ms, vt = timed(lambda: _capi.pack_v(v, nb), a.iters)
+    res["pack_v_ms"] = ms
+    res["pack_v_GBps"] = 2 * v.numel() * 2 / (ms * 1e-3) / 1e9
+    kept = int(cnt.sum().item())
+    pairs = kept + H * tb * nb
+    flops = 4 * 128 ** 3 * pairs
+    res["kept_mean"] = kept / (H * nimg)
+    res["kept_min_max"] = [int(cnt.min()), int(cnt.max())]
+    ms, o = timed(lambda: _capi.bsattn_fwd(q, k, vt, seqlens, idx, cnt, nimg, 128 ** -0.5, 0.0, nimg,
+                                           xcd_remap=not a.no_xcd), a.iters)
+    res["attn_ms"] = ms
+    res["attn_TFLOPs"] = flops / (ms * 1e-3) / 1e12
+    res["attn_frac_of_2.5PF"] = res["attn_TFLOPs"] / 2500
+    res["dense_equiv_TFLOPs"] = 4 * S * S * 128 * H / (ms * 1e-3) / 1e12
+    res["finite"] = bool(torch.isfinite(o.float()).all().item())
+    print(json.dumps(res))
+
+
+if __name__ == "__main__":
+    main()
