@@ -80,6 +80,13 @@ constexpr int BUF_BYTES = K_TILE_BYTES + V_TILE_BYTES;
         *reinterpret_cast<uint4*>(vb_ + 96 * 128) = vr3;                                            \
     } while (0)
 
+// Lazy running max: m~ is an integer-valued upper reference of each row's max, raised (by an integer step, so every
+// rescale factor is an exact power of two) only when a row's new max exceeds it by more than LAZY_THR in log2 units.
+// -m~ rides in the MFMA C operand of the first K.Q^T step, so S arrives already shifted and P = exp2(S) needs no
+// subtraction; O and l are rescaled only in the (rare) raise path.  P <= 2^LAZY_THR keeps the storage dtype's relative
+// precision (power-of-two scaling commutes with rounding), so results match the eager max up to fp32 rounding.
+constexpr float LAZY_THR = 8.0f;
+
 template <typename T, bool TEXT>
 __device__ __forceinline__ void attn_block(const AttnParams& P, unsigned char* smem, int b, int h, int m) {
     const int tid = threadIdx.x;
@@ -97,7 +104,6 @@ __device__ __forceinline__ void attn_block(const AttnParams& P, unsigned char* s
         list = P.idx + row * P.n_blocks;
         nkept = P.cnt[row];
     }
-    const int ntiles = nkept * 2;
 
     // ---- Q fragments: lane (q, hi) keeps Q[q][ds*16 + hi*8 .. +7] for ds = 0..7 ----
     const long long qrow = (long long)m * 128 + wave * 32 + lq;
@@ -123,124 +129,138 @@ __device__ __forceinline__ void attn_block(const AttnParams& P, unsigned char* s
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) oacc[i][r] = 0.f;
-    float m_i = -INFINITY, l_i = 0.f;
+    float l_i = 0.f;
+    float m_ref = 0.f;      // m~ (integer valued)
+    f32x16 cinit;           // MFMA C operand of the first K.Q^T step: -m~ (TEXT: -m~ / qk_scale, scaled afterwards)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) cinit[r] = 0.f;
+    bool first = true;
+    const float inv_scale = 1.0f / P.qk_scale;
 
     const uint16_t* kbh = P.k + b * P.k_sb + h * P.k_sh;
     const uint16_t* vbh = P.vt + ((long long)b * P.H + h) * (long long)P.n_blocks * 2 * (128 * KT);
 
-    // per-lane LDS read offsets
-    const int k_row_off = lq * 256;                 // + g*8192
-    const int k_sw = lq & 15;
-    const int v_row_off = K_TILE_BYTES + lq * 128;  // + db*4096
-    const int v_sw = (lq >> 1) & 7;
-
+    // ---- loop-invariant LDS addresses (buffer / group / d-block offsets are compile-time immediates) ----
+    int k_addr[8], v_addr[4];
+#pragma unroll
+    for (int ds = 0; ds < 8; ++ds) k_addr[ds] = lq * 256 + (((ds * 2 + hi) ^ (lq & 15)) << 4);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+        v_addr[ks] = K_TILE_BYTES + lq * 128 + ((((ks >> 1) * 4 + hi * 2 + (ks & 1)) ^ ((lq >> 1) & 7)) << 4);
     // staging: thread -> K row (tid>>4) + 16i, 16-B chunk tid&15 (rows 16i apart keep the same swizzle key);
     //          V^T row (tid>>3) + 32i, chunk tid&7 (rows 32i apart keep the same swizzle key)
     const int st_k_off = (tid >> 4) * 256 + (((tid & 15) ^ ((tid >> 4) & 15)) << 4);
     const int st_v_off = K_TILE_BYTES + (tid >> 3) * 128 + (((tid & 7) ^ ((tid >> 4) & 7)) << 4);
     uint4 kr0, kr1, kr2, kr3, vr0, vr1, vr2, vr3;
-    if (ntiles > 0) {
+
+    // one 64-key tile out of LDS buffer BUF (0/1); `blk` = kv block id, HALF = which half of it
+#define COMPUTE_TILE(BUF, HALF)                                                                                  \
+    do {                                                                                                         \
+        const unsigned char* cur = smem + (BUF) * BUF_BYTES;                                                     \
+        const int key0 = blk * 128 + (HALF) * KT;                                                                \
+        if (TEXT || key0 < seqlen) { /* a tile entirely past seqlen contributes exp2(-inf) = 0 */                \
+            f32x16 s0, s1;                                                                                       \
+            {                                                                                                    \
+                const uint4 ka = *reinterpret_cast<const uint4*>(cur + k_addr[0]);                               \
+                const uint4 kb = *reinterpret_cast<const uint4*>(cur + k_addr[0] + 8192);                        \
+                s0 = mfma32<T>(ka, qf[0], cinit);                                                                \
+                s1 = mfma32<T>(kb, qf[0], cinit);                                                                \
+            }                                                                                                    \
+            _Pragma("unroll") for (int ds = 1; ds < 8; ++ds) {                                                   \
+                const uint4 ka = *reinterpret_cast<const uint4*>(cur + k_addr[ds]);                              \
+                const uint4 kb = *reinterpret_cast<const uint4*>(cur + k_addr[ds] + 8192);                       \
+                s0 = mfma32<T>(ka, qf[ds], s0);                                                                  \
+                s1 = mfma32<T>(kb, qf[ds], s1);                                                                  \
+            }                                                                                                    \
+            if (TEXT) {                                                                                          \
+                _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                                 \
+                    s0[r] *= P.qk_scale;                                                                         \
+                    s1[r] *= P.qk_scale;                                                                         \
+                }                                                                                                \
+            } else {                                                                                             \
+                if (blk >= P.text_block_start) {                                                                 \
+                    _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                             \
+                        s0[r] += P.text_amp;                                                                     \
+                        s1[r] += P.text_amp;                                                                     \
+                    }                                                                                            \
+                }                                                                                                \
+                if (key0 + KT > seqlen) {                                                                        \
+                    _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                             \
+                        const int kk = key0 + (r & 3) + 8 * (r >> 2) + 4 * hi;                                   \
+                        if (kk >= seqlen) s0[r] = -INFINITY;                                                     \
+                        if (kk + 32 >= seqlen) s1[r] = -INFINITY;                                                \
+                    }                                                                                            \
+                }                                                                                                \
+            }                                                                                                    \
+            /* row max of the shifted scores (both half-waves of a row agree after the exchange) */              \
+            float tmax = fmaxf(s0[0], s1[0]);                                                                    \
+            _Pragma("unroll") for (int r = 1; r < 16; ++r) tmax = fmaxf(tmax, fmaxf(s0[r], s1[r]));              \
+            tmax = fmaxf(tmax, __shfl_xor(tmax, 32));                                                            \
+            if (first || __any(tmax > LAZY_THR)) { /* raise m~ (rare): exact power-of-two rescale */             \
+                const float delta = (first || tmax > LAZY_THR) ? ceilf(tmax) : 0.f;                              \
+                const float f2 = __builtin_amdgcn_exp2f(-delta);                                                 \
+                m_ref += delta;                                                                                  \
+                l_i *= f2;                                                                                       \
+                _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                                 \
+                    s0[r] -= delta;                                                                              \
+                    s1[r] -= delta;                                                                              \
+                    cinit[r] = TEXT ? -m_ref * inv_scale : -m_ref;                                               \
+                }                                                                                                \
+                _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                    \
+                    _Pragma("unroll") for (int r = 0; r < 16; ++r) oacc[i][r] *= f2;                             \
+                first = false;                                                                                   \
+            }                                                                                                    \
+            float psum = 0.f;                                                                                    \
+            _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                                     \
+                s0[r] = __builtin_amdgcn_exp2f(s0[r]);                                                           \
+                s1[r] = __builtin_amdgcn_exp2f(s1[r]);                                                           \
+                psum += s0[r] + s1[r];                                                                           \
+            }                                                                                                    \
+            l_i += psum;                                                                                         \
+            /* P -> 16-bit operands: k-step ks = 2g + s uses C registers 8s..8s+7 of group g */                  \
+            uint4 pf[4];                                                                                         \
+            pf[0] = make_uint4(pack2<T>(s0[0], s0[1]), pack2<T>(s0[2], s0[3]), pack2<T>(s0[4], s0[5]),           \
+                               pack2<T>(s0[6], s0[7]));                                                          \
+            pf[1] = make_uint4(pack2<T>(s0[8], s0[9]), pack2<T>(s0[10], s0[11]), pack2<T>(s0[12], s0[13]),       \
+                               pack2<T>(s0[14], s0[15]));                                                        \
+            pf[2] = make_uint4(pack2<T>(s1[0], s1[1]), pack2<T>(s1[2], s1[3]), pack2<T>(s1[4], s1[5]),           \
+                               pack2<T>(s1[6], s1[7]));                                                          \
+            pf[3] = make_uint4(pack2<T>(s1[8], s1[9]), pack2<T>(s1[10], s1[11]), pack2<T>(s1[12], s1[13]),       \
+                               pack2<T>(s1[14], s1[15]));                                                        \
+            /* O^T += V^T P^T: four independent accumulator chains per k-step */                                 \
+            _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) {                                                   \
+                _Pragma("unroll") for (int db = 0; db < 4; ++db) {                                               \
+                    const uint4 va = *reinterpret_cast<const uint4*>(cur + v_addr[ks] + db * 4096);              \
+                    oacc[db] = mfma32<T>(va, pf[ks], oacc[db]);                                                  \
+                }                                                                                                \
+            }                                                                                                    \
+        }                                                                                                        \
+    } while (0)
+
+    if (nkept > 0) {
         const int blk0 = TEXT ? 0 : list[0];
         STAGE_LOAD(kbh + (long long)blk0 * 128 * P.k_ss, vbh + (long long)blk0 * 2 * (128 * KT));
         STAGE_STORE(smem);
     }
     __syncthreads();
 
-    for (int t = 0; t < ntiles; ++t) {
-        unsigned char* cur = smem + (t & 1) * BUF_BYTES;
-        const int blk = TEXT ? (t >> 1) : list[t >> 1];
-        const int key0 = blk * 128 + (t & 1) * KT;
-        {   // prefetch tile t+1 (clamped: the last iteration re-fetches its own tile, which is never consumed)
-            const int tn = (t + 1 < ntiles) ? t + 1 : t;
-            const int nblk = TEXT ? (tn >> 1) : list[tn >> 1];
-            const int ntile = nblk * 2 + (tn & 1);
-            STAGE_LOAD(kbh + ((long long)ntile * KT) * P.k_ss, vbh + (long long)ntile * (128 * KT));
+    for (int i = 0; i < nkept; ++i) {
+        const int blk = TEXT ? i : list[i];
+        // half 0 lives in buffer 0; fetch half 1 of the same block into buffer 1 meanwhile
+        STAGE_LOAD(kbh + ((long long)blk * 128 + KT) * P.k_ss, vbh + ((long long)blk * 2 + 1) * (128 * KT));
+        COMPUTE_TILE(0, 0);
+        STAGE_STORE(smem + BUF_BYTES);
+        __syncthreads();
+        {   // half 1 in buffer 1; fetch half 0 of the next kept block (clamped: the last re-fetch is never consumed)
+            const int in = (i + 1 < nkept) ? i + 1 : i;
+            const int nblk = TEXT ? in : list[in];
+            STAGE_LOAD(kbh + ((long long)nblk * 128) * P.k_ss, vbh + ((long long)nblk * 2) * (128 * KT));
         }
-        const bool live = TEXT || (key0 < seqlen);  // a tile entirely past seqlen contributes exp2(-inf) = 0
-        if (live) {
-            // ---------------- S^T = K Q^T ----------------
-            f32x16 s0, s1;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                s0[r] = 0.f;
-                s1[r] = 0.f;
-            }
-#pragma unroll
-            for (int ds = 0; ds < 8; ++ds) {
-                const int c = ((ds * 2 + hi) ^ k_sw) << 4;
-                const uint4 ka = *reinterpret_cast<const uint4*>(cur + k_row_off + c);
-                const uint4 kb = *reinterpret_cast<const uint4*>(cur + k_row_off + 8192 + c);
-                s0 = mfma32<T>(ka, qf[ds], s0);
-                s1 = mfma32<T>(kb, qf[ds], s1);
-            }
-            // ---------------- logits fix-ups ----------------
-            if (TEXT) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    s0[r] *= P.qk_scale;
-                    s1[r] *= P.qk_scale;
-                }
-            } else {
-                if (blk >= P.text_block_start) {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        s0[r] += P.text_amp;
-                        s1[r] += P.text_amp;
-                    }
-                }
-                if (key0 + KT > seqlen) {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int kk = key0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                        if (kk >= seqlen) s0[r] = -INFINITY;
-                        if (kk + 32 >= seqlen) s1[r] = -INFINITY;
-                    }
-                }
-            }
-            // ---------------- online softmax (lane-local row) ----------------
-            float tmax = fmaxf(s0[0], s1[0]);
-#pragma unroll
-            for (int r = 1; r < 16; ++r) tmax = fmaxf(tmax, fmaxf(s0[r], s1[r]));
-            tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
-            const float m_new = fmaxf(m_i, tmax);
-            const float alpha = __builtin_amdgcn_exp2f(m_i - m_new);
-            float psum = 0.f;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                s0[r] = __builtin_amdgcn_exp2f(s0[r] - m_new);
-                s1[r] = __builtin_amdgcn_exp2f(s1[r] - m_new);
-                psum += s0[r] + s1[r];
-            }
-            l_i = l_i * alpha + psum;
-            m_i = m_new;
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) oacc[i][r] *= alpha;
-            // P -> 16-bit operands: k-step ks = 2g + s uses C registers 8s..8s+7 of group g
-            uint4 pf[4];
-            pf[0] = make_uint4(pack2<T>(s0[0], s0[1]), pack2<T>(s0[2], s0[3]), pack2<T>(s0[4], s0[5]),
-                               pack2<T>(s0[6], s0[7]));
-            pf[1] = make_uint4(pack2<T>(s0[8], s0[9]), pack2<T>(s0[10], s0[11]), pack2<T>(s0[12], s0[13]),
-                               pack2<T>(s0[14], s0[15]));
-            pf[2] = make_uint4(pack2<T>(s1[0], s1[1]), pack2<T>(s1[2], s1[3]), pack2<T>(s1[4], s1[5]),
-                               pack2<T>(s1[6], s1[7]));
-            pf[3] = make_uint4(pack2<T>(s1[8], s1[9]), pack2<T>(s1[10], s1[11]), pack2<T>(s1[12], s1[13]),
-                               pack2<T>(s1[14], s1[15]));
-            // ---------------- O^T += V^T P^T ----------------
-#pragma unroll
-            for (int db = 0; db < 4; ++db) {
-#pragma unroll
-                for (int ks = 0; ks < 4; ++ks) {
-                    const int c = (((ks >> 1) * 4 + hi * 2 + (ks & 1)) ^ v_sw) << 4;
-                    const uint4 va = *reinterpret_cast<const uint4*>(cur + v_row_off + db * 4096 + c);
-                    oacc[db] = mfma32<T>(va, pf[ks], oacc[db]);
-                }
-            }
-        }
-        STAGE_STORE(smem + ((t + 1) & 1) * BUF_BYTES);
+        COMPUTE_TILE(1, 1);
+        STAGE_STORE(smem);
         __syncthreads();
     }
+#undef COMPUTE_TILE
 
     // ---- epilogue: o = acc / l, rows >= seqlen written as zeros (image rows only) ----
     const float l_tot = l_i + __shfl_xor(l_i, 32);

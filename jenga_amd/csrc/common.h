@@ -27,9 +27,19 @@ template <> __device__ __forceinline__ uint16_t from_f32<BF16>(float f) {
 template <> __device__ __forceinline__ uint16_t from_f32<FP16>(float f) {
     return __builtin_bit_cast(uint16_t, (_Float16)f);
 }
-// two values -> one packed dword (lo in bits 0..15)
-template <typename T> __device__ __forceinline__ uint32_t pack2(float lo, float hi) {
-    return (uint32_t)from_f32<T>(lo) | ((uint32_t)from_f32<T>(hi) << 16);
+// two values -> one packed dword (lo in bits 0..15).  Vector conversions so that bf16 becomes ONE
+// v_cvt_pk_bf16_f32 (round-to-nearest-even) instead of two scalar converts + shift + or.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+template <typename T> __device__ __forceinline__ uint32_t pack2(float lo, float hi);
+template <> __device__ __forceinline__ uint32_t pack2<BF16>(float lo, float hi) {
+    const f32x2 v = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
+}
+template <> __device__ __forceinline__ uint32_t pack2<FP16>(float lo, float hi) {
+    const f32x2 v = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, f16x2));
 }
 template <typename T> __device__ __forceinline__ float round_to(float f) { return to_f32<T>(from_f32<T>(f)); }
 

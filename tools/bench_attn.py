@@ -36,6 +36,8 @@ def main():
     ap.add_argument("--iters", type=int, default=5)
     ap.add_argument("--valid-text", type=int, default=64)
     ap.add_argument("--no-xcd", action="store_true")
+    ap.add_argument("--same-list", action="store_true", help="every query block keeps the SAME blocks (perfect L2 reuse)")
+    ap.add_argument("--attn-only", action="store_true")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     t, h, w = a.grid
@@ -67,6 +69,11 @@ def main():
     ms, vt = timed(lambda: _capi.pack_v(v, nb), a.iters)
     res["pack_v_ms"] = ms
     res["pack_v_GBps"] = 2 * v.numel() * 2 / (ms * 1e-3) / 1e9
+    if a.same_list:
+        n = int(cnt.float().mean().item())
+        idx = torch.arange(nb, device=dev, dtype=torch.int32).expand(1, H, nimg, nb).contiguous()
+        idx[..., n - tb:n] = torch.arange(nimg, nb, device=dev, dtype=torch.int32)
+        cnt = torch.full_like(cnt, n)
     kept = int(cnt.sum().item())
     pairs = kept + H * tb * nb
     flops = 4 * 128 ** 3 * pairs
