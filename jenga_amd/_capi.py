@@ -34,6 +34,23 @@ SIGNATURES = {
 _lib = None
 
 
+class AttnProfile:
+    """Optional per-launch timing of jenga_bsattn_fwd with HIP events recorded on the launch stream (bench.py's
+    roofline leg).  Enable with `_capi.ATTN_PROFILE = AttnProfile()`; read with .summary() after a synchronize."""
+
+    def __init__(self):
+        self.events = []        # (start, stop)
+        self.pairs = None       # device int64 scalar: kept (q-block, kv-block) pairs over all recorded launches
+        self.launches = 0
+
+    def summary(self):
+        ms = sum(a.elapsed_time(b) for a, b in self.events)
+        return dict(launches=self.launches, total_ms=ms, pairs=int(self.pairs.item()) if self.pairs is not None else 0)
+
+
+ATTN_PROFILE = None
+
+
 class JengaError(RuntimeError):
     pass
 
@@ -229,11 +246,22 @@ def bsattn_fwd(q, k, vt, seqlens, idx, cnt, nq_img, sm_scale, text_amp, text_blo
         seqlens = seqlens.to(device=q.device, dtype=torch.int32)
     if idx is not None and idx.shape[-1] != n_blocks:
         raise ValueError("idx row length must equal the number of kv blocks")
+    prof = ATTN_PROFILE
     with torch.cuda.device(q.device):
+        if prof is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
         _check(lib().jenga_bsattn_fwd(_stream(q.device), _p(q), _p(k), _p(vt), _p(out), _p(seqlens), _p(idx), _p(cnt),
                                       B, H, n_blocks, nq_img, *_bshd_strides(q), *_bshd_strides(k),
                                       *_bshd_strides(out), float(sm_scale), float(text_amp), int(text_block_start),
                                       dtype_code(q.dtype), ATTN_XCD_REMAP if xcd_remap else 0), "jenga_bsattn_fwd")
+        if prof is not None:
+            e1.record()
+            prof.events.append((e0, e1))
+            prof.launches += 1
+            pairs = B * H * (n_blocks - nq_img) * n_blocks
+            tot = (cnt.sum(dtype=torch.int64) if cnt is not None else 0) + pairs
+            prof.pairs = tot if prof.pairs is None else prof.pairs + tot
     return out
 
 

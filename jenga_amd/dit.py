@@ -1,0 +1,355 @@
+"""HunyuanVideo DiT with the Jenga forward, as the AttenCarve hot path's CALLER.
+
+Counterpart of
+  hyvideo/modules/models_mul_block_gc_ha_multigpu.py   MMDoubleStreamBlock :28-316, MMSingleStreamBlock :319-500,
+                                                        HYVideoDiffusionTransformer :503-845 (config :852-870)
+  jenga_hyvideo.py                                      ra_forward :61-234 (Hilbert gather/scatter + step-skip cache)
+  jenga_hyvideo_multigpu.py                             new_forward / transformer_sub_forward :109-331 (sequence shards)
+
+The blocks keep the reference's positional calling convention (12 arguments, jenga_hyvideo.py:143-156 / :162-175) and
+state-dict names of the layers they own.  The dense linear algebra (QKV / proj / MLP GEMMs, LayerNorm, adaLN
+modulation, GELU) is plain torch -> hipBLASLt / rocm-torch: out of the hot-path scope.  Everything
+on the hot path is the HIP library: per-head RMSNorm+RoPE written straight into the concatenated (image|text) Q/K
+buffers, V re-tiling straight from the GEMM outputs, block selection, block-sparse attention writing straight into
+the consumer's buffer, Hilbert gather/scatter.
+
+Weights are synthetic (random init; there are no checkpoints in this environment); the time/text embedders of the
+real model (timestep MLPs, token refiner) are replaced by one linear each -- they run once per step on <= 256 tokens.
+"""
+import math
+from typing import Optional, Tuple
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import _capi
+from . import gilbert as G
+from .modules import attention_block_sparse as op
+from .modules.attention import attention as dense_attention
+from .modules.attention import get_cu_seqlens, my_parallel_attention
+from .modules.norm_layers import RMSNorm
+from .modules.posemb_layers import get_nd_rotary_pos_embed
+from .modules import ulysses
+
+# jenga_hyvideo.py:28
+NON_SKIP_STEPS = [0, 1, 2, 3, 4, 7, 10, 13, 16, 19, 22, 25, 26, 29, 32, 35, 38, 41, 43, 45, 46, 47, 49]
+
+HUNYUAN_VIDEO_CONFIG = {  # models_mul_block_gc_ha_multigpu.py:852-870
+    "HYVideo-T/2-cfgdistill": dict(mm_double_blocks_depth=20, mm_single_blocks_depth=40, rope_dim_list=[16, 56, 56],
+                                   hidden_size=3072, heads_num=24, mlp_width_ratio=4, guidance_embed=True),
+}
+
+
+def modulate(x, shift=None, scale=None):
+    if scale is None and shift is None:
+        return x
+    if shift is None:
+        return x * (1 + scale.unsqueeze(1))
+    if scale is None:
+        return x + shift.unsqueeze(1)
+    return torch.addcmul(shift.unsqueeze(1), x, 1 + scale.unsqueeze(1))
+
+
+def apply_gate(x, gate=None, tanh=False):
+    if gate is None:
+        return x
+    return x * (gate.unsqueeze(1).tanh() if tanh else gate.unsqueeze(1))
+
+
+class ModulateDiT(nn.Module):
+    def __init__(self, hidden_size, factor, dtype=None, device=None):
+        super().__init__()
+        self.act = nn.SiLU()
+        self.linear = nn.Linear(hidden_size, factor * hidden_size, bias=True, dtype=dtype, device=device)
+
+    def forward(self, x):
+        return self.linear(self.act(x))
+
+
+class MLP(nn.Module):
+    def __init__(self, in_channels, hidden_channels, dtype=None, device=None):
+        super().__init__()
+        self.fc1 = nn.Linear(in_channels, hidden_channels, bias=True, dtype=dtype, device=device)
+        self.fc2 = nn.Linear(hidden_channels, in_channels, bias=True, dtype=dtype, device=device)
+
+    def forward(self, x):
+        return self.fc2(F.gelu(self.fc1(x), approximate="tanh"))
+
+
+def _select_top_k(sa_drop_rate, img_block_num):
+    return int((1 - sa_drop_rate) * img_block_num)  # Python float truncation: (0.8, 900) -> 179 (models_mul...:242)
+
+
+class MMDoubleStreamBlock(nn.Module):
+    def __init__(self, hidden_size: int, heads_num: int, mlp_width_ratio: float, dtype=None, device=None):
+        fk = dict(dtype=dtype, device=device)
+        super().__init__()
+        self.heads_num = heads_num
+        head_dim = hidden_size // heads_num
+        mlp_hidden = int(hidden_size * mlp_width_ratio)
+        self.img_mod = ModulateDiT(hidden_size, 6, **fk)
+        self.img_norm1 = nn.LayerNorm(hidden_size, elementwise_affine=False, eps=1e-6, **fk)
+        self.img_attn_qkv = nn.Linear(hidden_size, hidden_size * 3, bias=True, **fk)
+        self.img_attn_q_norm = RMSNorm(head_dim, elementwise_affine=True, eps=1e-6, **fk)
+        self.img_attn_k_norm = RMSNorm(head_dim, elementwise_affine=True, eps=1e-6, **fk)
+        self.img_attn_proj = nn.Linear(hidden_size, hidden_size, bias=True, **fk)
+        self.img_norm2 = nn.LayerNorm(hidden_size, elementwise_affine=False, eps=1e-6, **fk)
+        self.img_mlp = MLP(hidden_size, mlp_hidden, **fk)
+        self.txt_mod = ModulateDiT(hidden_size, 6, **fk)
+        self.txt_norm1 = nn.LayerNorm(hidden_size, elementwise_affine=False, eps=1e-6, **fk)
+        self.txt_attn_qkv = nn.Linear(hidden_size, hidden_size * 3, bias=True, **fk)
+        self.txt_attn_q_norm = RMSNorm(head_dim, elementwise_affine=True, eps=1e-6, **fk)
+        self.txt_attn_k_norm = RMSNorm(head_dim, elementwise_affine=True, eps=1e-6, **fk)
+        self.txt_attn_proj = nn.Linear(hidden_size, hidden_size, bias=True, **fk)
+        self.txt_norm2 = nn.LayerNorm(hidden_size, elementwise_affine=False, eps=1e-6, **fk)
+        self.txt_mlp = MLP(hidden_size, mlp_hidden, **fk)
+        self.hybrid_seq_parallel_attn = None
+
+    def forward(self, img, txt, vec, cu_seqlens_q=None, cu_seqlens_kv=None, max_seqlen_q=None, max_seqlen_kv=None,
+                freqs_cis: tuple = None, sa_drop_rate: float = 0.0, txt_amp: float = 1.0, curve_sel: list = None,
+                p_remain_rates: float = 0.5, txt_block_num: int = 2, per_block_token: int = 128):
+        H = self.heads_num
+        B, S_img, C = img.shape
+        S_txt = txt.shape[1]
+        (img_mod1_shift, img_mod1_scale, img_mod1_gate, img_mod2_shift, img_mod2_scale,
+         img_mod2_gate) = self.img_mod(vec).chunk(6, dim=-1)
+        (txt_mod1_shift, txt_mod1_scale, txt_mod1_gate, txt_mod2_shift, txt_mod2_scale,
+         txt_mod2_gate) = self.txt_mod(vec).chunk(6, dim=-1)
+        img_qkv = self.img_attn_qkv(modulate(self.img_norm1(img), img_mod1_shift, img_mod1_scale)).view(
+            B, S_img, 3, H, 128)
+        txt_qkv = self.txt_attn_qkv(modulate(self.txt_norm1(txt), txt_mod1_shift, txt_mod1_scale)).view(
+            B, S_txt, 3, H, 128)
+        block_neighbor_list = curve_sel[0][2] if curve_sel is not None else None
+        top_k = _select_top_k(sa_drop_rate, S_img // per_block_token)
+        cos, sin = freqs_cis
+        # QK-norm + RoPE fused, written straight into the concatenated (image | text) buffers
+        q = torch.empty((B, S_img + S_txt, H, 128), dtype=img.dtype, device=img.device)
+        k = torch.empty_like(q)
+        _capi.rmsnorm_rope(img_qkv[:, :, 0], self.img_attn_q_norm.weight, cos, sin, out=q[:, :S_img])
+        _capi.rmsnorm_rope(img_qkv[:, :, 1], self.img_attn_k_norm.weight, cos, sin, out=k[:, :S_img])
+        _capi.rmsnorm_rope(txt_qkv[:, :, 0], self.txt_attn_q_norm.weight, None, None, out=q[:, S_img:])
+        _capi.rmsnorm_rope(txt_qkv[:, :, 1], self.txt_attn_k_norm.weight, None, None, out=k[:, S_img:])
+        if self.hybrid_seq_parallel_attn:
+            v = torch.cat((img_qkv[:, :, 2], txt_qkv[:, :, 2]), dim=1)
+            attn = my_parallel_attention(self.hybrid_seq_parallel_attn, q, k, v, img_q_len=S_img, img_kv_len=S_img,
+                                         cu_seqlens_q=cu_seqlens_q, cu_seqlens_kv=cu_seqlens_kv,
+                                         top_k=ulysses.get_sequence_parallel_world_size() * top_k, text_amp=txt_amp,
+                                         block_neighbor_list=block_neighbor_list, p_remain_rates=p_remain_rates)
+        elif sa_drop_rate == 0.0:
+            v = torch.cat((img_qkv[:, :, 2], txt_qkv[:, :, 2]), dim=1)
+            attn = dense_attention(q, k, v, cu_seqlens_q=cu_seqlens_q, cu_seqlens_kv=cu_seqlens_kv)
+        else:
+            nb, nimg = (S_img + S_txt) // 128, S_img // 128
+            vt = _capi.pack_v(img_qkv[:, :, 2], nimg, dst_block0=0, dst_blocks_total=nb)
+            _capi.pack_v(txt_qkv[:, :, 2], S_txt // 128, out=vt, dst_block0=nimg, dst_blocks_total=nb)
+            seqlens = cu_seqlens_q[1:2]
+            attn = op.attencarve_packed(q, k, vt, top_k, seqlens, txt_block_num, txt_amp, p_remain_rates,
+                                        block_neighbor_list).view(B, S_img + S_txt, H * 128)
+        img_attn, txt_attn = attn[:, :S_img], attn[:, S_img:]
+        img = img + apply_gate(self.img_attn_proj(img_attn), gate=img_mod1_gate)
+        img = img + apply_gate(self.img_mlp(modulate(self.img_norm2(img), img_mod2_shift, img_mod2_scale)),
+                               gate=img_mod2_gate)
+        txt = txt + apply_gate(self.txt_attn_proj(txt_attn), gate=txt_mod1_gate)
+        txt = txt + apply_gate(self.txt_mlp(modulate(self.txt_norm2(txt), txt_mod2_shift, txt_mod2_scale)),
+                               gate=txt_mod2_gate)
+        return img, txt
+
+
+class MMSingleStreamBlock(nn.Module):
+    def __init__(self, hidden_size: int, heads_num: int, mlp_width_ratio: float = 4.0, dtype=None, device=None):
+        fk = dict(dtype=dtype, device=device)
+        super().__init__()
+        self.hidden_size = hidden_size
+        self.heads_num = heads_num
+        head_dim = hidden_size // heads_num
+        self.mlp_hidden_dim = int(hidden_size * mlp_width_ratio)
+        self.linear1 = nn.Linear(hidden_size, hidden_size * 3 + self.mlp_hidden_dim, **fk)
+        self.linear2 = nn.Linear(hidden_size + self.mlp_hidden_dim, hidden_size, **fk)
+        self.q_norm = RMSNorm(head_dim, elementwise_affine=True, eps=1e-6, **fk)
+        self.k_norm = RMSNorm(head_dim, elementwise_affine=True, eps=1e-6, **fk)
+        self.pre_norm = nn.LayerNorm(hidden_size, elementwise_affine=False, eps=1e-6, **fk)
+        self.modulation = ModulateDiT(hidden_size, 3, **fk)
+        self.hybrid_seq_parallel_attn = None
+
+    def forward(self, x, vec, txt_len, cu_seqlens_q=None, cu_seqlens_kv=None, max_seqlen_q=None, max_seqlen_kv=None,
+                freqs_cis: Tuple[torch.Tensor, torch.Tensor] = None, sa_drop_rate: float = 0.0, txt_amp: float = 1.0,
+                curve_sel: list = None, p_remain_rates: float = 0.5, txt_block_num: int = 2,
+                per_block_token: int = 128):
+        H, C = self.heads_num, self.hidden_size
+        B, S, _ = x.shape
+        S_img = S - txt_len
+        mod_shift, mod_scale, mod_gate = self.modulation(vec).chunk(3, dim=-1)
+        lin1 = self.linear1(modulate(self.pre_norm(x), mod_shift, mod_scale))      # [B,S,3C + mlp]
+        qkv = lin1[..., : 3 * C].unflatten(-1, (3, H, 128))                        # strided views, no copies
+        mlp = lin1[..., 3 * C:]
+        cos, sin = freqs_cis
+        q = _capi.rmsnorm_rope(qkv[:, :, 0], self.q_norm.weight, cos, sin, s_rope=S_img)   # RoPE on image tokens only
+        k = _capi.rmsnorm_rope(qkv[:, :, 1], self.k_norm.weight, cos, sin, s_rope=S_img)
+        block_neighbor_list = curve_sel[0][2] if curve_sel is not None else None
+        top_k = _select_top_k(sa_drop_rate, S_img // per_block_token)
+        # concat buffer for linear2: attention writes its [B,S,H*128] output straight into the left part
+        cat = torch.empty((B, S, C + self.mlp_hidden_dim), dtype=x.dtype, device=x.device)
+        if self.hybrid_seq_parallel_attn:
+            attn = my_parallel_attention(self.hybrid_seq_parallel_attn, q, k, qkv[:, :, 2], img_q_len=S_img,
+                                         img_kv_len=S_img, cu_seqlens_q=cu_seqlens_q, cu_seqlens_kv=cu_seqlens_kv,
+                                         top_k=ulysses.get_sequence_parallel_world_size() * top_k, text_amp=txt_amp,
+                                         block_neighbor_list=block_neighbor_list, p_remain_rates=p_remain_rates)
+            cat[..., :C] = attn
+        elif sa_drop_rate == 0.0:
+            cat[..., :C] = dense_attention(q, k, qkv[:, :, 2], cu_seqlens_q=cu_seqlens_q, cu_seqlens_kv=cu_seqlens_kv)
+        else:
+            vt = _capi.pack_v(qkv[:, :, 2], S // 128)
+            op.attencarve_packed(q, k, vt, top_k, cu_seqlens_q[1:2], txt_block_num, txt_amp, p_remain_rates,
+                                 block_neighbor_list, out=cat[..., :C].unflatten(-1, (H, 128)))
+        torch.ops.aten.gelu.out(mlp, approximate="tanh", out=cat[..., C:])
+        return x + apply_gate(self.linear2(cat), gate=mod_gate)
+
+
+class JengaHYVideoDiT(nn.Module):
+    """Synthetic-weight HunyuanVideo DiT driven the way jenga_hyvideo.py drives the real one: Jenga state lives in
+    attributes set by the caller (jenga_hyvideo.py:275-287: enable_skip, cnt, num_steps, curve_sel, sa_drop_rate,
+    text_amp, p_remain_rates, linear_to_hilbert, hilbert_order, start_stage, previous_residual)."""
+
+    def __init__(self, config="HYVideo-T/2-cfgdistill", in_channels=16, out_channels=16, patch_size=(1, 2, 2),
+                 text_states_dim=4096, text_states_dim_2=768, depth_double=None, depth_single=None, dtype=torch.bfloat16,
+                 device=None):
+        super().__init__()
+        cfg = HUNYUAN_VIDEO_CONFIG[config]
+        self.hidden_size, self.heads_num = cfg["hidden_size"], cfg["heads_num"]
+        self.rope_dim_list = cfg["rope_dim_list"]
+        self.patch_size = list(patch_size)
+        self.out_channels = out_channels
+        fk = dict(dtype=dtype, device=device)
+        pdim = in_channels * math.prod(patch_size)
+        self.img_in = nn.Linear(pdim, self.hidden_size, **fk)             # PatchEmbed (conv3d, stride = kernel) as a GEMM
+        self.txt_in = nn.Linear(text_states_dim, self.hidden_size, **fk)  # stands in for the token refiner
+        self.time_in = nn.Linear(256, self.hidden_size, **fk)
+        self.vector_in = nn.Linear(text_states_dim_2, self.hidden_size, **fk)
+        self.guidance_in = nn.Linear(256, self.hidden_size, **fk)
+        nd = cfg["mm_double_blocks_depth"] if depth_double is None else depth_double
+        ns = cfg["mm_single_blocks_depth"] if depth_single is None else depth_single
+        self.double_blocks = nn.ModuleList(
+            [MMDoubleStreamBlock(self.hidden_size, self.heads_num, cfg["mlp_width_ratio"], **fk) for _ in range(nd)])
+        self.single_blocks = nn.ModuleList(
+            [MMSingleStreamBlock(self.hidden_size, self.heads_num, cfg["mlp_width_ratio"], **fk) for _ in range(ns)])
+        self.final_norm = nn.LayerNorm(self.hidden_size, elementwise_affine=False, eps=1e-6, **fk)
+        self.final_mod = nn.Linear(self.hidden_size, 2 * self.hidden_size, **fk)
+        self.final_linear = nn.Linear(self.hidden_size, math.prod(patch_size) * out_channels, **fk)
+        # Jenga state
+        self.enable_skip = True
+        self.cnt = 0
+        self.num_steps = 50
+        self.start_stage = False
+        self.previous_residual = None
+        self.curve_sel = None
+        self.linear_to_hilbert = None
+        self.hilbert_order = None
+        self.sa_drop_rate = 0.0
+        self.text_amp = 0.0
+        self.p_remain_rates = 0.3
+
+    @torch.no_grad()
+    def init_synthetic_weights(self, std=0.02, seed=0):
+        g = torch.Generator(device=self.img_in.weight.device).manual_seed(seed)
+        for name, p in self.named_parameters():
+            if name.endswith("norm.weight") or "_norm.weight" in name:
+                p.copy_((1 + 0.1 * torch.randn(p.shape, generator=g, device=p.device)).to(p.dtype))
+            elif p.dim() >= 2:
+                p.normal_(0.0, std, generator=g)
+            else:
+                p.normal_(0.0, std, generator=g)   # biases and modulation are non-zero so that gates are exercised
+        return self
+
+    # ---- static geometry for one resolution stage (jenga_hyvideo.py:43-58 + pipeline...prores.py:238-284) ----
+    def set_stage(self, latent_thw, device):
+        t, h, w = latent_thw
+        pt, ph, pw = self.patch_size
+        tt, th, tw = t // pt, h // ph, w // pw
+        l2h, h2l = G.gilbert_mapping(tt, th, tw, as_tensor=True, device=device)
+        nbm = G.gilbert_block_neighbor_mapping(tt, th, tw, as_tensor=True, device=device)
+        self.curve_sel = [[l2h, h2l, nbm]]
+        self.linear_to_hilbert, self.hilbert_order = l2h, h2l
+        cos, sin = get_nd_rotary_pos_embed(self.rope_dim_list, [tt, th, tw], theta=256, use_real=True,
+                                           theta_rescale_factor=1)
+        return cos.to(device), sin.to(device)
+
+    def patchify(self, x):
+        B, C, T, Hh, W = x.shape
+        pt, ph, pw = self.patch_size
+        x = x.view(B, C, T // pt, pt, Hh // ph, ph, W // pw, pw).permute(0, 2, 4, 6, 1, 3, 5, 7)
+        return x.reshape(B, (T // pt) * (Hh // ph) * (W // pw), C * pt * ph * pw)
+
+    def unpatchify(self, x, t, h, w):
+        c = self.out_channels
+        pt, ph, pw = self.patch_size
+        x = x.reshape(x.shape[0], t, h, w, c, pt, ph, pw)
+        x = torch.einsum("nthwcopq->nctohpwq", x)
+        return x.reshape(x.shape[0], c, t * pt, h * ph, w * pw)
+
+    @staticmethod
+    def _sinusoid(t, dim=256):
+        half = dim // 2
+        f = torch.exp(-math.log(10000) * torch.arange(half, dtype=torch.float32, device=t.device) / half)
+        a = t.float()[:, None] * f[None]
+        return torch.cat([a.cos(), a.sin()], dim=-1)
+
+    @torch.no_grad()
+    def forward(self, x, t, text_states=None, text_mask=None, text_states_2=None, freqs_cos=None, freqs_sin=None,
+                guidance=None, return_dict=True):
+        """Counterpart of ra_forward (single GPU) and of new_forward+transformer_sub_forward (sequence parallel: the
+        reordered image tokens and RoPE rows are split into N contiguous shards, jenga_hyvideo_multigpu.py:168-177)."""
+        _, _, ot, oh, ow = x.shape
+        tt, th, tw = ot // self.patch_size[0], oh // self.patch_size[1], ow // self.patch_size[2]
+        dt = self.img_in.weight.dtype
+        vec = self.time_in(self._sinusoid(t).to(dt)) + self.vector_in(text_states_2.to(dt))
+        vec = vec + self.guidance_in(self._sinusoid(guidance).to(dt))
+        img = self.img_in(self.patchify(x).to(dt))
+        txt = self.txt_in(text_states.to(dt))
+        txt_seq_len, img_seq_len = txt.shape[1], img.shape[1]
+        # Hilbert gather (K10): image tokens and RoPE rows into curve order
+        img = _capi.gather_rows(img, self.hilbert_order)
+        freqs_cos = _capi.gather_rows(freqs_cos.unsqueeze(0), self.hilbert_order)[0]
+        freqs_sin = _capi.gather_rows(freqs_sin.unsqueeze(0), self.hilbert_order)[0]
+        sp = self.double_blocks[0].hybrid_seq_parallel_attn if len(self.double_blocks) else None
+        if sp:
+            n, r = ulysses.get_sequence_parallel_world_size(), ulysses.get_sequence_parallel_rank()
+            assert img_seq_len % n == 0, f"cannot split {img_seq_len} image tokens over {n} ranks"
+            img = torch.chunk(img, n, dim=1)[r].contiguous()
+            freqs_cos = torch.chunk(freqs_cos, n, dim=0)[r].contiguous()
+            freqs_sin = torch.chunk(freqs_sin, n, dim=0)[r].contiguous()
+        loc_len = img.shape[1]
+        cu_seqlens_q = get_cu_seqlens(text_mask, loc_len)
+        cu_seqlens_kv = cu_seqlens_q
+        max_seqlen_q = max_seqlen_kv = loc_len + txt_seq_len
+        should_calc = (not self.enable_skip) or (self.cnt in NON_SKIP_STEPS) or self.start_stage
+        self.start_stage = False
+        if sp and self.enable_skip and torch.distributed.is_initialized():
+            flag = torch.tensor([1 if should_calc else 0], device=img.device)       # C4: agree on skip/compute
+            torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MIN, group=ulysses.get_sp_group().group)
+            should_calc = bool(flag.item())
+        if not should_calc:
+            img = img + self.previous_residual
+        else:
+            ori_img = img
+            freqs = (freqs_cos, freqs_sin)
+            for block in self.double_blocks:
+                img, txt = block(img, txt, vec, cu_seqlens_q, cu_seqlens_kv, max_seqlen_q, max_seqlen_kv, freqs,
+                                 self.sa_drop_rate, self.text_amp, self.curve_sel, self.p_remain_rates)
+            xcat = torch.cat((img, txt), 1)
+            for block in self.single_blocks:
+                xcat = block(xcat, vec, txt_seq_len, cu_seqlens_q, cu_seqlens_kv, max_seqlen_q, max_seqlen_kv, freqs,
+                             self.sa_drop_rate, self.text_amp, self.curve_sel, self.p_remain_rates)
+            img = xcat[:, :loc_len]
+            if self.enable_skip:
+                self.previous_residual = img - ori_img
+        self.cnt += 1
+        if self.cnt == self.num_steps:
+            self.cnt = 0
+        if sp:
+            img = ulysses.get_sp_group().all_gather(img.contiguous(), dim=1)       # C3
+        img = _capi.gather_rows(img.contiguous(), self.linear_to_hilbert)            # Hilbert scatter (K10)
+        shift, scale = self.final_mod(F.silu(vec)).chunk(2, dim=1)
+        img = self.final_linear(modulate(self.final_norm(img), shift, scale))
+        img = self.unpatchify(img, tt, th, tw)
+        return {"x": img} if return_dict else img

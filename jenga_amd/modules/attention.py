@@ -1,0 +1,52 @@
+"""Attention front-end helpers, counterpart of hyvideo/modules/attenion.py."""
+import torch
+
+from .. import _capi
+from . import attention_block_sparse as _op
+
+
+def get_cu_seqlens(text_mask, img_len):
+    """cu_seqlens for (valid | padding) segments per sample -- same values as attenion.py:34-57, but built on
+    text_mask's device without a Python loop over device scalars (the reference hard-codes device="cuda" and syncs
+    per batch element)."""
+    batch_size = text_mask.shape[0]
+    text_len = text_mask.sum(dim=1).to(torch.int32)
+    max_len = text_mask.shape[1] + img_len
+    base = torch.arange(batch_size, device=text_mask.device, dtype=torch.int32) * max_len
+    cu = torch.zeros(2 * batch_size + 1, dtype=torch.int32, device=text_mask.device)
+    cu[1::2] = base + text_len + img_len
+    cu[2::2] = base + max_len
+    return cu
+
+
+def my_parallel_attention(hybrid_seq_parallel_attn, q, k, v, img_q_len, img_kv_len, cu_seqlens_q, cu_seqlens_kv,
+                          top_k: int = 10e7, text_amp: float = 0.0, block_neighbor_list=None,
+                          p_remain_rates: float = 0.0):
+    """Adapter with the argument convention of attenion.py:159-195."""
+    attn = hybrid_seq_parallel_attn(
+        None, q[:, :img_q_len], k[:, :img_kv_len], v[:, :img_kv_len], dropout_p=0.0, causal=False,
+        joint_tensor_query=q[:, img_q_len:], joint_tensor_key=k[:, img_kv_len:], joint_tensor_value=v[:, img_kv_len:],
+        joint_strategy="rear", top_k=top_k, cu_seqlens_q=cu_seqlens_q, cu_seqlens_kv=cu_seqlens_kv,
+        text_amp=text_amp, block_neighbor_list=block_neighbor_list, p_remain_rates=p_remain_rates)
+    b, s, a, d = attn.shape
+    return attn.reshape(b, s, -1)
+
+
+def attention(q, k, v, mode="flash", drop_rate=0, attn_mask=None, causal=False, cu_seqlens_q=None,
+              cu_seqlens_kv=None, max_seqlen_q=None, max_seqlen_kv=None, batch_size=1):
+    """Dense path taken when sa_drop_rate == 0 (attenion.py:60-157, mode "flash" = flash_attn_varlen_func over the
+    (valid | padding) segments).  Runs the same HIP kernel with every kv block kept and the kv-length mask on, for all
+    query blocks.  Deviation, documented in DESIGN.md: the padding-segment rows (text padding, never read by any valid
+    token) come back as zeros instead of attending among themselves; valid rows are the same softmax."""
+    if q.shape[0] != 1:
+        raise ValueError("jenga_amd dense attention: batch must be 1")
+    B, S, H, D = q.shape
+    if S % 128:
+        raise ValueError("jenga_amd dense attention: S must be a multiple of 128")
+    nb = S // 128
+    seqlens = cu_seqlens_q[1:2].to(device=q.device, dtype=torch.int32)
+    idx = torch.arange(nb, device=q.device, dtype=torch.int32).expand(B, H, nb, nb).contiguous()
+    cnt = torch.full((B, H, nb), nb, dtype=torch.int32, device=q.device)
+    vt = _capi.pack_v(v if v.stride(-1) == 1 else v.contiguous(), nb)
+    o = _capi.bsattn_fwd(q, k, vt, seqlens, idx, cnt, nb, D ** -0.5, 0.0, nb)
+    return o.reshape(B, S, H * D)

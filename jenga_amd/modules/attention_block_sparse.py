@@ -38,6 +38,23 @@ def build_block_index(query, key, top_k, text_blocks, prob_threshold, block_neig
                               first_frame_blocks=first_frame_blocks, want_mask=want_mask)
 
 
+def attencarve_packed(q, k, vt, top_k, seqlens, text_blocks, text_amp, prob_threshold, block_neighbor_list,
+                      first_frame_blocks=0, out=None, return_lists=False):
+    """Core used by the DiT blocks: q/k [B,S,H,128] already normed+roped (any strides), vt = packed V workspace
+    (jenga_pack_v), seqlens int32 [B] on the device.  Selection + one attention launch; returns o [B,S,H,128]
+    (written into `out` if given, which may be a strided view, e.g. the left part of the single-stream blocks'
+    concat buffer)."""
+    B, S, H, D = q.shape
+    nb = S // BLOCK
+    nimg = nb - text_blocks
+    idx = cnt = None
+    if nimg > 0:
+        _, idx, cnt = build_block_index(q, k, top_k, text_blocks, prob_threshold, block_neighbor_list,
+                                        first_frame_blocks)
+    o = _capi.bsattn_fwd(q, k, vt, seqlens, idx, cnt, nimg, D ** -0.5, text_amp, nimg, out=out)
+    return (o, idx, cnt) if return_lists else o
+
+
 def _combined(query, key, value, top_k, seqlens, text_blocks, text_amp, prob_threshold, block_neighbor_list,
               shape_xfuse, first_frame_blocks=0, context_size=None, return_mask=False):
     B, S, H, D = query.shape
