@@ -1,0 +1,44 @@
+"""ORACLE (test infrastructure): the Ulysses sequence-parallel contract, restated.  PARITY UNPINNED: the reference
+wrapper (hyvideo/modules/xdit_ring_atten.py:61-222) subclasses yunchang==0.6.3.post1's LongContextAttention and calls
+yunchang.comm.all_to_all.SeqAllToAll4D (neither is in /root/reference nor installed; the reference has no tests and no
+CPU path for it), so this file restates the published Ulysses algorithm anchored on the reference's call sites:
+
+  * scatter_idx=2 / gather_idx=1 (:26-27,118-131): heads are split into N contiguous slices [r*H/N, (r+1)*H/N)
+    (consistent with the explicit slicing of the text K/V at :159-175); sequences are concatenated rank-major;
+  * text Q after the all-to-all is truncated to the first S_txt rows (:129-131) = rank 0's text rows for this rank's
+    heads = this rank's own (replicated) text rows;
+  * cu_seqlens = [0, n_valid_text + N*S_loc, N*S_loc + S_txt] (:105,183-184); top_k is passed through (the caller has
+    already multiplied it by N, models_mul_block_gc_ha_multigpu.py:249-251);
+  * the op runs with shape_xfuse=True on [1, N*S_loc + S_txt, H/N, D] (:186-199);
+  * image output goes back with the inverse all-to-all, text output is the concatenation over head slices (:206-217).
+
+simulate(...) runs all N ranks in one process with a fake all-to-all and returns each rank's [1, S_loc+S_txt, H, D].
+"""
+import numpy as np
+
+from . import attention as oa
+
+
+def simulate(q_shards, k_shards, v_shards, q_txt, k_txt, v_txt, top_k, n_valid_text, dtype, text_amp=0.0,
+             neighbors=None, p=0.3):
+    """q_shards[r]: [1,S_loc,H,D] (rank r's slice of the Hilbert-ordered image tokens); *_txt [1,S_txt,H,D]."""
+    N = len(q_shards)
+    _, S_loc, H, D = q_shards[0].shape
+    Hn = H // N
+    S_txt = q_txt.shape[1]
+    S_img = N * S_loc
+    outs = []
+    for r in range(N):
+        hs = slice(r * Hn, (r + 1) * Hn)
+        cat = lambda shards, txt: np.concatenate([s[:, :, hs] for s in shards] + [txt[:, :, hs]], axis=1)
+        q, k, v = cat(q_shards, q_txt), cat(k_shards, k_txt), cat(v_shards, v_txt)
+        cu = np.array([0, n_valid_text + S_img, S_img + S_txt], np.int64)
+        outs.append(oa.block_sparse_attention(q, k, v, top_k, dtype, cu_seqlens_q=cu, text_blocks=S_txt // 128,
+                                              text_amp=text_amp, block_neighbor_list=neighbors, shape_xfuse=True,
+                                              p_remain_rates=p))          # [1, S, Hn, D]
+    results = []
+    for r in range(N):
+        img = np.concatenate([outs[p_][:, r * S_loc:(r + 1) * S_loc] for p_ in range(N)], axis=2)   # heads back
+        txt = np.concatenate([outs[p_][:, S_img:] for p_ in range(N)], axis=2)
+        results.append(np.concatenate([img, txt], axis=1))
+    return results

@@ -1,0 +1,102 @@
+"""CPU, world_size 2, gloo: the Ulysses exchange of jenga_amd.modules.ulysses (pack -> all_to_all -> local op ->
+all_to_all / all_gather) against (i) the oracle's in-process N-rank simulation and (ii) the single-rank op with the
+multi-GPU top_k rule -- the equivalence SURVEY.md §8(c) asks for.  The local attention is injected (oracle) because
+the product has no CPU compute path; everything else is the shipped code."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import inputs
+from helpers import to_np
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _oracle_attn(q_all, k_all, v_all, top_k, seqlens, text_blocks, text_amp, p, neighbors):
+    from oracle import attention as oa
+    S = q_all.shape[1]
+    cu = np.array([0, int(seqlens[0]), S], np.int64)
+    nb = None if neighbors is None else np.asarray(neighbors)
+    o = oa.block_sparse_attention(to_np(q_all), to_np(k_all), to_np(v_all), top_k, "bfloat16", cu_seqlens_q=cu,
+                                  text_blocks=text_blocks, text_amp=text_amp, block_neighbor_list=nb,
+                                  shape_xfuse=True, p_remain_rates=p)
+    return torch.from_numpy(o).to(q_all.dtype)
+
+
+def _make_case():
+    from oracle import gilbert as og
+    gen = torch.Generator().manual_seed(123)
+    H, nimg, tb = 4, 8, 2                      # 1024 image tokens (8 blocks), 256 text tokens
+    q, k = inputs.peaky_qk(gen, 1, H, nimg + tb, nimg + tb, 128, 0.8)
+    q = q.transpose(1, 2).to(torch.bfloat16).contiguous()      # [1,S,H,D]
+    k = k.transpose(1, 2).to(torch.bfloat16).contiguous()
+    v = torch.randn(1, (nimg + tb) * 128, H, 128, generator=gen).to(torch.bfloat16)
+    nbm = og.gilbert_block_neighbor_mapping(2, 8, 64, 128)
+    return q, k, v, nbm, nimg, tb
+
+
+def _worker(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from jenga_amd.modules import ulysses
+        from jenga_amd.modules.attention import my_parallel_attention
+        ulysses.init_sequence_parallel()
+        assert ulysses.get_sequence_parallel_world_size() == world and ulysses.get_sequence_parallel_rank() == rank
+        q, k, v, nbm, nimg, tb = _make_case()
+        S_img = nimg * 128
+        S_loc = S_img // world
+        sl = slice(rank * S_loc, (rank + 1) * S_loc)
+        loc = lambda t: torch.cat([t[:, sl], t[:, S_img:]], dim=1)     # local image shard + replicated text
+        n_valid = 70
+        cu = torch.tensor([0, S_loc + n_valid, S_loc + tb * 128], dtype=torch.int32)
+        top_k_local = int((1 - 0.5) * (S_loc // 128))                   # models_mul...:242 on the LOCAL block count
+        sp = ulysses.UlyssesAttenCarve(attn_fn=_oracle_attn)
+        out = my_parallel_attention(sp, loc(q), loc(k), loc(v), img_q_len=S_loc, img_kv_len=S_loc, cu_seqlens_q=cu,
+                                    cu_seqlens_kv=cu, top_k=world * top_k_local, text_amp=0.25,
+                                    block_neighbor_list=torch.from_numpy(nbm), p_remain_rates=0.3)
+        ret[rank] = out.float().numpy()
+        # the all_gather used by the driver (jenga_hyvideo_multigpu.py:193)
+        g = ulysses.get_sp_group().all_gather(torch.full((1, 2, 3), float(rank)), dim=1)
+        assert g.shape == (1, 2 * world, 3) and g[0, 2 * rank, 0] == rank
+    finally:
+        dist.destroy_process_group()
+
+
+def test_ulysses_two_ranks_match_oracle_and_single_rank():
+    world = 2
+    port = _free_port()
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(world, port, ret), nprocs=world, join=True)
+    from oracle import attention as oa
+    from oracle import ulysses as ou
+    q, k, v, nbm, nimg, tb = _make_case()
+    S_img = nimg * 128
+    S_loc = S_img // world
+    H = q.shape[2]
+    top_k = world * int(0.5 * (S_loc // 128))
+    qn, kn, vn = to_np(q), to_np(k), to_np(v)
+    shards = lambda t: [t[:, r * S_loc:(r + 1) * S_loc] for r in range(world)]
+    sim = ou.simulate(shards(qn), shards(kn), shards(vn), qn[:, S_img:], kn[:, S_img:], vn[:, S_img:], top_k, 70,
+                      "bfloat16", text_amp=0.25, neighbors=nbm, p=0.3)
+    # single-rank op over all heads with the same top_k: heads are independent, so SP must reproduce it exactly
+    cu = np.array([0, S_img + 70, S_img + tb * 128], np.int64)
+    single = oa.block_sparse_attention(qn, kn, vn, top_k, "bfloat16", cu_seqlens_q=cu, text_blocks=tb, text_amp=0.25,
+                                       block_neighbor_list=nbm, shape_xfuse=True, p_remain_rates=0.3)
+    for r in range(world):
+        got = ret[r].reshape(1, S_loc + tb * 128, H, 128)
+        assert np.array_equal(got, sim[r]), f"rank {r}: exchange differs from the oracle simulation"
+        want = np.concatenate([single[:, r * S_loc:(r + 1) * S_loc], single[:, S_img:]], axis=1)
+        assert np.array_equal(got, want), f"rank {r}: SP result differs from the single-rank op"
