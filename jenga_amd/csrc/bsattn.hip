@@ -50,34 +50,38 @@ constexpr int K_TILE_BYTES = KT * 128 * 2;  // 16 KiB
 constexpr int V_TILE_BYTES = 128 * KT * 2;  // 16 KiB
 constexpr int BUF_BYTES = K_TILE_BYTES + V_TILE_BYTES;
 
-// Register-staged prefetch (global -> VGPR early, VGPR -> LDS after the compute of the current tile).  Kept as
-// eight named uint4 registers and macros on purpose: wrapped in a struct behind a conditional, hipcc parks the
-// aggregate in scratch, which drains vmcnt right after the loads and serialises the whole pipeline.
-#define STAGE_LOAD(KPTR, VPTR)                                                                      \
-    do {                                                                                            \
-        const uint16_t* kp_ = (KPTR) + (long long)(tid >> 4) * P.k_ss + (tid & 15) * 8;             \
-        const uint16_t* vp_ = (VPTR) + tid * 8;                                                     \
-        kr0 = *reinterpret_cast<const uint4*>(kp_);                                                 \
-        kr1 = *reinterpret_cast<const uint4*>(kp_ + 16 * P.k_ss);                                   \
-        kr2 = *reinterpret_cast<const uint4*>(kp_ + 32 * P.k_ss);                                   \
-        kr3 = *reinterpret_cast<const uint4*>(kp_ + 48 * P.k_ss);                                   \
-        vr0 = *reinterpret_cast<const uint4*>(vp_);                                                 \
-        vr1 = *reinterpret_cast<const uint4*>(vp_ + 2048);                                          \
-        vr2 = *reinterpret_cast<const uint4*>(vp_ + 4096);                                          \
-        vr3 = *reinterpret_cast<const uint4*>(vp_ + 6144);                                          \
-    } while (0)
-#define STAGE_STORE(BUF)                                                                            \
-    do {                                                                                            \
-        unsigned char* kb_ = (BUF) + st_k_off;                                                      \
-        unsigned char* vb_ = (BUF) + st_v_off;                                                      \
-        *reinterpret_cast<uint4*>(kb_) = kr0;                                                       \
-        *reinterpret_cast<uint4*>(kb_ + 16 * 256) = kr1;                                            \
-        *reinterpret_cast<uint4*>(kb_ + 32 * 256) = kr2;                                            \
-        *reinterpret_cast<uint4*>(kb_ + 48 * 256) = kr3;                                            \
-        *reinterpret_cast<uint4*>(vb_) = vr0;                                                       \
-        *reinterpret_cast<uint4*>(vb_ + 32 * 128) = vr1;                                            \
-        *reinterpret_cast<uint4*>(vb_ + 64 * 128) = vr2;                                            \
-        *reinterpret_cast<uint4*>(vb_ + 96 * 128) = vr3;                                            \
+// Direct global -> LDS staging (global_load_lds_dwordx4, 1 KiB per wave-instruction, no staging VGPRs, no
+// ds_write).  The LDS image of a wave-instruction is lane-linear (base + lane*16), so the XOR swizzle of the tile is
+// applied on the per-lane SOURCE address: piece pc = 4*wave + i covers K rows 4pc..4pc+3 (16 chunks each) or V^T rows
+// 8pc..8pc+7 (8 chunks each); lane l lands on chunk c' = l&15 (l&7) of row 4pc + (l>>4) (8pc + (l>>3)) and therefore
+// fetches source chunk c' ^ swizzle_key(row).
+// Issued through inline asm: with the builtin, hipcc cannot prove that later ds_reads do not alias the DMA destination
+// and drains vmcnt(0) before the first ds_read of the tile, which serialises prefetch and compute.  The asm form is
+// invisible to its waitcnt bookkeeping, so the kernel waits itself (STAGE_WAIT) right before the barrier that
+// publishes the tile.  M0 (DMA destination base) is saved/restored inside the statement (guide 5.7).
+__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(gsrc), "s"(lds_dst)
+        : "memory");
+}
+#define GLDS16(GPTR, LDSOFF) glds16((const void*)(GPTR), (LDSOFF))
+#define STAGE_WAIT() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#define STAGE_TILE(KPTR, VPTR, BUF)                                                               \
+    do {                                                                                          \
+        const uint16_t* kp_ = (KPTR);                                                             \
+        const uint16_t* vp_ = (VPTR);                                                             \
+        const unsigned lb_ = smem_base + (BUF) * BUF_BYTES + wave_u * 4096;                       \
+        GLDS16(kp_ + k_src0, lb_);                                                                \
+        GLDS16(kp_ + k_src1, lb_ + 1024);                                                         \
+        GLDS16(kp_ + k_src2, lb_ + 2048);                                                         \
+        GLDS16(kp_ + k_src3, lb_ + 3072);                                                         \
+        GLDS16(vp_ + v_src0, lb_ + K_TILE_BYTES);                                                 \
+        GLDS16(vp_ + v_src1, lb_ + K_TILE_BYTES + 1024);                                          \
+        GLDS16(vp_ + v_src2, lb_ + K_TILE_BYTES + 2048);                                          \
+        GLDS16(vp_ + v_src3, lb_ + K_TILE_BYTES + 3072);                                          \
     } while (0)
 
 // Lazy running max: m~ is an integer-valued upper reference of each row's max, raised (by an integer step, so every
@@ -147,11 +151,20 @@ __device__ __forceinline__ void attn_block(const AttnParams& P, unsigned char* s
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks)
         v_addr[ks] = K_TILE_BYTES + lq * 128 + ((((ks >> 1) * 4 + hi * 2 + (ks & 1)) ^ ((lq >> 1) & 7)) << 4);
-    // staging: thread -> K row (tid>>4) + 16i, 16-B chunk tid&15 (rows 16i apart keep the same swizzle key);
-    //          V^T row (tid>>3) + 32i, chunk tid&7 (rows 32i apart keep the same swizzle key)
-    const int st_k_off = (tid >> 4) * 256 + (((tid & 15) ^ ((tid >> 4) & 15)) << 4);
-    const int st_v_off = K_TILE_BYTES + (tid >> 3) * 128 + (((tid & 7) ^ ((tid >> 4) & 7)) << 4);
-    uint4 kr0, kr1, kr2, kr3, vr0, vr1, vr2, vr3;
+    // per-lane source offsets (elements) of the four K and four V^T pieces this wave stages per tile
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const unsigned smem_base =
+        __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem);
+    const int kr_ = 16 * wave_u + (lane >> 4), kc_ = lane & 15, ksw_ = lane >> 4;
+    const long long k_src0 = (long long)(kr_ + 0) * P.k_ss + ((kc_ ^ (0 + ksw_)) << 3);
+    const long long k_src1 = (long long)(kr_ + 4) * P.k_ss + ((kc_ ^ (4 + ksw_)) << 3);
+    const long long k_src2 = (long long)(kr_ + 8) * P.k_ss + ((kc_ ^ (8 + ksw_)) << 3);
+    const long long k_src3 = (long long)(kr_ + 12) * P.k_ss + ((kc_ ^ (12 + ksw_)) << 3);
+    const int vr_ = 32 * wave_u + (lane >> 3), vc_ = lane & 7, vsw_ = lane >> 4;
+    const int v_src0 = (vr_ + 0) * 64 + ((vc_ ^ ((0 + vsw_) & 7)) << 3);
+    const int v_src1 = (vr_ + 8) * 64 + ((vc_ ^ ((4 + vsw_) & 7)) << 3);
+    const int v_src2 = (vr_ + 16) * 64 + ((vc_ ^ ((8 + vsw_) & 7)) << 3);
+    const int v_src3 = (vr_ + 24) * 64 + ((vc_ ^ ((12 + vsw_) & 7)) << 3);
 
     // one 64-key tile out of LDS buffer BUF (0/1); `blk` = kv block id, HALF = which half of it
 #define COMPUTE_TILE(BUF, HALF)                                                                                  \
@@ -161,16 +174,24 @@ __device__ __forceinline__ void attn_block(const AttnParams& P, unsigned char* s
         if (TEXT || key0 < seqlen) { /* a tile entirely past seqlen contributes exp2(-inf) = 0 */                \
             f32x16 s0, s1;                                                                                       \
             {                                                                                                    \
-                const uint4 ka = *reinterpret_cast<const uint4*>(cur + k_addr[0]);                               \
-                const uint4 kb = *reinterpret_cast<const uint4*>(cur + k_addr[0] + 8192);                        \
-                s0 = mfma32<T>(ka, qf[0], cinit);                                                                \
-                s1 = mfma32<T>(kb, qf[0], cinit);                                                                \
-            }                                                                                                    \
-            _Pragma("unroll") for (int ds = 1; ds < 8; ++ds) {                                                   \
-                const uint4 ka = *reinterpret_cast<const uint4*>(cur + k_addr[ds]);                              \
-                const uint4 kb = *reinterpret_cast<const uint4*>(cur + k_addr[ds] + 8192);                       \
-                s0 = mfma32<T>(ka, qf[ds], s0);                                                                  \
-                s1 = mfma32<T>(kb, qf[ds], s1);                                                                  \
+                uint4 ka[8], kb[8];                                                                              \
+                _Pragma("unroll") for (int ds = 0; ds < 8; ++ds) {                                               \
+                    ka[ds] = *reinterpret_cast<const uint4*>(cur + k_addr[ds]);                                  \
+                    kb[ds] = *reinterpret_cast<const uint4*>(cur + k_addr[ds] + 8192);                           \
+                }                                                                                                \
+                s0 = mfma32<T>(ka[0], qf[0], cinit);                                                             \
+                s1 = mfma32<T>(kb[0], qf[0], cinit);                                                             \
+                _Pragma("unroll") for (int ds = 1; ds < 8; ++ds) {                                               \
+                    s0 = mfma32<T>(ka[ds], qf[ds], s0);                                                          \
+                    s1 = mfma32<T>(kb[ds], qf[ds], s1);                                                          \
+                }                                                                                                \
+                /* issue order: LDS reads run 2 k-steps (4 reads) ahead of the MFMAs that consume them */        \
+                __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);                                               \
+                _Pragma("unroll") for (int g_ = 0; g_ < 5; ++g_) {                                               \
+                    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                                           \
+                    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);                                           \
+                }                                                                                                \
+                __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);                                               \
             }                                                                                                    \
             if (TEXT) {                                                                                          \
                 _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                                 \
@@ -228,36 +249,47 @@ __device__ __forceinline__ void attn_block(const AttnParams& P, unsigned char* s
             pf[3] = make_uint4(pack2<T>(s1[8], s1[9]), pack2<T>(s1[10], s1[11]), pack2<T>(s1[12], s1[13]),       \
                                pack2<T>(s1[14], s1[15]));                                                        \
             /* O^T += V^T P^T: four independent accumulator chains per k-step */                                 \
-            _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) {                                                   \
-                _Pragma("unroll") for (int db = 0; db < 4; ++db) {                                               \
-                    const uint4 va = *reinterpret_cast<const uint4*>(cur + v_addr[ks] + db * 4096);              \
-                    oacc[db] = mfma32<T>(va, pf[ks], oacc[db]);                                                  \
+            {                                                                                                    \
+                uint4 va[4][4];                                                                                  \
+                _Pragma("unroll") for (int ks = 0; ks < 4; ++ks)                                                 \
+                    _Pragma("unroll") for (int db = 0; db < 4; ++db)                                             \
+                        va[ks][db] = *reinterpret_cast<const uint4*>(cur + v_addr[ks] + db * 4096);              \
+                _Pragma("unroll") for (int ks = 0; ks < 4; ++ks)                                                 \
+                    _Pragma("unroll") for (int db = 0; db < 4; ++db)                                             \
+                        oacc[db] = mfma32<T>(va[ks][db], pf[ks], oacc[db]);                                      \
+                /* reads of k-step ks+1 are issued before the MFMAs of k-step ks */                              \
+                __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);                                               \
+                _Pragma("unroll") for (int g_ = 0; g_ < 2; ++g_) {                                               \
+                    __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);                                           \
+                    __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);                                           \
                 }                                                                                                \
+                __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);                                               \
             }                                                                                                    \
         }                                                                                                        \
     } while (0)
 
     if (nkept > 0) {
         const int blk0 = TEXT ? 0 : list[0];
-        STAGE_LOAD(kbh + (long long)blk0 * 128 * P.k_ss, vbh + (long long)blk0 * 2 * (128 * KT));
-        STAGE_STORE(smem);
+        STAGE_TILE(kbh + (long long)blk0 * 128 * P.k_ss, vbh + (long long)blk0 * 2 * (128 * KT), 0);
     }
+    STAGE_WAIT();
     __syncthreads();
 
     for (int i = 0; i < nkept; ++i) {
         const int blk = TEXT ? i : list[i];
-        // half 0 lives in buffer 0; fetch half 1 of the same block into buffer 1 meanwhile
-        STAGE_LOAD(kbh + ((long long)blk * 128 + KT) * P.k_ss, vbh + ((long long)blk * 2 + 1) * (128 * KT));
+        // half 0 lives in buffer 0; fetch half 1 of the same block into buffer 1 meanwhile (buffer 1 was last read
+        // before the barrier that ended the previous iteration)
+        STAGE_TILE(kbh + ((long long)blk * 128 + KT) * P.k_ss, vbh + ((long long)blk * 2 + 1) * (128 * KT), 1);
         COMPUTE_TILE(0, 0);
-        STAGE_STORE(smem + BUF_BYTES);
+        STAGE_WAIT();
         __syncthreads();
         {   // half 1 in buffer 1; fetch half 0 of the next kept block (clamped: the last re-fetch is never consumed)
             const int in = (i + 1 < nkept) ? i + 1 : i;
             const int nblk = TEXT ? in : list[in];
-            STAGE_LOAD(kbh + ((long long)nblk * 128) * P.k_ss, vbh + ((long long)nblk * 2) * (128 * KT));
+            STAGE_TILE(kbh + ((long long)nblk * 128) * P.k_ss, vbh + ((long long)nblk * 2) * (128 * KT), 0);
         }
         COMPUTE_TILE(1, 1);
-        STAGE_STORE(smem);
+        STAGE_WAIT();
         __syncthreads();
     }
 #undef COMPUTE_TILE
