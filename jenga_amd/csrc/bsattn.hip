@@ -58,38 +58,59 @@ constexpr int BUF_BYTES = K_TILE_BYTES + V_TILE_BYTES;
 // Issued through inline asm: with the builtin, hipcc cannot prove that later ds_reads do not alias the DMA destination
 // and drains vmcnt(0) before the first ds_read of the tile, which serialises prefetch and compute.  The asm form is
 // invisible to its waitcnt bookkeeping, so the kernel waits itself (STAGE_WAIT) right before the barrier that
-// publishes the tile.  M0 (DMA destination base) is saved/restored inside the statement (guide 5.7).
-__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
+// publishes the tile.  One statement stages a whole tile: 4 K pieces + 4 V^T pieces of 1 KiB each for this wave,
+// global address = uniform 64-bit base (SGPR pair) + per-lane 32-bit byte offset (loop-invariant VGPR), LDS
+// destination = M0 (saved/restored inside the statement, guide 5.7), advanced by 1 KiB per piece.
+__device__ __forceinline__ void stage_tile(const void* kbase, const void* vbase, unsigned lds_k, unsigned lds_v,
+                                           unsigned k0, unsigned k1, unsigned k2, unsigned k3, unsigned v0,
+                                           unsigned v1, unsigned v2, unsigned v3) {
     unsigned keep;
     asm volatile(
-        "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %1\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %5, %3\n\t"
+        "s_add_u32 m0, m0, 0x400\n\t"
+        "global_load_lds_dwordx4 %6, %3\n\t"
+        "s_add_u32 m0, m0, 0x400\n\t"
+        "global_load_lds_dwordx4 %7, %3\n\t"
+        "s_add_u32 m0, m0, 0x400\n\t"
+        "global_load_lds_dwordx4 %8, %3\n\t"
+        "s_mov_b32 m0, %2\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %9, %4\n\t"
+        "s_add_u32 m0, m0, 0x400\n\t"
+        "global_load_lds_dwordx4 %10, %4\n\t"
+        "s_add_u32 m0, m0, 0x400\n\t"
+        "global_load_lds_dwordx4 %11, %4\n\t"
+        "s_add_u32 m0, m0, 0x400\n\t"
+        "global_load_lds_dwordx4 %12, %4\n\t"
+        "s_mov_b32 m0, %0"
         : "=&s"(keep)
-        : "v"(gsrc), "s"(lds_dst)
-        : "memory");
+        : "s"(lds_k), "s"(lds_v), "s"(kbase), "s"(vbase), "v"(k0), "v"(k1), "v"(k2), "v"(k3), "v"(v0), "v"(v1),
+          "v"(v2), "v"(v3)
+        : "memory", "scc");
 }
-#define GLDS16(GPTR, LDSOFF) glds16((const void*)(GPTR), (LDSOFF))
+#define STAGE_TILE(KPTR, VPTR, BUF)                                                                        \
+    stage_tile((KPTR), (VPTR), smem_base + (BUF) * BUF_BYTES + wave_u * 4096,                             \
+               smem_base + (BUF) * BUF_BYTES + K_TILE_BYTES + wave_u * 4096, k_src0, k_src1, k_src2, k_src3, \
+               v_src0, v_src1, v_src2, v_src3)
 #define STAGE_WAIT() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
-#define STAGE_TILE(KPTR, VPTR, BUF)                                                               \
-    do {                                                                                          \
-        const uint16_t* kp_ = (KPTR);                                                             \
-        const uint16_t* vp_ = (VPTR);                                                             \
-        const unsigned lb_ = smem_base + (BUF) * BUF_BYTES + wave_u * 4096;                       \
-        GLDS16(kp_ + k_src0, lb_);                                                                \
-        GLDS16(kp_ + k_src1, lb_ + 1024);                                                         \
-        GLDS16(kp_ + k_src2, lb_ + 2048);                                                         \
-        GLDS16(kp_ + k_src3, lb_ + 3072);                                                         \
-        GLDS16(vp_ + v_src0, lb_ + K_TILE_BYTES);                                                 \
-        GLDS16(vp_ + v_src1, lb_ + K_TILE_BYTES + 1024);                                          \
-        GLDS16(vp_ + v_src2, lb_ + K_TILE_BYTES + 2048);                                          \
-        GLDS16(vp_ + v_src3, lb_ + K_TILE_BYTES + 3072);                                          \
-    } while (0)
 
 // Lazy running max: m~ is an integer-valued upper reference of each row's max, raised (by an integer step, so every
 // rescale factor is an exact power of two) only when a row's new max exceeds it by more than LAZY_THR in log2 units.
-// -m~ rides in the MFMA C operand of the first K.Q^T step, so S arrives already shifted and P = exp2(S) needs no
-// subtraction; O and l are rescaled only in the (rare) raise path.  P <= 2^LAZY_THR keeps the storage dtype's relative
+// P = exp2(S - m~) costs one packed add per two scores; O and l are rescaled only in the (rare) raise path (keeping
+// -m~ in the MFMA C operand instead was tried: hipcc then copies the 32 C registers every tile, which costs more).  P <= 2^LAZY_THR keeps the storage dtype's relative
 // precision (power-of-two scaling commutes with rounding), so results match the eager max up to fp32 rounding.
 constexpr float LAZY_THR = 8.0f;
+#ifndef JENGA_SETPRIO
+#define JENGA_SETPRIO 1
+#endif
+#if JENGA_SETPRIO
+#define MFMA_PRIO(x) __builtin_amdgcn_s_setprio(x)
+#else
+#define MFMA_PRIO(x)
+#endif
 
 template <typename T, bool TEXT>
 __device__ __forceinline__ void attn_block(const AttnParams& P, unsigned char* smem, int b, int h, int m) {
@@ -106,7 +127,7 @@ __device__ __forceinline__ void attn_block(const AttnParams& P, unsigned char* s
     } else {
         const long long row = ((long long)b * P.H + h) * P.nq_img + m;
         list = P.idx + row * P.n_blocks;
-        nkept = P.cnt[row];
+        nkept = __builtin_amdgcn_readfirstlane(P.cnt[row]);
     }
 
     // ---- Q fragments: lane (q, hi) keeps Q[q][ds*16 + hi*8 .. +7] for ds = 0..7 ----
@@ -134,12 +155,13 @@ __device__ __forceinline__ void attn_block(const AttnParams& P, unsigned char* s
 #pragma unroll
         for (int r = 0; r < 16; ++r) oacc[i][r] = 0.f;
     float l_i = 0.f;
-    float m_ref = 0.f;      // m~ (integer valued)
-    f32x16 cinit;           // MFMA C operand of the first K.Q^T step: -m~ (TEXT: -m~ / qk_scale, scaled afterwards)
+    float neg_m = 0.f;      // -m~ (integer valued)
+    f32x16 zero16;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) cinit[r] = 0.f;
+    for (int r = 0; r < 16; ++r) zero16[r] = 0.f;
     bool first = true;
-    const float inv_scale = 1.0f / P.qk_scale;
+    // output row pointer computed up front: lets the o_* strides die before the loop (SGPR pressure)
+    uint16_t* const op = P.o + b * P.o_sb + qrow * P.o_ss + h * P.o_sh + hi * 4;
 
     const uint16_t* kbh = P.k + b * P.k_sb + h * P.k_sh;
     const uint16_t* vbh = P.vt + ((long long)b * P.H + h) * (long long)P.n_blocks * 2 * (128 * KT);
@@ -156,22 +178,23 @@ __device__ __forceinline__ void attn_block(const AttnParams& P, unsigned char* s
     const unsigned smem_base =
         __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem);
     const int kr_ = 16 * wave_u + (lane >> 4), kc_ = lane & 15, ksw_ = lane >> 4;
-    const long long k_src0 = (long long)(kr_ + 0) * P.k_ss + ((kc_ ^ (0 + ksw_)) << 3);
-    const long long k_src1 = (long long)(kr_ + 4) * P.k_ss + ((kc_ ^ (4 + ksw_)) << 3);
-    const long long k_src2 = (long long)(kr_ + 8) * P.k_ss + ((kc_ ^ (8 + ksw_)) << 3);
-    const long long k_src3 = (long long)(kr_ + 12) * P.k_ss + ((kc_ ^ (12 + ksw_)) << 3);
+    const unsigned kss_b = (unsigned)P.k_ss * 2u;   // K row stride in bytes (64 rows x stride < 2^31, checked on the host)
+    const unsigned k_src0 = (unsigned)(kr_ + 0) * kss_b + ((kc_ ^ (0 + ksw_)) << 4);
+    const unsigned k_src1 = (unsigned)(kr_ + 4) * kss_b + ((kc_ ^ (4 + ksw_)) << 4);
+    const unsigned k_src2 = (unsigned)(kr_ + 8) * kss_b + ((kc_ ^ (8 + ksw_)) << 4);
+    const unsigned k_src3 = (unsigned)(kr_ + 12) * kss_b + ((kc_ ^ (12 + ksw_)) << 4);
     const int vr_ = 32 * wave_u + (lane >> 3), vc_ = lane & 7, vsw_ = lane >> 4;
-    const int v_src0 = (vr_ + 0) * 64 + ((vc_ ^ ((0 + vsw_) & 7)) << 3);
-    const int v_src1 = (vr_ + 8) * 64 + ((vc_ ^ ((4 + vsw_) & 7)) << 3);
-    const int v_src2 = (vr_ + 16) * 64 + ((vc_ ^ ((8 + vsw_) & 7)) << 3);
-    const int v_src3 = (vr_ + 24) * 64 + ((vc_ ^ ((12 + vsw_) & 7)) << 3);
+    const unsigned v_src0 = (unsigned)(vr_ + 0) * 128 + ((vc_ ^ ((0 + vsw_) & 7)) << 4);
+    const unsigned v_src1 = (unsigned)(vr_ + 8) * 128 + ((vc_ ^ ((4 + vsw_) & 7)) << 4);
+    const unsigned v_src2 = (unsigned)(vr_ + 16) * 128 + ((vc_ ^ ((8 + vsw_) & 7)) << 4);
+    const unsigned v_src3 = (unsigned)(vr_ + 24) * 128 + ((vc_ ^ ((12 + vsw_) & 7)) << 4);
 
     // one 64-key tile out of LDS buffer BUF (0/1); `blk` = kv block id, HALF = which half of it
-#define COMPUTE_TILE(BUF, HALF)                                                                                  \
+#define COMPUTE_TILE(BUF, HALF, SLOW)                                                                            \
     do {                                                                                                         \
         const unsigned char* cur = smem + (BUF) * BUF_BYTES;                                                     \
         const int key0 = blk * 128 + (HALF) * KT;                                                                \
-        if (TEXT || key0 < seqlen) { /* a tile entirely past seqlen contributes exp2(-inf) = 0 */                \
+        if (!(SLOW) || key0 < seqlen) { /* a tile entirely past seqlen contributes exp2(-inf) = 0 */             \
             f32x16 s0, s1;                                                                                       \
             {                                                                                                    \
                 uint4 ka[8], kb[8];                                                                              \
@@ -179,8 +202,9 @@ __device__ __forceinline__ void attn_block(const AttnParams& P, unsigned char* s
                     ka[ds] = *reinterpret_cast<const uint4*>(cur + k_addr[ds]);                                  \
                     kb[ds] = *reinterpret_cast<const uint4*>(cur + k_addr[ds] + 8192);                           \
                 }                                                                                                \
-                s0 = mfma32<T>(ka[0], qf[0], cinit);                                                             \
-                s1 = mfma32<T>(kb[0], qf[0], cinit);                                                             \
+                MFMA_PRIO(1);                                                                                    \
+                s0 = mfma32<T>(ka[0], qf[0], zero16);                                                            \
+                s1 = mfma32<T>(kb[0], qf[0], zero16);                                                            \
                 _Pragma("unroll") for (int ds = 1; ds < 8; ++ds) {                                               \
                     s0 = mfma32<T>(ka[ds], qf[ds], s0);                                                          \
                     s1 = mfma32<T>(kb[ds], qf[ds], s1);                                                          \
@@ -192,13 +216,14 @@ __device__ __forceinline__ void attn_block(const AttnParams& P, unsigned char* s
                     __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);                                           \
                 }                                                                                                \
                 __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);                                               \
+                MFMA_PRIO(0);                                                                                    \
             }                                                                                                    \
             if (TEXT) {                                                                                          \
                 _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                                 \
                     s0[r] *= P.qk_scale;                                                                         \
                     s1[r] *= P.qk_scale;                                                                         \
                 }                                                                                                \
-            } else {                                                                                             \
+            } else if (SLOW) {                                                                                   \
                 if (blk >= P.text_block_start) {                                                                 \
                     _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                             \
                         s0[r] += P.text_amp;                                                                     \
@@ -213,28 +238,26 @@ __device__ __forceinline__ void attn_block(const AttnParams& P, unsigned char* s
                     }                                                                                            \
                 }                                                                                                \
             }                                                                                                    \
-            /* row max of the shifted scores (both half-waves of a row agree after the exchange) */              \
+            /* local max of this lane's 32 scores relative to the lazy reference m~.  The common path needs no      \
+               cross-half exchange: a wave-wide ballot decides whether ANY row must raise m~; only the (rare) raise  \
+               path pays the ds_bpermute so that both half-waves of a row apply the same integer step. */           \
             float tmax = fmaxf(s0[0], s1[0]);                                                                    \
             _Pragma("unroll") for (int r = 1; r < 16; ++r) tmax = fmaxf(tmax, fmaxf(s0[r], s1[r]));              \
-            tmax = fmaxf(tmax, __shfl_xor(tmax, 32));                                                            \
+            tmax += neg_m;                                                                                       \
             if (first || __any(tmax > LAZY_THR)) { /* raise m~ (rare): exact power-of-two rescale */             \
+                tmax = fmaxf(tmax, __shfl_xor(tmax, 32));                                                        \
                 const float delta = (first || tmax > LAZY_THR) ? ceilf(tmax) : 0.f;                              \
                 const float f2 = __builtin_amdgcn_exp2f(-delta);                                                 \
-                m_ref += delta;                                                                                  \
+                neg_m -= delta;                                                                                  \
                 l_i *= f2;                                                                                       \
-                _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                                 \
-                    s0[r] -= delta;                                                                              \
-                    s1[r] -= delta;                                                                              \
-                    cinit[r] = TEXT ? -m_ref * inv_scale : -m_ref;                                               \
-                }                                                                                                \
                 _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                    \
                     _Pragma("unroll") for (int r = 0; r < 16; ++r) oacc[i][r] *= f2;                             \
                 first = false;                                                                                   \
             }                                                                                                    \
             float psum = 0.f;                                                                                    \
             _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                                     \
-                s0[r] = __builtin_amdgcn_exp2f(s0[r]);                                                           \
-                s1[r] = __builtin_amdgcn_exp2f(s1[r]);                                                           \
+                s0[r] = __builtin_amdgcn_exp2f(s0[r] + neg_m);                                                   \
+                s1[r] = __builtin_amdgcn_exp2f(s1[r] + neg_m);                                                   \
                 psum += s0[r] + s1[r];                                                                           \
             }                                                                                                    \
             l_i += psum;                                                                                         \
@@ -254,6 +277,7 @@ __device__ __forceinline__ void attn_block(const AttnParams& P, unsigned char* s
                 _Pragma("unroll") for (int ks = 0; ks < 4; ++ks)                                                 \
                     _Pragma("unroll") for (int db = 0; db < 4; ++db)                                             \
                         va[ks][db] = *reinterpret_cast<const uint4*>(cur + v_addr[ks] + db * 4096);              \
+                MFMA_PRIO(1);                                                                                    \
                 _Pragma("unroll") for (int ks = 0; ks < 4; ++ks)                                                 \
                     _Pragma("unroll") for (int db = 0; db < 4; ++db)                                             \
                         oacc[db] = mfma32<T>(va[ks][db], pf[ks], oacc[db]);                                      \
@@ -264,40 +288,70 @@ __device__ __forceinline__ void attn_block(const AttnParams& P, unsigned char* s
                     __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);                                           \
                 }                                                                                                \
                 __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);                                               \
+                MFMA_PRIO(0);                                                                                    \
             }                                                                                                    \
         }                                                                                                        \
     } while (0)
 
+    // Kept lists ascend, so the blocks that need the text_amp add or the kv-length mask (text blocks, a padded last
+    // block) are the LAST ones: the fast loop carries neither code path (the mask path alone costs 60+ SGPRs and made
+    // the whole loop spill), the few remaining blocks go through the slow loop.
+    int n_fast = nkept;
+    if (!TEXT) {
+        while (n_fast > 0) {
+            const int bl = __builtin_amdgcn_readfirstlane(list[n_fast - 1]);
+            if (bl >= P.text_block_start || (bl + 1) * 128 > seqlen) --n_fast; else break;
+        }
+    }
+    // The kept list is read 64 entries at a time into one VGPR (lane j holds entry base+j) and entries are pulled out
+    // with v_readlane: a per-iteration `list[i]` is a VECTOR load for hipcc (it cannot prove the list is not aliased
+    // by the O stores), whose vmcnt(0) wait would also drain the LDS-DMA prefetch every iteration.
+    int lchunk = 0;
+#define LIST_GET(J, DST)                                                                                         \
+    do {                                                                                                         \
+        if (TEXT) {                                                                                              \
+            DST = (J);                                                                                           \
+        } else {                                                                                                 \
+            if (((J) & 63) == 0) lchunk = ((J) + lane < nkept) ? list[(J) + lane] : 0;                           \
+            DST = __builtin_amdgcn_readlane(lchunk, (J) & 63);                                                   \
+        }                                                                                                        \
+    } while (0)
+    int blk = 0;
     if (nkept > 0) {
-        const int blk0 = TEXT ? 0 : list[0];
-        STAGE_TILE(kbh + (long long)blk0 * 128 * P.k_ss, vbh + (long long)blk0 * 2 * (128 * KT), 0);
+        LIST_GET(0, blk);
+        STAGE_TILE(kbh + (long long)blk * 128 * P.k_ss, vbh + (long long)blk * 2 * (128 * KT), 0);
     }
     STAGE_WAIT();
     __syncthreads();
 
-    for (int i = 0; i < nkept; ++i) {
-        const int blk = TEXT ? i : list[i];
-        // half 0 lives in buffer 0; fetch half 1 of the same block into buffer 1 meanwhile (buffer 1 was last read
-        // before the barrier that ended the previous iteration)
-        STAGE_TILE(kbh + ((long long)blk * 128 + KT) * P.k_ss, vbh + ((long long)blk * 2 + 1) * (128 * KT), 1);
-        COMPUTE_TILE(0, 0);
-        STAGE_WAIT();
-        __syncthreads();
-        {   // half 1 in buffer 1; fetch half 0 of the next kept block (clamped: the last re-fetch is never consumed)
-            const int in = (i + 1 < nkept) ? i + 1 : i;
-            const int nblk = TEXT ? in : list[in];
-            STAGE_TILE(kbh + ((long long)nblk * 128) * P.k_ss, vbh + ((long long)nblk * 2) * (128 * KT), 0);
-        }
-        COMPUTE_TILE(1, 1);
-        STAGE_WAIT();
-        __syncthreads();
+#define BLOCK_LOOP(FROM, TO, SLOW)                                                                               \
+    for (int i = (FROM); i < (TO); ++i) {                                                                        \
+        /* half 0 lives in buffer 0; fetch half 1 of the same block into buffer 1 meanwhile (buffer 1 was last    \
+           read before the barrier that ended the previous iteration) */                                         \
+        STAGE_TILE(kbh + ((long long)blk * 128 + KT) * P.k_ss, vbh + ((long long)blk * 2 + 1) * (128 * KT), 1);  \
+        COMPUTE_TILE(0, 0, SLOW);                                                                                \
+        STAGE_WAIT();                                                                                            \
+        __syncthreads();                                                                                         \
+        /* half 1 in buffer 1; fetch half 0 of the next kept block (clamped: the last re-fetch is unused) */      \
+        int nblk = blk;                                                                                          \
+        if (i + 1 < nkept) LIST_GET(i + 1, nblk);                                                                \
+        STAGE_TILE(kbh + ((long long)nblk * 128) * P.k_ss, vbh + ((long long)nblk * 2) * (128 * KT), 0);         \
+        COMPUTE_TILE(1, 1, SLOW);                                                                                \
+        STAGE_WAIT();                                                                                            \
+        __syncthreads();                                                                                         \
+        blk = nblk;                                                                                              \
     }
+    BLOCK_LOOP(0, n_fast, 0)
+    if (!TEXT) {
+        BLOCK_LOOP(n_fast, nkept, 1)
+    }
+#undef LIST_GET
+#undef BLOCK_LOOP
 #undef COMPUTE_TILE
 
     // ---- epilogue: o = acc / l, rows >= seqlen written as zeros (image rows only) ----
     const float l_tot = l_i + __shfl_xor(l_i, 32);
     const bool row_ok = TEXT || (qrow < seqlen);
-    uint16_t* op = P.o + b * P.o_sb + qrow * P.o_ss + h * P.o_sh + hi * 4;
 #pragma unroll
     for (int db = 0; db < 4; ++db) {
 #pragma unroll
@@ -368,6 +422,10 @@ extern "C" int jenga_bsattn_fwd(void* stream, const void* q, const void* k, cons
     if (dtype != JENGA_BF16 && dtype != JENGA_FP16) {
         set_error("jenga_bsattn_fwd: dtype must be bf16 or fp16");
         return JENGA_EUNSUPPORTED;
+    }
+    if (k_ss <= 0 || k_ss > (1 << 23)) {  // per-lane 32-bit byte offsets inside a 64-row K tile
+        set_error("jenga_bsattn_fwd: key sequence stride %lld out of range", (long long)k_ss);
+        return JENGA_EINVAL;
     }
     AttnParams P;
     P.q = (const uint16_t*)q;
