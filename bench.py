@@ -185,6 +185,12 @@ def main():
     else:
         sec_per_video = elapsed
     ps = prof.summary()
+    traffic = None
+    try:   # HBM-side bytes per launch from the committed PMC passes (profiles/), scaled by this run's kept pairs
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_bsattn.json")))
+        traffic = int(pmc["derived"]["traffic_bytes_per_kept_pair"] * ps["pairs"] / max(ps["launches"], 1))
+    except Exception:
+        pass
     flops = ps["pairs"] * FLOPS_PER_PAIR
     ach = flops / (ps["total_ms"] * 1e-3) / 1e12 if ps["total_ms"] > 0 else 0.0
     res = {
@@ -204,7 +210,10 @@ def main():
                    "weights": "random init N(0,0.02), seed 0", "finite_output": finite},
         "roofline": {"kernel": "jenga::bsattn_fwd_kernel<bf16>", "bound": "mfma", "achieved": round(ach, 1),
                      "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_PEAK_TFLOPS, 4),
-                     "traffic": None, "launches": ps["launches"],
+                     "traffic": traffic,
+                     "traffic_source": "profiles/r01_pmc_bsattn.json: (2*FETCH_SIZE + WRITE_SIZE) per kept block pair "
+                                       "from separate rocprofv3 --pmc passes, x this run's pairs per launch",
+                     "launches": ps["launches"],
                      "avg_launch_ms": round(ps["total_ms"] / max(ps["launches"], 1), 3),
                      "kept_block_pairs_per_launch": ps["pairs"] // max(ps["launches"], 1),
                      "algorithmic_flops": "4*128^3 per kept (128-query, 128-key) block pair, realised masks"},

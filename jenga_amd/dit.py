@@ -106,6 +106,7 @@ class MMDoubleStreamBlock(nn.Module):
         self.txt_mlp = MLP(hidden_size, mlp_hidden, **fk)
         self.hybrid_seq_parallel_attn = None
 
+    @torch.no_grad()   # inference only, like the reference (hyvideo/inference.py:195 disables grad globally)
     def forward(self, img, txt, vec, cu_seqlens_q=None, cu_seqlens_kv=None, max_seqlen_q=None, max_seqlen_kv=None,
                 freqs_cis: tuple = None, sa_drop_rate: float = 0.0, txt_amp: float = 1.0, curve_sel: list = None,
                 p_remain_rates: float = 0.5, txt_block_num: int = 2, per_block_token: int = 128):
@@ -172,6 +173,7 @@ class MMSingleStreamBlock(nn.Module):
         self.modulation = ModulateDiT(hidden_size, 3, **fk)
         self.hybrid_seq_parallel_attn = None
 
+    @torch.no_grad()
     def forward(self, x, vec, txt_len, cu_seqlens_q=None, cu_seqlens_kv=None, max_seqlen_q=None, max_seqlen_kv=None,
                 freqs_cis: Tuple[torch.Tensor, torch.Tensor] = None, sa_drop_rate: float = 0.0, txt_amp: float = 1.0,
                 curve_sel: list = None, p_remain_rates: float = 0.5, txt_block_num: int = 2,
