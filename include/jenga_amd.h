@@ -68,6 +68,21 @@ int jenga_rmsnorm_rope(void* stream, const void* x, void* out, const void* weigh
                        int64_t x_sh, int64_t o_sb, int64_t o_ss, int64_t o_sh, int64_t s_rope, float eps,
                        int dtype);
 
+/* Wan flavour of the pre-ops (wan/modules/model_mul.py).
+ * jenga_rmsnorm_rows: WanRMSNorm.forward :74-90 over the full model width C (1536 / 5120):
+ *   out = (x.float()*rsqrt(mean(x^2)+eps)).type_as(x) * weight; weight_fp32 != 0: weight and out are fp32 (torch's
+ *   promotion of dtype*fp32), else weight and out are in dtype.  x [rows, C] with a row stride.
+ * jenga_rope_complex: rope_apply :40-71 -- adjacent pairs as complex numbers multiplied in float64 by
+ *   cos/sin[s][64] (float64 tables already expanded per token, including the Hilbert freq_remap), rounded to fp32
+ *   (out_dtype 2, what rope_apply returns) or on to bf16 (out_dtype 0, what the Wan attention op casts to,
+ *   wan/modules/attention_block_triton_diffres.py:456-463).  in_dtype: 0 bf16, 1 fp16, 2 fp32.  Tokens >= s_rope are
+ *   copied through (the reference concatenates x[i, seq_len:] back, :67). */
+int jenga_rmsnorm_rows(void* stream, const void* x, void* out, const void* weight, int64_t rows, int64_t C,
+                       int64_t x_row_stride, int64_t o_row_stride, float eps, int dtype, int weight_fp32);
+int jenga_rope_complex(void* stream, const void* x, void* out, const double* cos, const double* sin, int64_t B,
+                       int64_t S, int64_t H, int64_t x_sb, int64_t x_ss, int64_t x_sh, int64_t o_sb, int64_t o_ss,
+                       int64_t o_sh, int64_t s_rope, int in_dtype, int out_dtype);
+
 /* ---------------------------------------------------------------------------------------------------
  * Block selection.  Replaces _build_block_index_with_importance_optimized
  * (hyvideo/modules/attention_block_triton_diffres.py:198-295; Wan first_frame_blocks rule

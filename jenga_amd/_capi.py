@@ -22,6 +22,8 @@ SIGNATURES = {
     "jenga_gilbert_neighbors": (_i32, [_vp, _i32, _i32, _i32, _i32, _vp, _vp]),
     "jenga_gather_rows": (_i32, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64]),
     "jenga_rmsnorm_rope": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp] + [_i64] * 10 + [_f32, _i32]),
+    "jenga_rmsnorm_rows": (_i32, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _f32, _i32, _i32]),
+    "jenga_rope_complex": (_i32, [_vp, _vp, _vp, _vp, _vp] + [_i64] * 10 + [_i32, _i32]),
     "jenga_block_pool": (_i32, [_vp, _vp, _vp] + [_i64] * 6 + [_i32]),
     "jenga_block_select": (_i32, [_vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp] + [_i64] * 6 + [_f32, _i64, _i32]),
     "jenga_pack_v_bytes": (ctypes.c_size_t, [_i64, _i64, _i64]),
@@ -172,6 +174,42 @@ def rmsnorm_rope(x, weight, cos, sin, s_rope=None, eps=1e-6, out=None):
     with torch.cuda.device(x.device):
         _check(lib().jenga_rmsnorm_rope(_stream(x.device), _p(x), _p(out), _p(weight), _p(cos), _p(sin), B, S, H,
                                         *xs, *os_, s_rope, float(eps), dtype_code(x.dtype)), "jenga_rmsnorm_rope")
+    return out
+
+
+def rmsnorm_rows(x, weight, eps):
+    """WanRMSNorm: x [..., C] (bf16/fp16, last dim contiguous), weight [C] fp32 or x.dtype -> x.dtype*weight.dtype."""
+    _need_gpu(x, "rmsnorm_rows")
+    C = x.shape[-1]
+    x2 = x.reshape(-1, C)
+    if x2.stride(-1) != 1:
+        x2 = x2.contiguous()
+    w32 = weight.dtype == torch.float32
+    w = weight.to(device=x.device).contiguous() if w32 else weight.to(device=x.device, dtype=x.dtype).contiguous()
+    out = torch.empty(x2.shape, dtype=torch.float32 if w32 else x.dtype, device=x.device)
+    with torch.cuda.device(x.device):
+        _check(lib().jenga_rmsnorm_rows(_stream(x.device), _p(x2), _p(out), _p(w), x2.shape[0], C, x2.stride(0),
+                                        out.stride(0), float(eps), dtype_code(x.dtype), int(w32)),
+               "jenga_rmsnorm_rows")
+    return out.reshape(x.shape)
+
+
+def rope_complex(x, cos64, sin64, s_rope, out_dtype=torch.float32):
+    """x [B,S,H,128] (bf16/fp16/fp32); cos64/sin64 float64 [>=s_rope, 64] -> fp32 (rope_apply's result) or bf16."""
+    _need_gpu(x, "rope_complex")
+    B, S, H, D = x.shape
+    if D != 128 or cos64.dtype != torch.float64 or cos64.shape[-1] != 64 or cos64.shape[0] < s_rope:
+        raise ValueError("rope_complex: head_dim 128 and float64 [S,64] tables required")
+    codes = {torch.bfloat16: 0, torch.float16: 1, torch.float32: 2}
+    if x.dtype not in codes or out_dtype not in (torch.float32, torch.bfloat16):
+        raise ValueError("rope_complex: unsupported dtype")
+    if x.stride(-1) != 1:
+        x = x.contiguous()
+    out = torch.empty((B, S, H, D), dtype=out_dtype, device=x.device)
+    with torch.cuda.device(x.device):
+        _check(lib().jenga_rope_complex(_stream(x.device), _p(x), _p(out), _p(cos64.contiguous()),
+                                        _p(sin64.contiguous()), B, S, H, *_bshd_strides(x), *_bshd_strides(out),
+                                        int(s_rope), codes[x.dtype], codes[out_dtype]), "jenga_rope_complex")
     return out
 
 

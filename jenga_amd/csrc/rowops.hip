@@ -301,3 +301,155 @@ extern "C" int jenga_ulysses_unpack_heads(void* stream, const void* recv, void* 
                                           int64_t N, int64_t y_sb, int64_t y_ss, int64_t y_sh) {
     return ulysses_common(false, stream, recv, y, B, S_loc, H, N, y_sb, y_ss, y_sh);
 }
+
+// ================================================================================================ Wan flavour
+// Full-width RMSNorm (wan/modules/model_mul.py:74-90): y = (x.float() * rsqrt(mean(x^2) + eps)).type_as(x) * weight
+// with weight in fp32 (out fp32, torch type promotion) or in the storage dtype (out in the storage dtype).
+// One workgroup per row; C <= 8192, multiple of 8.
+namespace jenga {
+namespace {
+template <typename T, bool W32>
+__global__ void __launch_bounds__(256) rmsnorm_rows_kernel(const uint16_t* __restrict__ x, void* __restrict__ out,
+                                                           const void* __restrict__ weight, long long rows, int C,
+                                                           long long x_rs, long long o_rs, float eps) {
+    __shared__ float red[4];
+    for (long long row = blockIdx.x; row < rows; row += gridDim.x) {
+        const uint16_t* xr = x + row * x_rs;
+        float f[4][8];
+        float ss = 0.f;
+        int nv = 0;
+        for (int c = threadIdx.x * 8; c < C; c += 256 * 8, ++nv) {
+            unpack8<T>(*reinterpret_cast<const uint4*>(xr + c), f[nv]);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) ss = __fadd_rn(ss, __fmul_rn(f[nv][e], f[nv][e]));
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = ss;
+        __syncthreads();
+        ss = (red[0] + red[1]) + (red[2] + red[3]);
+        __syncthreads();
+        const float r = __fdiv_rn(1.0f, __fsqrt_rn(__fadd_rn(__fdiv_rn(ss, (float)C), eps)));
+        nv = 0;
+        for (int c = threadIdx.x * 8; c < C; c += 256 * 8, ++nv) {
+            float y[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) y[e] = round_to<T>(__fmul_rn(f[nv][e], r));
+            if (W32) {
+                const float4* wp = reinterpret_cast<const float4*>(reinterpret_cast<const float*>(weight) + c);
+                const float4 w0 = wp[0], w1 = wp[1];
+                float4* op = reinterpret_cast<float4*>(reinterpret_cast<float*>(out) + row * o_rs + c);
+                op[0] = make_float4(__fmul_rn(y[0], w0.x), __fmul_rn(y[1], w0.y), __fmul_rn(y[2], w0.z),
+                                    __fmul_rn(y[3], w0.w));
+                op[1] = make_float4(__fmul_rn(y[4], w1.x), __fmul_rn(y[5], w1.y), __fmul_rn(y[6], w1.z),
+                                    __fmul_rn(y[7], w1.w));
+            } else {
+                float wv[8];
+                unpack8<T>(*reinterpret_cast<const uint4*>(reinterpret_cast<const uint16_t*>(weight) + c), wv);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) y[e] = __fmul_rn(y[e], wv[e]);
+                *reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(out) + row * o_rs + c) = pack8<T>(y);
+            }
+        }
+    }
+}
+
+// fp64 complex RoPE (wan/modules/model_mul.py:40-71): pairs (x[2j], x[2j+1]) as complex, multiplied in float64 by
+// (cos, sin)[s][j] (tables already expanded per position, incl. the Hilbert freq_remap), rounded to fp32 (".float()")
+// or further to the storage dtype when the consumer is the bf16 attention op.  Tokens s >= s_rope pass through.
+// IN: 0 = bf16, 1 = fp16, 2 = fp32; OUT: 0 = bf16, 2 = fp32
+template <int IN, int OUT>
+__global__ void rope_complex_kernel(const void* __restrict__ x, void* __restrict__ out, const double* __restrict__ cosT,
+                                    const double* __restrict__ sinT, long long B, long long S, long long H,
+                                    long long x_sb, long long x_ss, long long x_sh, long long o_sb, long long o_ss,
+                                    long long o_sh, long long s_rope) {
+    const int sub = threadIdx.x & 15, rig = threadIdx.x >> 4;
+    const long long rows = B * S * H;
+    for (long long row = (long long)blockIdx.x * 16 + rig; row < rows; row += (long long)gridDim.x * 16) {
+        const long long h = row % H, s = (row / H) % S, b = row / (H * S);
+        const long long xo = b * x_sb + s * x_ss + h * x_sh + sub * 8;
+        float f[8];
+        if (IN == 2) {
+            const float4* p = reinterpret_cast<const float4*>(reinterpret_cast<const float*>(x) + xo);
+            const float4 a = p[0], c = p[1];
+            f[0] = a.x; f[1] = a.y; f[2] = a.z; f[3] = a.w; f[4] = c.x; f[5] = c.y; f[6] = c.z; f[7] = c.w;
+        } else if (IN == 0) {
+            unpack8<BF16>(*reinterpret_cast<const uint4*>(reinterpret_cast<const uint16_t*>(x) + xo), f);
+        } else {
+            unpack8<FP16>(*reinterpret_cast<const uint4*>(reinterpret_cast<const uint16_t*>(x) + xo), f);
+        }
+        if (s < s_rope) {
+            const double* cp = cosT + s * 64 + sub * 4;
+            const double* sp = sinT + s * 64 + sub * 4;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const double a = (double)f[2 * j], bb = (double)f[2 * j + 1], c = cp[j], d = sp[j];
+                const double re = __dsub_rn(__dmul_rn(a, c), __dmul_rn(bb, d));   // (a+ib)(c+id), no fused ops
+                const double im = __dadd_rn(__dmul_rn(a, d), __dmul_rn(bb, c));
+                f[2 * j] = (float)re;
+                f[2 * j + 1] = (float)im;
+            }
+        }
+        const long long oo = b * o_sb + s * o_ss + h * o_sh + sub * 8;
+        if (OUT == 2) {
+            float4* p = reinterpret_cast<float4*>(reinterpret_cast<float*>(out) + oo);
+            p[0] = make_float4(f[0], f[1], f[2], f[3]);
+            p[1] = make_float4(f[4], f[5], f[6], f[7]);
+        } else {
+            *reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(out) + oo) = pack8<BF16>(f);
+        }
+    }
+}
+}  // namespace
+}  // namespace jenga
+
+extern "C" int jenga_rmsnorm_rows(void* stream, const void* x, void* out, const void* weight, int64_t rows, int64_t C,
+                                  int64_t x_row_stride, int64_t o_row_stride, float eps, int dtype, int weight_fp32) {
+    if (!x || !out || !weight || rows < 0 || C <= 0 || (C & 7) || C > 8192 || (x_row_stride & 7) ||
+        (o_row_stride & 7) || ((uintptr_t)x & 15) || ((uintptr_t)out & 15) || ((uintptr_t)weight & 15)) {
+        set_error("jenga_rmsnorm_rows: bad arguments (C must be a multiple of 8, <= 8192)");
+        return JENGA_EINVAL;
+    }
+    if (dtype != JENGA_BF16 && dtype != JENGA_FP16) {
+        set_error("jenga_rmsnorm_rows: dtype must be bf16 or fp16");
+        return JENGA_EUNSUPPORTED;
+    }
+    if (rows == 0) return JENGA_OK;
+    const int grid = grid_for(rows, 65536);
+#define LAUNCH_RR(T, W)                                                                                          \
+    hipLaunchKernelGGL((rmsnorm_rows_kernel<T, W>), dim3(grid), dim3(256), 0, (hipStream_t)stream,               \
+                       (const uint16_t*)x, out, weight, (long long)rows, (int)C, (long long)x_row_stride,        \
+                       (long long)o_row_stride, eps)
+    if (dtype == JENGA_BF16) { if (weight_fp32) LAUNCH_RR(BF16, true); else LAUNCH_RR(BF16, false); }
+    else { if (weight_fp32) LAUNCH_RR(FP16, true); else LAUNCH_RR(FP16, false); }
+#undef LAUNCH_RR
+    JENGA_CHECK_LAUNCH("jenga_rmsnorm_rows");
+    return JENGA_OK;
+}
+
+extern "C" int jenga_rope_complex(void* stream, const void* x, void* out, const double* cosT, const double* sinT,
+                                  int64_t B, int64_t S, int64_t H, int64_t x_sb, int64_t x_ss, int64_t x_sh,
+                                  int64_t o_sb, int64_t o_ss, int64_t o_sh, int64_t s_rope, int in_dtype,
+                                  int out_dtype) {
+    if (!x || !out || !cosT || !sinT || B < 0 || S < 0 || H < 0 || !strides_ok(x_sb, x_ss, x_sh) ||
+        !strides_ok(o_sb, o_ss, o_sh) || s_rope < 0 || s_rope > S) {
+        set_error("jenga_rope_complex: bad arguments");
+        return JENGA_EINVAL;
+    }
+    if ((in_dtype != 0 && in_dtype != 1 && in_dtype != 2) || (out_dtype != 0 && out_dtype != 2)) {
+        set_error("jenga_rope_complex: in_dtype in {bf16=0, fp16=1, fp32=2}, out_dtype in {bf16=0, fp32=2}");
+        return JENGA_EUNSUPPORTED;
+    }
+    const long long rows = (long long)B * S * H;
+    if (rows == 0) return JENGA_OK;
+    const int grid = grid_for((rows + 15) / 16, 32768);
+#define LAUNCH_RC(I, O)                                                                                           \
+    hipLaunchKernelGGL((rope_complex_kernel<I, O>), dim3(grid), dim3(256), 0, (hipStream_t)stream, x, out, cosT,  \
+                       sinT, (long long)B, (long long)S, (long long)H, (long long)x_sb, (long long)x_ss,          \
+                       (long long)x_sh, (long long)o_sb, (long long)o_ss, (long long)o_sh, (long long)s_rope)
+    if (out_dtype == 2) { if (in_dtype == 0) LAUNCH_RC(0, 2); else if (in_dtype == 1) LAUNCH_RC(1, 2); else LAUNCH_RC(2, 2); }
+    else { if (in_dtype == 0) LAUNCH_RC(0, 0); else if (in_dtype == 1) LAUNCH_RC(1, 0); else LAUNCH_RC(2, 0); }
+#undef LAUNCH_RC
+    JENGA_CHECK_LAUNCH("jenga_rope_complex");
+    return JENGA_OK;
+}

@@ -1,0 +1,109 @@
+"""Wan2.1 flavour of the AttenCarve caller, counterpart of wan/modules/model_mul.py:
+   rope_params :29-37, rope_apply :40-71, WanRMSNorm :74-90, WanSelfAttention :108-180.
+
+Numerics on the GPU: jenga_rmsnorm_rows (full-width RMSNorm), jenga_rope_complex (float64 complex rotation),
+jenga_amd.modules.attention_block_sparse.block_sparse_attention_wan (selection + block-sparse attention).
+The linear layers are plain torch (hipBLASLt)."""
+import math
+
+import torch
+import torch.nn as nn
+
+from .. import _capi
+from . import attention_block_sparse as _op
+
+
+def rope_params(max_seq_len, dim, theta=10000):
+    """complex128 [max_seq_len, dim/2] -- same torch calls as the reference (:29-37)."""
+    assert dim % 2 == 0
+    freqs = torch.outer(torch.arange(max_seq_len),
+                        1.0 / torch.pow(theta, torch.arange(0, dim, 2).to(torch.float64).div(dim)))
+    return torch.polar(torch.ones_like(freqs), freqs)
+
+
+def wan_freqs(head_dim=128):
+    """The model-level table (model_mul.py:502-507): three axis tables concatenated to [1024, head_dim/2]."""
+    d = head_dim
+    return torch.cat([rope_params(1024, d - 4 * (d // 6)), rope_params(1024, 2 * (d // 6)),
+                      rope_params(1024, 2 * (d // 6))], dim=1)
+
+
+def expand_freqs(freqs, grid, freq_remap=None):
+    """Per-token multipliers for an (f, h, w) grid, split [c-2(c//3), c//3, c//3] and broadcast exactly as rope_apply
+    does (:45-65) -> (cos, sin) float64 [f*h*w, c].  Static per resolution: build once, keep on the device."""
+    f, h, w = grid
+    c = freqs.shape[1]
+    parts = freqs.split([c - 2 * (c // 3), c // 3, c // 3], dim=1)
+    fi = torch.cat([parts[0][:f].view(f, 1, 1, -1).expand(f, h, w, -1),
+                    parts[1][:h].view(1, h, 1, -1).expand(f, h, w, -1),
+                    parts[2][:w].view(1, 1, w, -1).expand(f, h, w, -1)], dim=-1).reshape(f * h * w, c)
+    if freq_remap is not None:
+        fi = fi[freq_remap.to(fi.device)]
+    return fi.real.contiguous(), fi.imag.contiguous()
+
+
+def rope_apply(x, grid_sizes, freqs, freq_remap=None, out_dtype=torch.float32, _cache={}):
+    """x [B,S,N,128]; grid_sizes [B,3]; freqs complex128 [1024,64] -> float32 [B,S,N,128] (the reference returns
+    `.float()`); out_dtype=torch.bfloat16 fuses the cast the Wan attention op applies next."""
+    grids = grid_sizes.tolist() if torch.is_tensor(grid_sizes) else list(grid_sizes)
+    if len({tuple(g) for g in grids}) != 1:
+        raise ValueError("jenga_amd rope_apply: all samples of the batch must share one (f,h,w) grid")
+    f, h, w = grids[0]
+    key = (f, h, w, x.device, None if freq_remap is None else freq_remap.data_ptr(), freqs.data_ptr())
+    if key not in _cache:
+        cos, sin = expand_freqs(freqs, (f, h, w), freq_remap)
+        _cache.clear()
+        _cache[key] = (cos.to(x.device), sin.to(x.device))
+    cos, sin = _cache[key]
+    return _capi.rope_complex(x, cos, sin, f * h * w, out_dtype=out_dtype)
+
+
+class WanRMSNorm(nn.Module):
+    def __init__(self, dim, eps=1e-5):
+        super().__init__()
+        self.dim = dim
+        self.eps = eps
+        self.weight = nn.Parameter(torch.ones(dim))
+
+    def forward(self, x):
+        return _capi.rmsnorm_rows(x, self.weight, self.eps)
+
+
+class WanSelfAttention(nn.Module):
+    """Same constructor / forward signature as the reference (:108-180)."""
+
+    def __init__(self, dim, num_heads, window_size=(-1, -1), qk_norm=True, eps=1e-6, index=0, num_layers=0,
+                 dtype=None, device=None):
+        assert dim % num_heads == 0
+        super().__init__()
+        self.dim, self.num_heads, self.head_dim = dim, num_heads, dim // num_heads
+        self.window_size, self.qk_norm, self.eps = window_size, qk_norm, eps
+        self.index, self.num_layers = index, num_layers
+        fk = dict(dtype=dtype, device=device)
+        self.q, self.k, self.v, self.o = (nn.Linear(dim, dim, **fk) for _ in range(4))
+        self.norm_q = WanRMSNorm(dim, eps=eps).to(device) if qk_norm else nn.Identity()
+        self.norm_k = WanRMSNorm(dim, eps=eps).to(device) if qk_norm else nn.Identity()
+
+    @torch.no_grad()
+    def forward(self, x, seq_lens, grid_sizes, freqs, sa_drop_rate=0.0, per_block_tokens=128, p_remain_rates=0.8,
+                freq_remap=None, block_neighbor_list=None):
+        b, s, n, d = *x.shape[:2], self.num_heads, self.head_dim
+        q = self.norm_q(self.q(x)).view(b, s, n, d)
+        k = self.norm_k(self.k(x)).view(b, s, n, d)
+        v = self.v(x).view(b, s, n, d)
+        # rope_apply returns fp32 in the reference and the attention op immediately casts to bf16
+        # (attention_block_triton_diffres.py:456-463 / flash_attention's half()): fuse that cast into the kernel.
+        qr = rope_apply(q, grid_sizes, freqs, freq_remap, out_dtype=torch.bfloat16)
+        kr = rope_apply(k, grid_sizes, freqs, freq_remap, out_dtype=torch.bfloat16)
+        num_blocks = math.ceil(x.shape[1] / per_block_tokens)
+        if sa_drop_rate <= 0.25:
+            # dense: every block kept (flash_attention with k_lens = seq_lens masks keys >= seq_len, :153-159)
+            top_k, ffb = num_blocks, 0
+        else:
+            top_k = math.ceil(int(num_blocks * (1 - sa_drop_rate)))
+            ffb = math.ceil(num_blocks // 21)
+        out = _op.block_sparse_attention_wan(qr, kr, v.to(torch.bfloat16), top_k, text_blocks=0,
+                                             block_neighbor_list=block_neighbor_list if sa_drop_rate > 0.25 else None,
+                                             p_remain_rates=p_remain_rates if sa_drop_rate > 0.25 else 2.0,
+                                             first_frame_blocks=ffb)
+        return self.o(out.to(x.dtype).flatten(2))

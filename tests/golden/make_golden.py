@@ -221,17 +221,53 @@ def gen_norm_rope():
         json.dump(meta, f, indent=1, sort_keys=True)
 
 
+def gen_wan():
+    """wan/modules/model_mul.py: rope_params / rope_apply / WanRMSNorm (diffusers is absent -> stubbed for the import)."""
+    for name in ("diffusers", "diffusers.configuration_utils", "diffusers.models", "diffusers.models.modeling_utils"):
+        sys.modules.setdefault(name, types.ModuleType(name))
+    sys.modules["diffusers.configuration_utils"].ConfigMixin = object
+    sys.modules["diffusers.configuration_utils"].register_to_config = lambda f: f
+    sys.modules["diffusers.models.modeling_utils"].ModelMixin = torch.nn.Module
+    _install_flash_stub()
+    pkg = types.ModuleType("refwan"); pkg.__path__ = [os.path.join(REF, "wan", "modules")]
+    sys.modules["refwan"] = pkg
+    import importlib
+    mm = importlib.import_module("refwan.model_mul")
+    d = 128
+    freqs = torch.cat([mm.rope_params(1024, d - 4 * (d // 6)), mm.rope_params(1024, 2 * (d // 6)),
+                       mm.rope_params(1024, 2 * (d // 6))], dim=1)
+    gen = torch.Generator().manual_seed(77)
+    grid = (3, 4, 5)                       # 60 tokens, + 4 padding tokens that must pass through
+    x = (torch.randn(1, 64, 2, d, generator=gen) * 1.5).to(torch.bfloat16)
+    remap = torch.randperm(60, generator=gen)
+    out = {"freqs_re_head": freqs.real[:8].numpy(), "freqs_im_head": freqs.imag[:8].numpy(),
+           "x": x.view(torch.uint16).numpy(), "remap": remap.numpy(),
+           "rope": mm.rope_apply(x, torch.tensor([grid]), freqs).numpy(),
+           "rope_remap": mm.rope_apply(x, torch.tensor([grid]), freqs, remap).numpy()}
+    norm = mm.WanRMSNorm(1536, eps=1e-6)
+    with torch.no_grad():
+        norm.weight.copy_(1 + 0.1 * torch.randn(1536, generator=gen))
+        xn = (torch.randn(2, 10, 1536, generator=gen) * 2).to(torch.bfloat16)
+        out["norm_x"] = xn.view(torch.uint16).numpy()
+        out["norm_w"] = norm.weight.numpy()
+        out["norm_y"] = norm(xn).numpy()
+    np.savez_compressed(os.path.join(OUT, "wan_cases.npz"), **out)
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--big", action="store_true", help="also hash the full-size curves (about 1 min)")
     ap.add_argument("--only", default="")
     a = ap.parse_args()
     torch.set_grad_enabled(False)
-    gen_gilbert(a.big)
+    if a.only != "wan":
+        gen_gilbert(a.big)
     if a.only in ("", "select", "attn"):
         gen_select()
     if a.only in ("", "attn"):
         gen_attn()
     if a.only in ("", "rope"):
         gen_norm_rope()
+    if a.only in ("", "wan"):
+        gen_wan()
     print("golden fixtures written to", OUT)

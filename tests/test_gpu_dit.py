@@ -79,7 +79,9 @@ def test_single_stream_block_vs_oracle_composition(dev):
     cat = torch.cat((attn, F.gelu(lin1[..., 3 * C:], approximate="tanh")), 2)
     ref = x + blk.linear2(cat) * gate.unsqueeze(1)
     err = (out.float() - ref.float()).abs()
-    assert err.max().item() <= 0.06 and err.mean().item() <= 2e-3, (err.max().item(), err.mean().item())
+    # residual stream values reach |x| ~ 8 where one bf16 ulp is 0.0625: bound = 2 ulp of the value + 0.02
+    bound = 2 * torch.exp2(torch.floor(torch.log2(ref.float().abs().clamp_min(1e-3))) - 7) + 0.02
+    assert (err <= bound).all() and err.mean().item() <= 2e-3, (err.max().item(), err.mean().item())
 
 
 def test_double_stream_block_vs_oracle_composition(dev):
@@ -117,7 +119,8 @@ def test_double_stream_block_vs_oracle_composition(dev):
     r_txt = r_txt + blk.txt_mlp(dit.modulate(blk.txt_norm2(r_txt), tm[3], tm[4])) * tm[5].unsqueeze(1)
     for got, ref in ((o_img, r_img), (o_txt, r_txt)):
         err = (got.float() - ref.float()).abs()
-        assert err.max().item() <= 0.08 and err.mean().item() <= 3e-3, (err.max().item(), err.mean().item())
+        bound = 2 * torch.exp2(torch.floor(torch.log2(ref.float().abs().clamp_min(1e-3))) - 7) + 0.03
+        assert (err <= bound).all() and err.mean().item() <= 3e-3, (err.max().item(), err.mean().item())
 
 
 def test_forward_gather_scatter_and_skip_cache(dev):

@@ -282,3 +282,70 @@ def test_whole_op_flavours_vs_oracle(dev, flavour):
     bad_rows = (err.max(axis=-1) > 3e-2).mean()
     assert bad_rows <= 0.02, bad_rows
     assert np.median(err) <= 2e-3
+
+
+# ----------------------------------------------------------------------------------------------- Wan flavour
+def test_wan_preops_vs_reference_golden(golden_dir, dev):
+    from jenga_amd.modules import wan as W
+    g = np.load(os.path.join(golden_dir, "wan_cases.npz"))
+    freqs = W.wan_freqs()
+    assert np.array_equal(freqs.real[:8].numpy(), g["freqs_re_head"])
+    x = from_bits(g["x"], "bfloat16").to(dev)
+    grid = torch.tensor([[3, 4, 5]])
+    r = W.rope_apply(x, grid, freqs)
+    assert r.dtype == torch.float32 and np.array_equal(r.cpu().numpy(), g["rope"])           # fp64 math: bit-exact
+    r2 = W.rope_apply(x, grid, freqs, torch.from_numpy(g["remap"]))
+    assert np.array_equal(r2.cpu().numpy(), g["rope_remap"])
+    rb = W.rope_apply(x, grid, freqs, out_dtype=torch.bfloat16)                               # fused cast
+    assert torch.equal(rb.cpu(), torch.from_numpy(g["rope"]).to(torch.bfloat16))
+    norm = W.WanRMSNorm(1536, eps=1e-6).to(dev)
+    norm.weight.data.copy_(torch.from_numpy(g["norm_w"]))
+    y = norm(from_bits(g["norm_x"], "bfloat16").to(dev))
+    assert y.dtype == torch.float32
+    assert_ulp_close(y.cpu().numpy(), g["norm_y"], "bfloat16", max_ulps=2)
+
+
+@pytest.mark.parametrize("rate", [0.0, 0.7])
+def test_wan_self_attention_vs_oracle_composition(dev, rate):
+    """WanSelfAttention.forward: q/k/v linears (torch) -> WanRMSNorm -> fp64 RoPE -> dense (rate<=0.25) or AttenCarve."""
+    from jenga_amd.modules import wan as W
+    from oracle import attention as oa
+    from oracle import gilbert as og
+    from oracle import wan as ow
+    torch.manual_seed(0)
+    dim, heads, grid = 256, 2, (3, 16, 21)            # 1008 tokens -> padded to 8 blocks by the op
+    S = grid[0] * grid[1] * grid[2]
+    att = W.WanSelfAttention(dim, heads, dtype=torch.bfloat16, device=dev)
+    for lin in (att.q, att.k, att.v, att.o):
+        lin.weight.data.normal_(0, 0.08)
+    x = torch.randn(1, S, dim, device=dev).to(torch.bfloat16)
+    nbm = og.sliced_gilbert_block_neighbor_mapping(*grid, 128)
+    l2h, h2l = og.sliced_gilbert_mapping(*grid)
+    remap = torch.from_numpy(h2l)
+    freqs = W.wan_freqs()
+    out = att(x, torch.tensor([S]), torch.tensor([list(grid)]), freqs, sa_drop_rate=rate, p_remain_rates=0.8,
+              freq_remap=remap, block_neighbor_list=torch.from_numpy(nbm))
+    # oracle composition on the same linear outputs
+    with torch.no_grad():
+        q, k, v = att.q(x), att.k(x), att.v(x)
+    wq, wk = att.norm_q.weight.detach().cpu().numpy(), att.norm_k.weight.detach().cpu().numpy()
+    rnd = lambda a: torch.from_numpy(a).to(torch.bfloat16).float().numpy()
+    qn = ow.wan_rmsnorm(to_np(q), wq, "bfloat16", 1e-6).reshape(1, S, heads, 128)
+    kn = ow.wan_rmsnorm(to_np(k), wk, "bfloat16", 1e-6).reshape(1, S, heads, 128)
+    fr = ow.wan_freqs()
+    qr, kr = rnd(ow.rope_apply(qn, grid, fr, h2l)), rnd(ow.rope_apply(kn, grid, fr, h2l))
+    vv = to_np(v).reshape(1, S, heads, 128)
+    nb = 8
+    if rate <= 0.25:
+        ref = oa.block_sparse_attention(qr, kr, vv, nb, "bfloat16", text_blocks=0, block_neighbor_list=None,
+                                        p_remain_rates=2.0, flavour="wan")
+    else:
+        import math
+        ref = oa.block_sparse_attention(qr, kr, vv, math.ceil(int(nb * (1 - rate))), "bfloat16", text_blocks=0,
+                                        block_neighbor_list=nbm, p_remain_rates=0.8, flavour="wan",
+                                        first_frame_blocks=math.ceil(nb // 21))
+    with torch.no_grad():
+        want = att.o(torch.from_numpy(ref).to(torch.bfloat16).to(dev))
+    err = (out.float() - want.float()).abs()
+    assert err.mean().item() <= 3e-3 and (err.max(-1).values > 0.08).float().mean().item() <= 0.02, \
+        (err.max().item(), err.mean().item())

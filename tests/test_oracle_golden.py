@@ -134,3 +134,16 @@ def test_rope_table_full_size(golden_dir):
     assert cos.shape == (115200, 128)
     ref_row = np.array(meta["rope_32_45_80_cos_row12345"], np.float32)
     assert np.abs(cos[12345, ::16] - ref_row).max() <= 2e-6
+
+
+def test_wan_preops_bit_exact(golden_dir):
+    """wan/modules/model_mul.py rope_params / rope_apply (with and without freq_remap) / WanRMSNorm."""
+    from oracle import wan as ow
+    g = np.load(os.path.join(golden_dir, "wan_cases.npz"))
+    fr = ow.wan_freqs()
+    assert np.array_equal(fr.real[:8], g["freqs_re_head"]) and np.array_equal(fr.imag[:8], g["freqs_im_head"])
+    x = to_np(from_bits(g["x"], "bfloat16"))
+    assert np.array_equal(ow.rope_apply(x, (3, 4, 5), fr), g["rope"])
+    assert np.array_equal(ow.rope_apply(x, (3, 4, 5), fr, g["remap"]), g["rope_remap"])
+    y = ow.wan_rmsnorm(to_np(from_bits(g["norm_x"], "bfloat16")), g["norm_w"], "bfloat16", 1e-6)
+    assert_ulp_close(y, g["norm_y"], "bfloat16", max_ulps=2)
