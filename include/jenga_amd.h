@@ -137,6 +137,7 @@ int jenga_bsattn_fwd(void* stream, const void* q, const void* k, const void* vt,
                      float text_amp, int64_t text_block_start, int dtype, int flags);
 /* flags */
 #define JENGA_ATTN_XCD_REMAP 1 /* contiguous q-block ranges per XCD (L2 locality); 0 = plain head-major order */
+#define JENGA_ATTN_PINGPONG 2  /* 8-wave workgroups, MFMA / softmax phases of the two waves per SIMD in anti-phase */
 
 /* ---------------------------------------------------------------------------------------------------
  * Ulysses head pack/unpack: the local halves of xFuserLongContextAttention.forward's SeqAllToAll4D calls

@@ -7,10 +7,12 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libjenga_amd.so")
+LIB_PATH = os.environ.get("JENGA_LIB", os.path.join(_HERE, "libjenga_amd.so"))
 
 JENGA_BF16, JENGA_FP16 = 0, 1
 ATTN_XCD_REMAP = 1
+ATTN_PINGPONG = 2
+ATTN_DEFAULT_FLAGS = int(os.environ.get("JENGA_ATTN_FLAGS", str(ATTN_XCD_REMAP)))
 
 _vp, _i64, _i32, _f32 = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_float
 
@@ -271,7 +273,8 @@ def pack_v(v, n_blocks=None, out=None, dst_block0=0, dst_blocks_total=None):
     return out
 
 
-def bsattn_fwd(q, k, vt, seqlens, idx, cnt, nq_img, sm_scale, text_amp, text_block_start, out=None, xcd_remap=True):
+def bsattn_fwd(q, k, vt, seqlens, idx, cnt, nq_img, sm_scale, text_amp, text_block_start, out=None, xcd_remap=True,
+               flags=None):
     """q,k [B,S,H,128]; vt from pack_v; seqlens int32 [B] device; idx/cnt from block_select -> o [B,S,H,128]."""
     _need_gpu(q, "bsattn_fwd")
     B, S, H, D = q.shape
@@ -292,7 +295,9 @@ def bsattn_fwd(q, k, vt, seqlens, idx, cnt, nq_img, sm_scale, text_amp, text_blo
         _check(lib().jenga_bsattn_fwd(_stream(q.device), _p(q), _p(k), _p(vt), _p(out), _p(seqlens), _p(idx), _p(cnt),
                                       B, H, n_blocks, nq_img, *_bshd_strides(q), *_bshd_strides(k),
                                       *_bshd_strides(out), float(sm_scale), float(text_amp), int(text_block_start),
-                                      dtype_code(q.dtype), ATTN_XCD_REMAP if xcd_remap else 0), "jenga_bsattn_fwd")
+                                      dtype_code(q.dtype),
+                                      (ATTN_DEFAULT_FLAGS if flags is None else flags) & ~(0 if xcd_remap else ATTN_XCD_REMAP)),
+               "jenga_bsattn_fwd")
         if prof is not None:
             e1.record()
             prof.events.append((e0, e1))

@@ -46,7 +46,7 @@ def build(force=False, verbose=False):
     for src, extra in SOURCES:
         obj = os.path.join(objdir, src.rsplit(".", 1)[0] + ".o")
         cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-x", "hip", "-c",
-               os.path.join(CSRC, src), "-o", obj] + extra
+               os.path.join(CSRC, src), "-o", obj] + extra + os.environ.get("JENGA_HIPCC_FLAGS", "").split()
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))

@@ -38,6 +38,9 @@ def main():
     ap.add_argument("--no-xcd", action="store_true")
     ap.add_argument("--same-list", action="store_true", help="every query block keeps the SAME blocks (perfect L2 reuse)")
     ap.add_argument("--attn-only", action="store_true")
+    ap.add_argument("--l2-resident", type=int, default=0,
+                    help="N>0: every query block reads the same N kv blocks repeatedly (same pair count): isolates MFMA/LDS work from L2-miss fill traffic")
+    ap.add_argument("--flags", type=int, default=None, help="jenga_bsattn_fwd flags (1 = XCD remap, 2 = ping-pong)")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     t, h, w = a.grid
@@ -74,13 +77,17 @@ def main():
         idx = torch.arange(nb, device=dev, dtype=torch.int32).expand(1, H, nimg, nb).contiguous()
         idx[..., n - tb:n] = torch.arange(nimg, nb, device=dev, dtype=torch.int32)
         cnt = torch.full_like(cnt, n)
+    if a.l2_resident:
+        n = int(cnt.float().mean().item())
+        idx = (torch.arange(nb, device=dev, dtype=torch.int32) % a.l2_resident).expand(1, H, nimg, nb).contiguous()
+        cnt = torch.full_like(cnt, n)
     kept = int(cnt.sum().item())
     pairs = kept + H * tb * nb
     flops = 4 * 128 ** 3 * pairs
     res["kept_mean"] = kept / (H * nimg)
     res["kept_min_max"] = [int(cnt.min()), int(cnt.max())]
     ms, o = timed(lambda: _capi.bsattn_fwd(q, k, vt, seqlens, idx, cnt, nimg, 128 ** -0.5, 0.0, nimg,
-                                           xcd_remap=not a.no_xcd), a.iters)
+                                           xcd_remap=not a.no_xcd, flags=a.flags), a.iters)
     res["attn_ms"] = ms
     res["attn_TFLOPs"] = flops / (ms * 1e-3) / 1e12
     res["attn_frac_of_2.5PF"] = res["attn_TFLOPs"] / 2500
