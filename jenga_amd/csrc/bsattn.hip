@@ -103,6 +103,7 @@ __device__ __forceinline__ void stage_tile(const void* kbase, const void* vbase,
 // -m~ in the MFMA C operand instead was tried: hipcc then copies the 32 C registers every tile, which costs more).  P <= 2^LAZY_THR keeps the storage dtype's relative
 // precision (power-of-two scaling commutes with rounding), so results match the eager max up to fp32 rounding.
 constexpr float LAZY_THR = 8.0f;
+constexpr float RAISE_SUM = 256.0f;   // 2^LAZY_THR
 #ifndef JENGA_SETPRIO
 #define JENGA_SETPRIO 1
 #endif
@@ -196,69 +197,108 @@ __device__ __forceinline__ void attn_block(const AttnParams& P, unsigned char* s
         const int key0 = blk * 128 + (HALF) * KT;                                                                \
         if (!(SLOW) || key0 < seqlen) { /* a tile entirely past seqlen contributes exp2(-inf) = 0 */             \
             f32x16 s0, s1;                                                                                       \
+            float psum;                                                                                          \
+            const bool pre = first; /* wave-uniform: update m~ from the row max BEFORE exponentiating */         \
             {                                                                                                    \
-                uint4 ka[8], kb[8];                                                                              \
-                MFMA_PRIO(1);                                                                                    \
-                _Pragma("unroll") for (int ds = 0; ds < 8; ++ds) {                                               \
-                    ka[ds] = *reinterpret_cast<const uint4*>(cur + k_addr[ds]);                                  \
-                    kb[ds] = *reinterpret_cast<const uint4*>(cur + k_addr[ds] + 8192);                           \
+                {                                                                                                \
+                    uint4 ka[8], kb[8];                                                                          \
+                    MFMA_PRIO(1);                                                                                \
+                    _Pragma("unroll") for (int ds = 0; ds < 8; ++ds) {                                           \
+                        ka[ds] = *reinterpret_cast<const uint4*>(cur + k_addr[ds]);                              \
+                        kb[ds] = *reinterpret_cast<const uint4*>(cur + k_addr[ds] + 8192);                       \
+                    }                                                                                            \
+                    s0 = mfma32<T>(ka[0], qf[0], zero16);                                                        \
+                    s1 = mfma32<T>(kb[0], qf[0], zero16);                                                        \
+                    _Pragma("unroll") for (int ds = 1; ds < 8; ++ds) {                                           \
+                        s0 = mfma32<T>(ka[ds], qf[ds], s0);                                                      \
+                        s1 = mfma32<T>(kb[ds], qf[ds], s1);                                                      \
+                    }                                                                                            \
+                    /* issue order: LDS reads run 3 k-steps (6 reads) ahead of the MFMAs that consume them */    \
+                    __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);                                           \
+                    _Pragma("unroll") for (int g_ = 0; g_ < 5; ++g_) {                                           \
+                        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                                       \
+                        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);                                       \
+                    }                                                                                            \
+                    __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);                                           \
+                    MFMA_PRIO(0);                                                                                \
                 }                                                                                                \
-                s0 = mfma32<T>(ka[0], qf[0], zero16);                                                            \
-                s1 = mfma32<T>(kb[0], qf[0], zero16);                                                            \
-                _Pragma("unroll") for (int ds = 1; ds < 8; ++ds) {                                               \
-                    s0 = mfma32<T>(ka[ds], qf[ds], s0);                                                          \
-                    s1 = mfma32<T>(kb[ds], qf[ds], s1);                                                          \
-                }                                                                                                \
-                /* issue order: LDS reads run 2 k-steps (4 reads) ahead of the MFMAs that consume them */        \
-                __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);                                               \
-                _Pragma("unroll") for (int g_ = 0; g_ < 5; ++g_) {                                               \
-                    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                                           \
-                    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);                                           \
-                }                                                                                                \
-                __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);                                               \
-                MFMA_PRIO(0);                                                                                    \
-            }                                                                                                    \
-            if (TEXT) {                                                                                          \
-                _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                                 \
-                    s0[r] *= P.qk_scale;                                                                         \
-                    s1[r] *= P.qk_scale;                                                                         \
-                }                                                                                                \
-            } else if (SLOW) {                                                                                   \
-                if (blk >= P.text_block_start) {                                                                 \
+                if (TEXT) {                                                                                      \
                     _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                             \
-                        s0[r] += P.text_amp;                                                                     \
-                        s1[r] += P.text_amp;                                                                     \
+                        s0[r] *= P.qk_scale;                                                                     \
+                        s1[r] *= P.qk_scale;                                                                     \
+                    }                                                                                            \
+                } else if (SLOW) {                                                                               \
+                    if (blk >= P.text_block_start) {                                                             \
+                        _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                         \
+                            s0[r] += P.text_amp;                                                                 \
+                            s1[r] += P.text_amp;                                                                 \
+                        }                                                                                        \
+                    }                                                                                            \
+                    if (key0 + KT > seqlen) {                                                                    \
+                        _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                         \
+                            const int kk = key0 + (r & 3) + 8 * (r >> 2) + 4 * hi;                               \
+                            if (kk >= seqlen) s0[r] = -INFINITY;                                                 \
+                            if (kk + 32 >= seqlen) s1[r] = -INFINITY;                                            \
+                        }                                                                                        \
                     }                                                                                            \
                 }                                                                                                \
-                if (key0 + KT > seqlen) {                                                                        \
+                if (pre) { /* first tile of the row block, or the careful re-run after an exp2 overflow */       \
+                    float tmax = fmaxf(s0[0], s1[0]);                                                            \
+                    _Pragma("unroll") for (int r = 1; r < 16; ++r) tmax = fmaxf(tmax, fmaxf(s0[r], s1[r]));      \
+                    tmax += neg_m;                                                                               \
+                    tmax = fmaxf(tmax, __shfl_xor(tmax, 32));                                                    \
+                    const bool go_ = first ? (tmax > -1e20f) : (tmax > LAZY_THR);                                \
+                    const float delta = go_ ? ceilf(tmax) : 0.f;                                                 \
+                    const float f2 = __builtin_amdgcn_exp2f(-delta);                                             \
+                    neg_m -= delta;                                                                              \
+                    l_i *= f2;                                                                                   \
+                    _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                \
+                        _Pragma("unroll") for (int r = 0; r < 16; ++r) oacc[i][r] *= f2;                         \
+                    first = false;                                                                               \
+                }                                                                                                \
+                /* hot path: P = exp2(S - m~) and its row sum with packed adds, no row max.  P goes to its own   \
+                   registers so that the raw scores survive until the check below. */                            \
+                f32x16 p0, p1;                                                                                   \
+                {                                                                                                \
+                    const f32x2 nm2 = {neg_m, neg_m};                                                            \
+                    f32x2 ps2 = {0.f, 0.f};                                                                      \
+                    _Pragma("unroll") for (int r = 0; r < 16; r += 2) {                                          \
+                        f32x2 a0 = {s0[r], s0[r + 1]}, a1 = {s1[r], s1[r + 1]};                                  \
+                        a0 += nm2;                                                                               \
+                        a1 += nm2;                                                                               \
+                        a0.x = __builtin_amdgcn_exp2f(a0.x);                                                     \
+                        a0.y = __builtin_amdgcn_exp2f(a0.y);                                                     \
+                        a1.x = __builtin_amdgcn_exp2f(a1.x);                                                     \
+                        a1.y = __builtin_amdgcn_exp2f(a1.y);                                                     \
+                        p0[r] = a0.x; p0[r + 1] = a0.y; p1[r] = a1.x; p1[r + 1] = a1.y;                          \
+                        ps2 += a0;                                                                               \
+                        ps2 += a1;                                                                               \
+                    }                                                                                            \
+                    psum = ps2.x + ps2.y;                                                                        \
+                }                                                                                                \
+                /* rare: any P > 2^THR implies a row sum > 2^THR (and an overflowed exp2 gives inf): raise m~ by  \
+                   an integer step from the row max of the intact scores, then exponentiate again.  Exact; the   \
+                   row max is only ever computed in here and on the first tile. */                               \
+                if (!pre && __any(!(psum <= RAISE_SUM))) {                                                       \
+                    float tmax = fmaxf(s0[0], s1[0]);                                                            \
+                    _Pragma("unroll") for (int r = 1; r < 16; ++r) tmax = fmaxf(tmax, fmaxf(s0[r], s1[r]));      \
+                    tmax += neg_m;                                                                               \
+                    tmax = fmaxf(tmax, __shfl_xor(tmax, 32));                                                    \
+                    const float delta = (tmax > LAZY_THR) ? ceilf(tmax) : 0.f;                                   \
+                    const float f2 = __builtin_amdgcn_exp2f(-delta);                                             \
+                    neg_m -= delta;                                                                              \
+                    l_i *= f2;                                                                                   \
+                    _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                \
+                        _Pragma("unroll") for (int r = 0; r < 16; ++r) oacc[i][r] *= f2;                         \
+                    psum = 0.f;                                                                                  \
                     _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                             \
-                        const int kk = key0 + (r & 3) + 8 * (r >> 2) + 4 * hi;                                   \
-                        if (kk >= seqlen) s0[r] = -INFINITY;                                                     \
-                        if (kk + 32 >= seqlen) s1[r] = -INFINITY;                                                \
+                        p0[r] = __builtin_amdgcn_exp2f(s0[r] + neg_m);                                           \
+                        p1[r] = __builtin_amdgcn_exp2f(s1[r] + neg_m);                                           \
+                        psum += p0[r] + p1[r];                                                                   \
                     }                                                                                            \
                 }                                                                                                \
-            }                                                                                                    \
-            /* local max of this lane's 32 scores relative to the lazy reference m~.  The common path needs no      \
-               cross-half exchange: a wave-wide ballot decides whether ANY row must raise m~; only the (rare) raise  \
-               path pays the ds_bpermute so that both half-waves of a row apply the same integer step. */           \
-            float tmax = fmaxf(s0[0], s1[0]);                                                                    \
-            _Pragma("unroll") for (int r = 1; r < 16; ++r) tmax = fmaxf(tmax, fmaxf(s0[r], s1[r]));              \
-            tmax += neg_m;                                                                                       \
-            if (first || __any(tmax > LAZY_THR)) { /* raise m~ (rare): exact power-of-two rescale */             \
-                tmax = fmaxf(tmax, __shfl_xor(tmax, 32));                                                        \
-                const float delta = (first || tmax > LAZY_THR) ? ceilf(tmax) : 0.f;                              \
-                const float f2 = __builtin_amdgcn_exp2f(-delta);                                                 \
-                neg_m -= delta;                                                                                  \
-                l_i *= f2;                                                                                       \
-                _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                    \
-                    _Pragma("unroll") for (int r = 0; r < 16; ++r) oacc[i][r] *= f2;                             \
-                first = false;                                                                                   \
-            }                                                                                                    \
-            float psum = 0.f;                                                                                    \
-            _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                                     \
-                s0[r] = __builtin_amdgcn_exp2f(s0[r] + neg_m);                                                   \
-                s1[r] = __builtin_amdgcn_exp2f(s1[r] + neg_m);                                                   \
-                psum += s0[r] + s1[r];                                                                           \
+                s0 = p0;                                                                                         \
+                s1 = p1;                                                                                         \
             }                                                                                                    \
             l_i += psum;                                                                                         \
             /* P -> 16-bit operands: k-step ks = 2g + s uses C registers 8s..8s+7 of group g */                  \

@@ -349,3 +349,32 @@ def test_wan_self_attention_vs_oracle_composition(dev, rate):
     err = (out.float() - want.float()).abs()
     assert err.mean().item() <= 3e-3 and (err.max(-1).values > 0.08).float().mean().item() <= 0.02, \
         (err.max().item(), err.mean().item())
+
+
+@pytest.mark.parametrize("dt", ["bfloat16", "float16"])
+def test_sparse_kernel_running_max_jumps(dev, dt):
+    """Forces the rare branches of the lazy running max: keys whose score exceeds everything seen before by ~30,
+    ~100 and > 127 log2 units (the last one overflows exp2 against the stale reference), placed in late tiles and in
+    both 64-key halves.  Bounded random data never takes these branches, so this test is the only thing guarding them."""
+    from oracle import attention as oa
+    gen = torch.Generator().manual_seed(23)
+    H, nb_img, tb = 2, 8, 1
+    S = (nb_img + tb) * 128
+    tdt = getattr(torch, dt)
+    q = torch.randn(1, H, nb_img * 128, 128, generator=gen)
+    k = torch.randn(1, H, S, 128, generator=gen)
+    v = torch.randn(1, H, S, 128, generator=gen)
+    # (query row, key row, gain): key = gain * query  ->  score ~ gain * 128 * 0.1275 log2 units
+    for (qr, kr, gain) in [(5, 3 * 128 + 7, 1.8), (200, 5 * 128 + 100, 6.0), (201, 6 * 128 + 2, 9.5),
+                           (640, 7 * 128 + 70, 9.0), (641, 2 * 128 + 33, 2.5)]:
+        k[0, :, kr] = gain * q[0, :, qr]
+    q, k, v = q.to(tdt), k.to(tdt), v.to(tdt)
+    mask = torch.ones(1, H, nb_img, nb_img + tb, dtype=torch.bool)
+    seqlen = nb_img * 128 + 50
+    o = _run_kernel(q, k, v, mask, seqlen, 0.0, nb_img, dev)
+    ref = oa.sparse_rows(to_np(q), to_np(k), to_np(v), [seqlen], mask.numpy(), 128 ** -0.5, dt, 0.0, nb_img)
+    assert np.isfinite(o).all()
+    tol = 3e-2 if dt == "bfloat16" else 6e-3
+    assert np.abs(o - ref).max() <= tol, np.abs(o - ref).max()
+    for qr in (5, 200, 201, 640, 641):            # the spiked rows themselves: softmax collapses onto one key
+        assert np.abs(o[0, :, qr] - ref[0, :, qr]).max() <= tol
