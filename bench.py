@@ -133,7 +133,7 @@ def main():
                      freqs_sin=sin, guidance=guidance, return_dict=False)
 
     if a.steps >= 50:
-        plan = list(range(50))
+        plan = [i % 50 for i in range(a.steps)]      # whole loop(s); sec/video = elapsed * 50 / steps
         sampled = False
     else:
         pattern = [0, 5, 7, 26, 27, 29]        # computed@r0, skipped, computed@r0, computed@r1, skipped, computed@r1
@@ -183,7 +183,7 @@ def main():
             scale = 1.0
         sec_per_video = sum(n * t for n, t in parts if n and t == t) * scale / 1e3
     else:
-        sec_per_video = elapsed
+        sec_per_video = elapsed * 50.0 / len(plan)
     ps = prof.summary()
     traffic = None
     try:   # HBM-side bytes per launch from the committed PMC passes (profiles/), scaled by this run's kept pairs

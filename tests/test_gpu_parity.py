@@ -378,3 +378,27 @@ def test_sparse_kernel_running_max_jumps(dev, dt):
     assert np.abs(o - ref).max() <= tol, np.abs(o - ref).max()
     for qr in (5, 200, 201, 640, 641):            # the spiked rows themselves: softmax collapses onto one key
         assert np.abs(o[0, :, qr] - ref[0, :, qr]).max() <= tol
+
+
+def test_dense_path_vs_oracle(dev):
+    """sa_drop_rate == 0 (attenion.py:108-121, flash_attn_varlen over the valid | padding segments): valid rows must
+    match softmax over the valid keys; padding rows are returned as zeros (documented deviation)."""
+    from jenga_amd.modules.attention import attention, get_cu_seqlens
+    from oracle import attention as oa
+    gen = torch.Generator().manual_seed(31)
+    H, S_img, S_txt, valid = 2, 512, 256, 90
+    S = S_img + S_txt
+    q = torch.randn(1, S, H, 128, generator=gen).to(torch.bfloat16)
+    k = torch.randn(1, S, H, 128, generator=gen).to(torch.bfloat16)
+    v = torch.randn(1, S, H, 128, generator=gen).to(torch.bfloat16)
+    mask = torch.zeros(1, S_txt, dtype=torch.int64)
+    mask[:, :valid] = 1
+    cu = get_cu_seqlens(mask.to(dev), S_img)
+    assert cu.tolist() == [0, S_img + valid, S]
+    o = attention(q.to(dev), k.to(dev), v.to(dev), cu_seqlens_q=cu, cu_seqlens_kv=cu).float().cpu().numpy()
+    tr = lambda t: np.transpose(to_np(t), (0, 2, 1, 3))
+    ref = oa.dense_varlen(tr(q), tr(k), tr(v), [0, S_img + valid, S], 128 ** -0.5, "bfloat16")
+    ref = np.transpose(ref, (0, 2, 1, 3)).reshape(1, S, H * 128)
+    n = S_img + valid
+    assert np.abs(o[:, :n] - ref[:, :n]).max() <= 2e-2
+    assert np.all(o[:, n:] == 0)
