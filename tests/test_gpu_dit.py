@@ -168,3 +168,28 @@ def test_sequence_parallel_path_world1_rccl(dev):
         assert torch.equal(got, ref)
     finally:
         dist.destroy_process_group()
+
+
+def test_wan_teacache_forward_gather_scatter_and_cache(dev):
+    """Wan driver skeleton: pad -> sliced-Hilbert gather -> blocks / cached residual -> scatter."""
+    from jenga_amd import gilbert as G
+    from jenga_amd.wan_driver import TeaCache, teacache_forward
+    grid = (3, 6, 8)
+    L = grid[0] * grid[1] * grid[2]
+    seq_len = 160                                             # padded like the reference's seq_len argument
+    l2h, h2l = G.sliced_gilbert_mapping(*grid, as_tensor=True)
+    pad = torch.arange(L, seq_len, device=dev)
+    order = torch.cat([h2l, pad])                             # padding tokens stay at the tail
+    inv = torch.cat([l2h, pad])
+    x = torch.randn(1, L, 64, device=dev).to(torch.bfloat16)
+    e = torch.randn(1, 32, device=dev)
+    tea = TeaCache(num_steps=4, thresh=1e9)                   # everything after the retained steps is skipped
+    add_one = lambda t, **kw: t + 1
+    outs = []
+    for _ in range(6):
+        y, calc = teacache_forward(x, e, e.unsqueeze(1), [add_one, add_one], tea, order, inv, seq_len=seq_len)
+        outs.append((y, calc))
+    want = torch.cat([x, x.new_zeros(1, seq_len - L, 64)], 1) + 2
+    assert [c for _, c in outs] == [True, True, False, False, False, False]
+    for y, _ in outs:
+        assert y.shape == (1, seq_len, 64) and torch.equal(y, want)

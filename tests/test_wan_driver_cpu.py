@@ -1,0 +1,71 @@
+"""CPU: host logic of the Wan driver (drop-rate warm-up, TeaCache decision) against hand-derived sequences that follow
+jenga_wan.py:190-206 and :595-626 line by line."""
+import numpy as np
+import torch
+
+from jenga_amd.wan_driver import TEACACHE_COEFFS, TeaCache, sa_drop_rate_for_step
+
+
+def test_drop_rate_schedule():
+    rates = [0.7, 0.8]
+    n = 50
+    got = [sa_drop_rate_for_step(i, n, rates) for i in range(n)]
+    assert got[0] == 0.0                                   # warm-up starts dense
+    assert abs(got[1] - (1 / 49 * 10) * 0.7) < 1e-12
+    assert got[5] == 0.7 and got[25] == 0.7                # 5/49*10 > 1 -> capped at the rate
+    assert got[26] == 0.8 and got[49] == 0.8
+    assert sa_drop_rate_for_step(30, n, [0.6]) == 0.6
+
+
+def _ref_decisions(embs, num_steps, thresh, coeffs, ret_steps, cutoff):
+    """Independent restatement of the even/odd accumulators."""
+    acc = {0: 0.0, 1: 0.0}
+    prev = {}
+    out = []
+    for cnt, e in enumerate(embs):
+        p = cnt % 2
+        if cnt < ret_steps or cnt >= cutoff:
+            calc = True
+            acc[p] = 0.0
+        else:
+            rel = float((e - prev[p]).abs().mean() / prev[p].abs().mean())
+            acc[p] += float(np.poly1d(coeffs)(rel))
+            calc = not (acc[p] < thresh)
+            if calc:
+                acc[p] = 0.0
+        prev[p] = e
+        out.append(calc)
+    return out
+
+
+def test_teacache_decisions_follow_the_reference_rule():
+    torch.manual_seed(0)
+    steps = 12
+    base = torch.randn(1, 64)
+    embs = [base * (1 + 0.02 * (i // 2)) + 0.001 * torch.randn(1, 64) for i in range(2 * steps)]
+    tea = TeaCache(steps, thresh=0.08, task="t2v-1.3B", use_ret_steps=False)
+    got = []
+    for e in embs:
+        calc, parity = tea.decide(e, e.unsqueeze(1).repeat(1, 6, 1))
+        assert parity == tea.cnt % 2
+        got.append(calc)
+        tea.advance()
+    ref = _ref_decisions(embs, steps, 0.08, TEACACHE_COEFFS[("t2v-1.3B", False)], 2, 2 * steps - 2)
+    assert got == ref
+    assert got[0] and got[1] and got[-1] and got[-2]          # first step and last step are always computed
+    assert not all(got)                                       # something was actually skipped
+    assert tea.cnt == 0                                       # wrapped around after num_steps*2 calls
+
+
+def test_teacache_stage_start_forces_compute():
+    tea = TeaCache(10, thresh=10.0)
+    e = torch.ones(1, 8)
+    for _ in range(4):
+        tea.decide(e, e.unsqueeze(1))
+        tea.advance()
+    calc, _ = tea.decide(e, e.unsqueeze(1))
+    assert not calc                                           # huge threshold: skipped
+    tea.advance()
+    tea.stage_start = True
+    calc, _ = tea.decide(e, e.unsqueeze(1))
+    assert calc
