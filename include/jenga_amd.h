@@ -83,6 +83,23 @@ int jenga_rope_complex(void* stream, const void* x, void* out, const double* cos
                        int64_t S, int64_t H, int64_t x_sb, int64_t x_ss, int64_t x_sh, int64_t o_sb, int64_t o_ss,
                        int64_t o_sh, int64_t s_rope, int in_dtype, int out_dtype);
 
+/* DiT block glue around the GEMMs: fused replacements of eager elementwise chains.
+ * jenga_ln_modulate: modulate(LayerNorm(x), shift, scale) = LN(x)*(1+scale)+shift
+ *   (models_mul_block_gc_ha_multigpu.py:196-199, 404; modulate_layers.py:31-50), LayerNorm without affine.
+ *   mask != NULL selects (shift2, scale2) for rows with mask[row] != 0: the I2V "token_replace" modulation of the
+ *   first-frame tokens (hyvideo_i2v/modules/modulate_layers.py:51-56).  shift/scale: [C] in dtype.
+ * jenga_gate_residual: res + apply_gate(y, gate) (models_mul...:297-315, 500; modulate_layers.py:53-68), gate2/mask as
+ *   above (hyvideo_i2v/modules/modulate_layers.py:84-95).
+ * jenga_gelu_tanh: tanh-approximated GELU (mlp_act "gelu_tanh") between strided buffers. */
+int jenga_ln_modulate(void* stream, const void* x, void* y, const void* shift, const void* scale, const void* shift2,
+                      const void* scale2, const uint8_t* mask, int64_t rows, int64_t C, int64_t x_row_stride,
+                      int64_t y_row_stride, float eps, int dtype);
+int jenga_gate_residual(void* stream, const void* res, const void* y, const void* gate, const void* gate2,
+                        const uint8_t* mask, void* out, int64_t rows, int64_t C, int64_t res_row_stride,
+                        int64_t y_row_stride, int64_t o_row_stride, int dtype);
+int jenga_gelu_tanh(void* stream, const void* x, void* out, int64_t rows, int64_t C, int64_t x_row_stride,
+                    int64_t o_row_stride, int dtype);
+
 /* ---------------------------------------------------------------------------------------------------
  * Block selection.  Replaces _build_block_index_with_importance_optimized
  * (hyvideo/modules/attention_block_triton_diffres.py:198-295; Wan first_frame_blocks rule

@@ -26,6 +26,9 @@ SIGNATURES = {
     "jenga_rmsnorm_rope": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp] + [_i64] * 10 + [_f32, _i32]),
     "jenga_rmsnorm_rows": (_i32, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _f32, _i32, _i32]),
     "jenga_rope_complex": (_i32, [_vp, _vp, _vp, _vp, _vp] + [_i64] * 10 + [_i32, _i32]),
+    "jenga_ln_modulate": (_i32, [_vp] * 8 + [_i64] * 4 + [_f32, _i32]),
+    "jenga_gate_residual": (_i32, [_vp] * 7 + [_i64] * 5 + [_i32]),
+    "jenga_gelu_tanh": (_i32, [_vp, _vp, _vp] + [_i64] * 4 + [_i32]),
     "jenga_block_pool": (_i32, [_vp, _vp, _vp] + [_i64] * 6 + [_i32]),
     "jenga_block_select": (_i32, [_vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp] + [_i64] * 6 + [_f32, _i64, _i32]),
     "jenga_pack_v_bytes": (ctypes.c_size_t, [_i64, _i64, _i64]),
@@ -212,6 +215,63 @@ def rope_complex(x, cos64, sin64, s_rope, out_dtype=torch.float32):
         _check(lib().jenga_rope_complex(_stream(x.device), _p(x), _p(out), _p(cos64.contiguous()),
                                         _p(sin64.contiguous()), B, S, H, *_bshd_strides(x), *_bshd_strides(out),
                                         int(s_rope), codes[x.dtype], codes[out_dtype]), "jenga_rope_complex")
+    return out
+
+
+def _rows2d(t):
+    """[..., C] with unit inner stride and a single uniform row stride -> (rows, C, row_stride)."""
+    C = t.shape[-1]
+    t2 = t.reshape(-1, C) if t.is_contiguous() else t
+    if t2.dim() == 3 and t2.shape[0] == 1:
+        t2 = t2[0]
+    if t2.dim() != 2 or t2.stride(1) != 1:
+        raise ValueError("expected a [rows, C] (or [1, rows, C]) tensor with contiguous channels")
+    return t2, t2.shape[0], C, t2.stride(0)
+
+
+def ln_modulate(x, shift, scale, eps=1e-6, shift2=None, scale2=None, mask=None, out=None):
+    """x [1,S,C]; shift/scale [1,C] or [C] -> LayerNorm(x)*(1+scale)+shift; rows with mask use (shift2, scale2)."""
+    _need_gpu(x, "ln_modulate")
+    x2, rows, C, xrs = _rows2d(x)
+    if out is None:
+        out = torch.empty(x.shape, dtype=x.dtype, device=x.device)
+    o2, _, _, ors = _rows2d(out)
+    v = lambda t: None if t is None else t.reshape(-1).to(dtype=x.dtype).contiguous()
+    sh, sc, sh2, sc2 = v(shift), v(scale), v(shift2), v(scale2)
+    m = None if mask is None else mask.to(torch.uint8).contiguous()
+    with torch.cuda.device(x.device):
+        _check(lib().jenga_ln_modulate(_stream(x.device), _p(x2), _p(o2), _p(sh), _p(sc), _p(sh2), _p(sc2), _p(m),
+                                       rows, C, xrs, ors, float(eps), dtype_code(x.dtype)), "jenga_ln_modulate")
+    return out
+
+
+def gate_residual(res, y, gate, gate2=None, mask=None, out=None):
+    """res + y * gate (per-channel gate [1,C]); rows with mask use gate2."""
+    _need_gpu(res, "gate_residual")
+    r2, rows, C, rrs = _rows2d(res)
+    y2, _, _, yrs = _rows2d(y)
+    if out is None:
+        out = torch.empty(res.shape, dtype=res.dtype, device=res.device)
+    o2, _, _, ors = _rows2d(out)
+    g = gate.reshape(-1).to(dtype=res.dtype).contiguous()
+    g2 = None if gate2 is None else gate2.reshape(-1).to(dtype=res.dtype).contiguous()
+    m = None if mask is None else mask.to(torch.uint8).contiguous()
+    with torch.cuda.device(res.device):
+        _check(lib().jenga_gate_residual(_stream(res.device), _p(r2), _p(y2), _p(g), _p(g2), _p(m), _p(o2), rows, C,
+                                         rrs, yrs, ors, dtype_code(res.dtype)), "jenga_gate_residual")
+    return out
+
+
+def gelu_tanh(x, out=None):
+    """tanh-GELU; x / out may be strided views (uniform row stride, contiguous channels)."""
+    _need_gpu(x, "gelu_tanh")
+    x2, rows, C, xrs = _rows2d(x)
+    if out is None:
+        out = torch.empty(x.shape, dtype=x.dtype, device=x.device)
+    o2, _, _, ors = _rows2d(out)
+    with torch.cuda.device(x.device):
+        _check(lib().jenga_gelu_tanh(_stream(x.device), _p(x2), _p(o2), rows, C, xrs, ors, dtype_code(x.dtype)),
+               "jenga_gelu_tanh")
     return out
 
 

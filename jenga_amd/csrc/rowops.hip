@@ -453,3 +453,190 @@ extern "C" int jenga_rope_complex(void* stream, const void* x, void* out, const 
     JENGA_CHECK_LAUNCH("jenga_rope_complex");
     return JENGA_OK;
 }
+
+// ================================================================================================ DiT block glue (f-2/f-3)
+// Fused elementwise passes around the GEMMs of the DiT blocks (models_mul_block_gc_ha_multigpu.py:196-203, 297-315,
+// 404-406, 498-500; hyvideo_i2v/modules/modulate_layers.py:37-110 for the token-replace variant).  Rounding points
+// follow the eager reference: every torch op result is rounded to the storage dtype.
+namespace jenga {
+namespace {
+
+// y = modulate(LayerNorm(x), shift, scale): LayerNorm without affine (eps), then x*(1+scale)+shift.  With a token
+// mask (I2V "token_replace": first-frame tokens use a second modulation set) rows with mask != 0 use (shift2, scale2).
+// One workgroup per row, C <= 8192 (multiple of 8).
+template <typename T>
+__global__ void __launch_bounds__(256) ln_modulate_kernel(const uint16_t* __restrict__ x, uint16_t* __restrict__ y,
+                                                          const uint16_t* __restrict__ shift,
+                                                          const uint16_t* __restrict__ scale,
+                                                          const uint16_t* __restrict__ shift2,
+                                                          const uint16_t* __restrict__ scale2,
+                                                          const uint8_t* __restrict__ mask, long long rows, int C,
+                                                          long long x_rs, long long y_rs, float eps) {
+    __shared__ float red[2][4];
+    for (long long row = blockIdx.x; row < rows; row += gridDim.x) {
+        const uint16_t* xr = x + row * x_rs;
+        const bool alt = mask && mask[row];
+        const uint16_t* sh = alt ? shift2 : shift;
+        const uint16_t* sc = alt ? scale2 : scale;
+        float f[4][8];
+        float s1 = 0.f, s2 = 0.f;
+        int nv = 0;
+        for (int c = threadIdx.x * 8; c < C; c += 2048, ++nv) {
+            unpack8<T>(*reinterpret_cast<const uint4*>(xr + c), f[nv]);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                s1 += f[nv][e];
+                s2 += f[nv][e] * f[nv][e];
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            s1 += __shfl_xor(s1, o);
+            s2 += __shfl_xor(s2, o);
+        }
+        if ((threadIdx.x & 63) == 0) {
+            red[0][threadIdx.x >> 6] = s1;
+            red[1][threadIdx.x >> 6] = s2;
+        }
+        __syncthreads();
+        s1 = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+        s2 = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+        __syncthreads();
+        const float mean = s1 / (float)C;
+        const float var = fmaxf(s2 / (float)C - mean * mean, 0.f);
+        const float rstd = 1.0f / sqrtf(var + eps);
+        nv = 0;
+        for (int c = threadIdx.x * 8; c < C; c += 2048, ++nv) {
+            float sv[8], hv[8], o[8];
+            unpack8<T>(*reinterpret_cast<const uint4*>(sc + c), sv);
+            unpack8<T>(*reinterpret_cast<const uint4*>(sh + c), hv);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float n = round_to<T>((f[nv][e] - mean) * rstd);           // F.layer_norm -> dtype
+                const float m = round_to<T>(n * round_to<T>(1.0f + sv[e]));       // x * (1 + scale)
+                o[e] = m + hv[e];                                                 // + shift (rounded by pack8)
+            }
+            *reinterpret_cast<uint4*>(y + row * y_rs + c) = pack8<T>(o);
+        }
+    }
+}
+
+// out = res + y * gate (apply_gate + residual add); rows with mask != 0 use gate2.  16 B per lane, grid-stride.
+template <typename T>
+__global__ void gate_residual_kernel(const uint16_t* __restrict__ res, const uint16_t* __restrict__ y,
+                                     const uint16_t* __restrict__ gate, const uint16_t* __restrict__ gate2,
+                                     const uint8_t* __restrict__ mask, uint16_t* __restrict__ out, long long rows,
+                                     int C, long long res_rs, long long y_rs, long long o_rs) {
+    const int vpr = C / 8;
+    const long long total = rows * vpr;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const long long row = i / vpr;
+        const int c = (int)(i % vpr) * 8;
+        const uint16_t* g = (mask && mask[row]) ? gate2 : gate;
+        float a[8], b[8], gv[8], o[8];
+        unpack8<T>(*reinterpret_cast<const uint4*>(res + row * res_rs + c), a);
+        unpack8<T>(*reinterpret_cast<const uint4*>(y + row * y_rs + c), b);
+        unpack8<T>(*reinterpret_cast<const uint4*>(g + c), gv);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = a[e] + round_to<T>(b[e] * gv[e]);
+        *reinterpret_cast<uint4*>(out + row * o_rs + c) = pack8<T>(o);
+    }
+}
+
+// tanh-approximated GELU from a (strided) source into a (strided) destination: the single-stream blocks write
+// gelu(mlp) straight into the right part of linear2's concat buffer.
+template <typename T>
+__global__ void gelu_tanh_kernel(const uint16_t* __restrict__ x, uint16_t* __restrict__ out, long long rows, int C,
+                                 long long x_rs, long long o_rs) {
+    const int vpr = C / 8;
+    const long long total = rows * vpr;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const long long row = i / vpr;
+        const int c = (int)(i % vpr) * 8;
+        float a[8], o[8];
+        unpack8<T>(*reinterpret_cast<const uint4*>(x + row * x_rs + c), a);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float v = a[e];
+            const float inner = 0.7978845608028654f * (v + 0.044715f * v * v * v);
+            o[e] = 0.5f * v * (1.0f + tanhf(inner));
+        }
+        *reinterpret_cast<uint4*>(out + row * o_rs + c) = pack8<T>(o);
+    }
+}
+
+}  // namespace
+}  // namespace jenga
+
+extern "C" int jenga_ln_modulate(void* stream, const void* x, void* y, const void* shift, const void* scale,
+                                 const void* shift2, const void* scale2, const uint8_t* mask, int64_t rows, int64_t C,
+                                 int64_t x_row_stride, int64_t y_row_stride, float eps, int dtype) {
+    if (!x || !y || !shift || !scale || rows < 0 || C <= 0 || (C & 7) || C > 8192 || (x_row_stride & 7) ||
+        (y_row_stride & 7) || (mask && (!shift2 || !scale2))) {
+        set_error("jenga_ln_modulate: bad arguments (C multiple of 8, <= 8192; mask needs the second modulation set)");
+        return JENGA_EINVAL;
+    }
+    if (dtype != JENGA_BF16 && dtype != JENGA_FP16) {
+        set_error("jenga_ln_modulate: dtype must be bf16 or fp16");
+        return JENGA_EUNSUPPORTED;
+    }
+    if (rows == 0) return JENGA_OK;
+#define LAUNCH_LM(T)                                                                                              \
+    hipLaunchKernelGGL(ln_modulate_kernel<T>, dim3(grid_for(rows, 65536)), dim3(256), 0, (hipStream_t)stream,     \
+                       (const uint16_t*)x, (uint16_t*)y, (const uint16_t*)shift, (const uint16_t*)scale,          \
+                       (const uint16_t*)shift2, (const uint16_t*)scale2, mask, (long long)rows, (int)C,           \
+                       (long long)x_row_stride, (long long)y_row_stride, eps)
+    if (dtype == JENGA_BF16) LAUNCH_LM(BF16); else LAUNCH_LM(FP16);
+#undef LAUNCH_LM
+    JENGA_CHECK_LAUNCH("jenga_ln_modulate");
+    return JENGA_OK;
+}
+
+extern "C" int jenga_gate_residual(void* stream, const void* res, const void* y, const void* gate, const void* gate2,
+                                   const uint8_t* mask, void* out, int64_t rows, int64_t C, int64_t res_row_stride,
+                                   int64_t y_row_stride, int64_t o_row_stride, int dtype) {
+    if (!res || !y || !gate || !out || rows < 0 || C <= 0 || (C & 7) || (res_row_stride & 7) || (y_row_stride & 7) ||
+        (o_row_stride & 7) || (mask && !gate2)) {
+        set_error("jenga_gate_residual: bad arguments");
+        return JENGA_EINVAL;
+    }
+    if (dtype != JENGA_BF16 && dtype != JENGA_FP16) {
+        set_error("jenga_gate_residual: dtype must be bf16 or fp16");
+        return JENGA_EUNSUPPORTED;
+    }
+    if (rows == 0) return JENGA_OK;
+    const int grid = grid_for((rows * (C / 8) + 255) / 256, 32768);
+#define LAUNCH_GR(T)                                                                                              \
+    hipLaunchKernelGGL(gate_residual_kernel<T>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)res, \
+                       (const uint16_t*)y, (const uint16_t*)gate, (const uint16_t*)gate2, mask, (uint16_t*)out,   \
+                       (long long)rows, (int)C, (long long)res_row_stride, (long long)y_row_stride,               \
+                       (long long)o_row_stride)
+    if (dtype == JENGA_BF16) LAUNCH_GR(BF16); else LAUNCH_GR(FP16);
+#undef LAUNCH_GR
+    JENGA_CHECK_LAUNCH("jenga_gate_residual");
+    return JENGA_OK;
+}
+
+extern "C" int jenga_gelu_tanh(void* stream, const void* x, void* out, int64_t rows, int64_t C, int64_t x_row_stride,
+                               int64_t o_row_stride, int dtype) {
+    if (!x || !out || rows < 0 || C <= 0 || (C & 7) || (x_row_stride & 7) || (o_row_stride & 7)) {
+        set_error("jenga_gelu_tanh: bad arguments");
+        return JENGA_EINVAL;
+    }
+    if (dtype != JENGA_BF16 && dtype != JENGA_FP16) {
+        set_error("jenga_gelu_tanh: dtype must be bf16 or fp16");
+        return JENGA_EUNSUPPORTED;
+    }
+    if (rows == 0) return JENGA_OK;
+    const int grid = grid_for((rows * (C / 8) + 255) / 256, 32768);
+    if (dtype == JENGA_BF16)
+        hipLaunchKernelGGL(gelu_tanh_kernel<BF16>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)x,
+                           (uint16_t*)out, (long long)rows, (int)C, (long long)x_row_stride, (long long)o_row_stride);
+    else
+        hipLaunchKernelGGL(gelu_tanh_kernel<FP16>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)x,
+                           (uint16_t*)out, (long long)rows, (int)C, (long long)x_row_stride, (long long)o_row_stride);
+    JENGA_CHECK_LAUNCH("jenga_gelu_tanh");
+    return JENGA_OK;
+}

@@ -74,7 +74,8 @@ class MLP(nn.Module):
         self.fc2 = nn.Linear(hidden_channels, in_channels, bias=True, dtype=dtype, device=device)
 
     def forward(self, x):
-        return self.fc2(F.gelu(self.fc1(x), approximate="tanh"))
+        h = self.fc1(x)
+        return self.fc2(_capi.gelu_tanh(h, out=h) if h.is_cuda else F.gelu(h, approximate="tanh"))
 
 
 def _select_top_k(sa_drop_rate, img_block_num):
@@ -109,7 +110,10 @@ class MMDoubleStreamBlock(nn.Module):
     @torch.no_grad()   # inference only, like the reference (hyvideo/inference.py:195 disables grad globally)
     def forward(self, img, txt, vec, cu_seqlens_q=None, cu_seqlens_kv=None, max_seqlen_q=None, max_seqlen_kv=None,
                 freqs_cis: tuple = None, sa_drop_rate: float = 0.0, txt_amp: float = 1.0, curve_sel: list = None,
-                p_remain_rates: float = 0.5, txt_block_num: int = 2, per_block_token: int = 128):
+                p_remain_rates: float = 0.5, txt_block_num: int = 2, per_block_token: int = 128,
+                token_replace_vec=None, first_frame_mask=None):
+        """token_replace_vec / first_frame_mask: the I2V "token_replace" conditioning (hyvideo_i2v/modules/
+        models_mul.py:136-320): image tokens with first_frame_mask set are modulated / gated by a second vector."""
         H = self.heads_num
         B, S_img, C = img.shape
         S_txt = txt.shape[1]
@@ -117,10 +121,14 @@ class MMDoubleStreamBlock(nn.Module):
          img_mod2_gate) = self.img_mod(vec).chunk(6, dim=-1)
         (txt_mod1_shift, txt_mod1_scale, txt_mod1_gate, txt_mod2_shift, txt_mod2_scale,
          txt_mod2_gate) = self.txt_mod(vec).chunk(6, dim=-1)
-        img_qkv = self.img_attn_qkv(modulate(self.img_norm1(img), img_mod1_shift, img_mod1_scale)).view(
-            B, S_img, 3, H, 128)
-        txt_qkv = self.txt_attn_qkv(modulate(self.txt_norm1(txt), txt_mod1_shift, txt_mod1_scale)).view(
-            B, S_txt, 3, H, 128)
+        tr = [None] * 6
+        if token_replace_vec is not None:
+            tr = self.img_mod(token_replace_vec).chunk(6, dim=-1)
+        fm = first_frame_mask if token_replace_vec is not None else None
+        # LayerNorm + adaLN modulation fused (one pass over HBM instead of three)
+        img_qkv = self.img_attn_qkv(_capi.ln_modulate(img, img_mod1_shift, img_mod1_scale, shift2=tr[0], scale2=tr[1],
+                                                      mask=fm)).view(B, S_img, 3, H, 128)
+        txt_qkv = self.txt_attn_qkv(_capi.ln_modulate(txt, txt_mod1_shift, txt_mod1_scale)).view(B, S_txt, 3, H, 128)
         block_neighbor_list = curve_sel[0][2] if curve_sel is not None else None
         top_k = _select_top_k(sa_drop_rate, S_img // per_block_token)
         cos, sin = freqs_cis
@@ -148,12 +156,14 @@ class MMDoubleStreamBlock(nn.Module):
             attn = op.attencarve_packed(q, k, vt, top_k, seqlens, txt_block_num, txt_amp, p_remain_rates,
                                         block_neighbor_list).view(B, S_img + S_txt, H * 128)
         img_attn, txt_attn = attn[:, :S_img], attn[:, S_img:]
-        img = img + apply_gate(self.img_attn_proj(img_attn), gate=img_mod1_gate)
-        img = img + apply_gate(self.img_mlp(modulate(self.img_norm2(img), img_mod2_shift, img_mod2_scale)),
-                               gate=img_mod2_gate)
-        txt = txt + apply_gate(self.txt_attn_proj(txt_attn), gate=txt_mod1_gate)
-        txt = txt + apply_gate(self.txt_mlp(modulate(self.txt_norm2(txt), txt_mod2_shift, txt_mod2_scale)),
-                               gate=txt_mod2_gate)
+        # gated residual adds fused; the MLP input is again LayerNorm + modulate in one pass
+        img = _capi.gate_residual(img, self.img_attn_proj(img_attn), img_mod1_gate, gate2=tr[2], mask=fm)
+        img = _capi.gate_residual(img, self.img_mlp(_capi.ln_modulate(img, img_mod2_shift, img_mod2_scale,
+                                                                      shift2=tr[3], scale2=tr[4], mask=fm)),
+                                  img_mod2_gate, gate2=tr[5], mask=fm)
+        txt = _capi.gate_residual(txt, self.txt_attn_proj(txt_attn), txt_mod1_gate)
+        txt = _capi.gate_residual(txt, self.txt_mlp(_capi.ln_modulate(txt, txt_mod2_shift, txt_mod2_scale)),
+                                  txt_mod2_gate)
         return img, txt
 
 
@@ -177,12 +187,17 @@ class MMSingleStreamBlock(nn.Module):
     def forward(self, x, vec, txt_len, cu_seqlens_q=None, cu_seqlens_kv=None, max_seqlen_q=None, max_seqlen_kv=None,
                 freqs_cis: Tuple[torch.Tensor, torch.Tensor] = None, sa_drop_rate: float = 0.0, txt_amp: float = 1.0,
                 curve_sel: list = None, p_remain_rates: float = 0.5, txt_block_num: int = 2,
-                per_block_token: int = 128):
+                per_block_token: int = 128, token_replace_vec=None, first_frame_mask=None):
         H, C = self.heads_num, self.hidden_size
         B, S, _ = x.shape
         S_img = S - txt_len
         mod_shift, mod_scale, mod_gate = self.modulation(vec).chunk(3, dim=-1)
-        lin1 = self.linear1(modulate(self.pre_norm(x), mod_shift, mod_scale))      # [B,S,3C + mlp]
+        tr, fm = [None] * 3, None
+        if token_replace_vec is not None:       # I2V token_replace (hyvideo_i2v/modules/models_mul.py:393-506)
+            tr = self.modulation(token_replace_vec).chunk(3, dim=-1)
+            fm = torch.cat([first_frame_mask.to(torch.uint8),
+                            torch.zeros(txt_len, dtype=torch.uint8, device=x.device)])   # text rows: regular set
+        lin1 = self.linear1(_capi.ln_modulate(x, mod_shift, mod_scale, shift2=tr[0], scale2=tr[1], mask=fm))
         qkv = lin1[..., : 3 * C].unflatten(-1, (3, H, 128))                        # strided views, no copies
         mlp = lin1[..., 3 * C:]
         cos, sin = freqs_cis
@@ -204,8 +219,8 @@ class MMSingleStreamBlock(nn.Module):
             vt = _capi.pack_v(qkv[:, :, 2], S // 128)
             op.attencarve_packed(q, k, vt, top_k, cu_seqlens_q[1:2], txt_block_num, txt_amp, p_remain_rates,
                                  block_neighbor_list, out=cat[..., :C].unflatten(-1, (H, 128)))
-        torch.ops.aten.gelu.out(mlp, approximate="tanh", out=cat[..., C:])
-        return x + apply_gate(self.linear2(cat), gate=mod_gate)
+        _capi.gelu_tanh(mlp, out=cat[..., C:])
+        return _capi.gate_residual(x, self.linear2(cat), mod_gate, gate2=tr[2], mask=fm)
 
 
 class JengaHYVideoDiT(nn.Module):

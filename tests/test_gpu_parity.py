@@ -402,3 +402,41 @@ def test_dense_path_vs_oracle(dev):
     n = S_img + valid
     assert np.abs(o[:, :n] - ref[:, :n]).max() <= 2e-2
     assert np.all(o[:, n:] == 0)
+
+
+# ----------------------------------------------------------------------------------------------- DiT block glue
+def test_fused_elementwise_vs_eager_chain(dev):
+    """jenga_ln_modulate / jenga_gate_residual / jenga_gelu_tanh against the eager torch chains of the reference blocks
+    (every op result rounded to bf16), incl. the I2V token-replace selection and strided views."""
+    import torch.nn.functional as F
+    from jenga_amd import _capi
+    g = torch.Generator(device=dev).manual_seed(9)
+    S, C = 300, 3072
+    x = (torch.randn(1, S, C, generator=g, device=dev) * 2 + 0.3).to(torch.bfloat16)
+    vecs = [(0.2 * torch.randn(1, C, generator=g, device=dev)).to(torch.bfloat16) for _ in range(6)]
+    sh, sc, gt, sh2, sc2, gt2 = vecs
+    mask = torch.rand(S, generator=g, device=dev) < 0.3
+    eager = lambda t, s_, c_: F.layer_norm(t, (C,), eps=1e-6) * (1 + c_.unsqueeze(1)) + s_.unsqueeze(1)
+    y = _capi.ln_modulate(x, sh, sc)
+    # x*(1+scale) and shift can cancel, so a one-ulp flip of an intermediate is measured at the row's scale
+    assert_ulp_close(to_np(y), to_np(eager(x, sh, sc)), "bfloat16", max_frac=5e-3, max_ulps=2, rowwise=True)
+    y2 = _capi.ln_modulate(x, sh, sc, shift2=sh2, scale2=sc2, mask=mask)
+    ref2 = eager(x, sh, sc)
+    ref2[:, mask] = eager(x, sh2, sc2)[:, mask]
+    assert_ulp_close(to_np(y2), to_np(ref2), "bfloat16", max_frac=5e-3, max_ulps=2, rowwise=True)
+    # gate + residual, y as a strided view
+    big = torch.randn(1, S, 2 * C, generator=g, device=dev).to(torch.bfloat16)
+    yv = big[..., C:]
+    out = _capi.gate_residual(x, yv, gt)
+    assert torch.equal(out, x + yv * gt.unsqueeze(1))
+    out2 = _capi.gate_residual(x, yv, gt, gate2=gt2, mask=mask)
+    ref = x + yv * gt.unsqueeze(1)
+    ref[:, mask] = (x + yv * gt2.unsqueeze(1))[:, mask]
+    assert torch.equal(out2, ref)
+    # gelu into the right part of a concat buffer
+    cat = torch.zeros(1, S, C + 512, device=dev, dtype=torch.bfloat16)
+    src = big[..., :512]
+    _capi.gelu_tanh(src, out=cat[..., C:])
+    want = F.gelu(src, approximate="tanh")
+    assert_ulp_close(to_np(cat[..., C:]), to_np(want), "bfloat16", max_frac=2e-3, max_ulps=1)
+    assert torch.count_nonzero(cat[..., :C]) == 0
