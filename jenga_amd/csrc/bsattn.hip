@@ -49,6 +49,10 @@ constexpr int KT = 64;                      // keys per LDS tile
 constexpr int K_TILE_BYTES = KT * 128 * 2;  // 16 KiB
 constexpr int V_TILE_BYTES = 128 * KT * 2;  // 16 KiB
 constexpr int BUF_BYTES = K_TILE_BYTES + V_TILE_BYTES;
+// 4-wave kernel LDS: K ring of 3 slots (tile t in slot t % 3, fetched two tiles ahead) + V^T ring of 2 slots
+// (fetched one tile ahead, first read in the second half of its tile): 80 KiB, two workgroups fill the CU's 160 KiB.
+constexpr int W4_V_RING = 3 * K_TILE_BYTES;
+constexpr int W4_LDS_BYTES = 3 * K_TILE_BYTES + 2 * V_TILE_BYTES;
 
 // Direct global -> LDS staging (global_load_lds_dwordx4, 1 KiB per wave-instruction, no staging VGPRs, no
 // ds_write).  The LDS image of a wave-instruction is lane-linear (base + lane*16), so the XOR swizzle of the tile is
@@ -60,22 +64,15 @@ constexpr int BUF_BYTES = K_TILE_BYTES + V_TILE_BYTES;
 // invisible to its waitcnt bookkeeping, so the kernel waits itself (STAGE_WAIT) right before the barrier that
 // publishes the tile.  One statement stages a whole tile: 4 K pieces + 4 V^T pieces of 1 KiB each for this wave,
 // global address = uniform 64-bit base (SGPR pair) + per-lane 32-bit byte offset (loop-invariant VGPR), LDS
-// destination = M0 (saved/restored inside the statement, guide 5.7), advanced by 1 KiB per piece.
+// destination = M0 (saved/restored inside the statement, guide 5.7), advanced by 1 KiB per piece.  The four V^T
+// pieces go out BEFORE the four K pieces: loads complete in order, so `s_waitcnt vmcnt(4)` retires everything up to
+// and including this call's V pieces while its K pieces (needed one tile later) stay in flight.
 __device__ __forceinline__ void stage_tile(const void* kbase, const void* vbase, unsigned lds_k, unsigned lds_v,
                                            unsigned k0, unsigned k1, unsigned k2, unsigned k3, unsigned v0,
                                            unsigned v1, unsigned v2, unsigned v3) {
     unsigned keep;
     asm volatile(
         "s_mov_b32 %0, m0\n\t"
-        "s_mov_b32 m0, %1\n\t"
-        "s_nop 0\n\t"
-        "global_load_lds_dwordx4 %5, %3\n\t"
-        "s_add_u32 m0, m0, 0x400\n\t"
-        "global_load_lds_dwordx4 %6, %3\n\t"
-        "s_add_u32 m0, m0, 0x400\n\t"
-        "global_load_lds_dwordx4 %7, %3\n\t"
-        "s_add_u32 m0, m0, 0x400\n\t"
-        "global_load_lds_dwordx4 %8, %3\n\t"
         "s_mov_b32 m0, %2\n\t"
         "s_nop 0\n\t"
         "global_load_lds_dwordx4 %9, %4\n\t"
@@ -85,17 +82,27 @@ __device__ __forceinline__ void stage_tile(const void* kbase, const void* vbase,
         "global_load_lds_dwordx4 %11, %4\n\t"
         "s_add_u32 m0, m0, 0x400\n\t"
         "global_load_lds_dwordx4 %12, %4\n\t"
+        "s_mov_b32 m0, %1\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %5, %3\n\t"
+        "s_add_u32 m0, m0, 0x400\n\t"
+        "global_load_lds_dwordx4 %6, %3\n\t"
+        "s_add_u32 m0, m0, 0x400\n\t"
+        "global_load_lds_dwordx4 %7, %3\n\t"
+        "s_add_u32 m0, m0, 0x400\n\t"
+        "global_load_lds_dwordx4 %8, %3\n\t"
         "s_mov_b32 m0, %0"
         : "=&s"(keep)
         : "s"(lds_k), "s"(lds_v), "s"(kbase), "s"(vbase), "v"(k0), "v"(k1), "v"(k2), "v"(k3), "v"(v0), "v"(v1),
           "v"(v2), "v"(v3)
         : "memory", "scc");
 }
-#define STAGE_TILE(KPTR, VPTR, BUF)                                                                        \
-    stage_tile((KPTR), (VPTR), smem_base + (BUF) * BUF_BYTES + wave_u * 4096,                             \
-               smem_base + (BUF) * BUF_BYTES + K_TILE_BYTES + wave_u * 4096, k_src0, k_src1, k_src2, k_src3, \
+#define STAGE_TILE(KPTR, VPTR, KSLOT, VSLOT)                                                               \
+    stage_tile((KPTR), (VPTR), smem_base + (KSLOT) * K_TILE_BYTES + wave_u * 4096,                        \
+               smem_base + W4_V_RING + (VSLOT) * V_TILE_BYTES + wave_u * 4096, k_src0, k_src1, k_src2, k_src3, \
                v_src0, v_src1, v_src2, v_src3)
 #define STAGE_WAIT() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#define STAGE_WAIT_KEEP_K() asm volatile("s_waitcnt vmcnt(4)" ::: "memory")
 
 // Lazy running max: m~ is an integer-valued upper reference of each row's max, raised (by an integer step, so every
 // rescale factor is an exact power of two) only when a row's new max exceeds it by more than LAZY_THR in log2 units.
@@ -191,9 +198,10 @@ __device__ __forceinline__ void attn_block(const AttnParams& P, unsigned char* s
     const unsigned v_src3 = (unsigned)(vr_ + 24) * 128 + ((vc_ ^ ((12 + vsw_) & 7)) << 4);
 
     // one 64-key tile out of LDS buffer BUF (0/1); `blk` = kv block id, HALF = which half of it
-#define COMPUTE_TILE(BUF, HALF, SLOW)                                                                            \
+#define COMPUTE_TILE(KSLOT, VSLOT, HALF, SLOW)                                                                   \
     do {                                                                                                         \
-        const unsigned char* cur = smem + (BUF) * BUF_BYTES;                                                     \
+        const unsigned char* cur = smem + (KSLOT) * K_TILE_BYTES;                                                \
+        const unsigned char* curv = smem + W4_V_RING + (VSLOT) * V_TILE_BYTES - K_TILE_BYTES;                    \
         const int key0 = blk * 128 + (HALF) * KT;                                                                \
         if (!(SLOW) || key0 < seqlen) { /* a tile entirely past seqlen contributes exp2(-inf) = 0 */             \
             f32x16 s0, s1;                                                                                       \
@@ -317,7 +325,7 @@ __device__ __forceinline__ void attn_block(const AttnParams& P, unsigned char* s
                 MFMA_PRIO(1);                                                                                    \
                 _Pragma("unroll") for (int ks = 0; ks < 4; ++ks)                                                 \
                     _Pragma("unroll") for (int db = 0; db < 4; ++db)                                             \
-                        va[ks][db] = *reinterpret_cast<const uint4*>(cur + v_addr[ks] + db * 4096);              \
+                        va[ks][db] = *reinterpret_cast<const uint4*>(curv + v_addr[ks] + db * 4096);             \
                 _Pragma("unroll") for (int ks = 0; ks < 4; ++ks)                                                 \
                     _Pragma("unroll") for (int db = 0; db < 4; ++db)                                             \
                         oacc[db] = mfma32<T>(va[ks][db], pf[ks], oacc[db]);                                      \
@@ -356,35 +364,44 @@ __device__ __forceinline__ void attn_block(const AttnParams& P, unsigned char* s
             DST = __builtin_amdgcn_readlane(lchunk, (J) & 63);                                                   \
         }                                                                                                        \
     } while (0)
-    int blk = 0;
+    // Tile t (= 2*i + half of kept block i) reads K slot t % 3 and V^T slot t % 2.  At the start of tile t the DMA of
+    // V(t+1) and K(t+2) goes out; at its end vmcnt(4) retires V(t+1) (and K(t+1), issued a tile earlier) and leaves
+    // K(t+2) in flight across the barrier: K has two tiles of lead, V one and a half.
+    int blk = 0, ks_cur = 0, ks_p2 = 2;   // K slot of the current tile / of tile t+2
     if (nkept > 0) {
         LIST_GET(0, blk);
-        STAGE_TILE(kbh + (long long)blk * 128 * P.k_ss, vbh + (long long)blk * 2 * (128 * KT), 0);
+        // prologue: V(0) + K(0), then (dummy V into the free slot) + K(1); keep K(1) in flight
+        STAGE_TILE(kbh + (long long)blk * 128 * P.k_ss, vbh + (long long)blk * 2 * (128 * KT), 0, 0);
+        STAGE_TILE(kbh + ((long long)blk * 128 + KT) * P.k_ss, vbh + ((long long)blk * 2 + 1) * (128 * KT), 1, 1);
     }
-    STAGE_WAIT();
+    STAGE_WAIT_KEEP_K();
     __syncthreads();
 
 #define BLOCK_LOOP(FROM, TO, SLOW)                                                                               \
     for (int i = (FROM); i < (TO); ++i) {                                                                        \
-        /* half 0 lives in buffer 0; fetch half 1 of the same block into buffer 1 meanwhile (buffer 1 was last    \
-           read before the barrier that ended the previous iteration) */                                         \
-        STAGE_TILE(kbh + ((long long)blk * 128 + KT) * P.k_ss, vbh + ((long long)blk * 2 + 1) * (128 * KT), 1);  \
-        COMPUTE_TILE(0, 0, SLOW);                                                                                \
-        STAGE_WAIT();                                                                                            \
-        __syncthreads();                                                                                         \
-        /* half 1 in buffer 1; fetch half 0 of the next kept block (clamped: the last re-fetch is unused) */      \
         int nblk = blk;                                                                                          \
         if (i + 1 < nkept) LIST_GET(i + 1, nblk);                                                                \
-        STAGE_TILE(kbh + ((long long)nblk * 128) * P.k_ss, vbh + ((long long)nblk * 2) * (128 * KT), 0);         \
-        COMPUTE_TILE(1, 1, SLOW);                                                                                \
-        STAGE_WAIT();                                                                                            \
+        /* tile 2i: V(2i+1) = block i half 1 -> V slot 1; K(2i+2) = next block half 0 -> K slot (t+2)%3 */       \
+        STAGE_TILE(kbh + ((long long)nblk * 128) * P.k_ss, vbh + ((long long)blk * 2 + 1) * (128 * KT), ks_p2, 1); \
+        COMPUTE_TILE(ks_cur, 0, 0, SLOW);                                                                        \
+        STAGE_WAIT_KEEP_K();                                                                                     \
         __syncthreads();                                                                                         \
+        ks_cur = (ks_cur == 2) ? 0 : ks_cur + 1;                                                                 \
+        ks_p2 = (ks_p2 == 2) ? 0 : ks_p2 + 1;                                                                    \
+        /* tile 2i+1: V(2i+2) = next block half 0 -> V slot 0; K(2i+3) = next block half 1 */                    \
+        STAGE_TILE(kbh + ((long long)nblk * 128 + KT) * P.k_ss, vbh + ((long long)nblk * 2) * (128 * KT), ks_p2, 0); \
+        COMPUTE_TILE(ks_cur, 1, 1, SLOW);                                                                        \
+        STAGE_WAIT_KEEP_K();                                                                                     \
+        __syncthreads();                                                                                         \
+        ks_cur = (ks_cur == 2) ? 0 : ks_cur + 1;                                                                 \
+        ks_p2 = (ks_p2 == 2) ? 0 : ks_p2 + 1;                                                                    \
         blk = nblk;                                                                                              \
     }
     BLOCK_LOOP(0, n_fast, 0)
     if (!TEXT) {
         BLOCK_LOOP(n_fast, nkept, 1)
     }
+    STAGE_WAIT();   // drain the last (unused) prefetch before the workgroup's LDS is released
 #undef LIST_GET
 #undef BLOCK_LOOP
 #undef COMPUTE_TILE
@@ -892,7 +909,7 @@ extern "C" int jenga_bsattn_fwd(void* stream, const void* q, const void* k, cons
         }
         return JENGA_OK;
     }
-    const size_t smem = 2 * BUF_BYTES;
+    const size_t smem = W4_LDS_BYTES;
     if (dtype == JENGA_BF16) {
         static bool attr_done = false;
         if (!attr_done) {
