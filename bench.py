@@ -37,8 +37,11 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=6)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--rates", type=float, nargs=2, default=[0.75, 0.85],
-                    help="sa-drop-rates per stage; 0.75 0.85 = the shipped Jenga-Base script, 0.7 0.8 = BASELINE.json's pair")
+    ap.add_argument("--rates", type=float, nargs="+", default=None,
+                    help="sa-drop-rates per stage; default per preset (base: 0.75 0.85 = the shipped Jenga-Base script; "
+                         "0.7 0.8 = BASELINE.json's pair)")
+    ap.add_argument("--preset", choices=["base", "turbo", "3stage"], default="base",
+                    help="scripts/hyvideo_jenga_{base,turbo,3stage}.sh: resolution / step / shift / drop-rate lists")
     ap.add_argument("--p-remain", type=float, default=0.3)
     ap.add_argument("--latent", type=int, nargs=3, default=[32, 90, 160], help="latent T H W (720x1280x125f)")
     ap.add_argument("--depth", type=int, nargs=2, default=None, help="override (double, single) block counts (debug only)")
@@ -47,8 +50,20 @@ def parse():
     return ap.parse_args()
 
 
-def rate_for_step(i, rates):
-    return rates[0] if i <= 25 else rates[1]     # step-rate-list 0.5 1.0 (pipeline...prores.py:422,697-698)
+PRESETS = {   # scripts/hyvideo_jenga_base.sh:19-25, hyvideo_jenga_turbo.sh, hyvideo_jenga_3stage.sh
+    "base": dict(res=[1.0, 1.0], steps=[0.5, 1.0], rates=[0.75, 0.85], shifts=[7, 7]),
+    "turbo": dict(res=[0.75, 1.0], steps=[0.5, 1.0], rates=[0.7, 0.8], shifts=[7, 9]),
+    "3stage": dict(res=[0.5, 0.75, 1.0], steps=[0.3, 0.5, 1.0], rates=[0.75, 0.85, 0.85], shifts=[7, 9, 11]),
+}
+
+
+def stage_of(i, split):
+    """Step i runs at stage k = number of split points strictly below i (the switch happens AFTER step split[k],
+    pipeline_hunyuan_video_prores.py:697-698)."""
+    k = 0
+    while k < len(split) - 1 and i > split[k]:
+        k += 1
+    return k
 
 
 def cpu_baseline(rates, p_remain):
@@ -110,10 +125,25 @@ def main():
         ulysses.init_sequence_parallel()
         for blk in list(model.double_blocks) + list(model.single_blocks):
             blk.hybrid_seq_parallel_attn = ulysses.UlyssesAttenCarve()
+    from jenga_amd import prores
+    preset = dict(PRESETS[a.preset])
+    if a.rates:
+        preset["rates"] = list(a.rates) + [a.rates[-1]] * (len(preset["res"]) - len(a.rates))
+    a.rates = preset["rates"]
     T, Hh, W = a.latent
-    cos, sin = model.set_stage((T, Hh, W), dev)
+    shapes, split = prores.stage_plan((T, Hh, W), 50, preset["res"], preset["steps"])
     g = torch.Generator(device=dev).manual_seed(42)
-    latents = torch.randn(1, 16, T, Hh, W, generator=g, device=dev, dtype=torch.bfloat16)
+    stages = []
+    for k, shp in enumerate(shapes):      # static geometry + synthetic latents per resolution stage
+        cos_k, sin_k = model.set_stage(shp, dev)
+        stages.append(dict(shape=shp, cos=cos_k, sin=sin_k, curve=model.curve_sel, l2h=model.linear_to_hilbert,
+                           h2l=model.hilbert_order,
+                           latents=torch.randn(1, 16, *shp, generator=g, device=dev, dtype=torch.bfloat16),
+                           text_amp=prores.stage_text_amp(shp, shapes[-1]) if preset["res"][k] != 1.0 else 0.0))
+    # steps forced to compute by `start_stage` right after a resolution switch (:755)
+    forced = {split[k] + 1 for k in range(len(split) - 1) if preset["res"][k] != 1.0}
+    computed_steps = sorted(set(NON_SKIP_STEPS) | forced)
+    sched = prores.FlowMatchSchedule(50, shift=preset["shifts"][0])
     g2 = torch.Generator(device=dev).manual_seed(43)
     text = torch.randn(1, 256, 4096, generator=g2, device=dev, dtype=torch.bfloat16)
     text2 = torch.randn(1, 768, generator=g2, device=dev, dtype=torch.bfloat16)
@@ -126,17 +156,36 @@ def main():
     model.enable_skip = True
 
     def run_step(i):
+        k = stage_of(i, split)
+        st = stages[k]
+        model.curve_sel, model.linear_to_hilbert, model.hilbert_order = st["curve"], st["l2h"], st["h2l"]
         model.cnt = i
-        model.sa_drop_rate = rate_for_step(i, a.rates)
-        tval = torch.tensor([1000.0 * (1 - i / 50)], device=dev)
-        return model(latents, tval, text_states=text, text_mask=text_mask, text_states_2=text2, freqs_cos=cos,
-                     freqs_sin=sin, guidance=guidance, return_dict=False)
+        model.sa_drop_rate = a.rates[k]
+        model.text_amp = st["text_amp"]
+        model.start_stage = i in forced
+        tval = sched.timesteps[i:i + 1].to(dev)
+        out_ = model(st["latents"], tval, text_states=text, text_mask=text_mask, text_states_2=text2,
+                     freqs_cos=st["cos"], freqs_sin=st["sin"], guidance=guidance, return_dict=False)
+        if i in split[:-1] and k + 1 < len(stages) and preset["res"][k] != 1.0:
+            # the re-noising hop to the next resolution (x0-predict, trilinear upsample, add noise)
+            nxt = stages[k + 1]
+            prores.switch_stage(sched, out_, i, st["latents"], nxt["shape"], preset["shifts"][k + 1], nxt["latents"])
+        return out_
+
+    def klass(i):
+        return (stage_of(i, split), "c" if i in computed_steps else "s")
 
     if a.steps >= 50:
         plan = [i % 50 for i in range(a.steps)]      # whole loop(s); sec/video = elapsed * 50 / steps
         sampled = False
     else:
-        pattern = [0, 5, 7, 26, 27, 29]        # computed@r0, skipped, computed@r0, computed@r1, skipped, computed@r1
+        # class-balanced sample of the schedule: per stage two computed steps and one skipped one
+        pattern = []
+        for k in range(len(stages)):
+            ids = [i for i in range(50) if stage_of(i, split) == k]
+            comp = [i for i in ids if i in computed_steps]
+            skip = [i for i in ids if i not in computed_steps]
+            pattern += comp[:1] + skip[:1] + comp[1:2]
         plan = [pattern[j % len(pattern)] for j in range(a.steps)]
         sampled = True
 
@@ -146,7 +195,7 @@ def main():
         torch.cuda.synchronize()
 
     for w in range(a.warmup):
-        run_step(0 if w % 2 == 0 else 26)       # computed steps: also fills previous_residual
+        run_step(computed_steps[0] if w % 2 == 0 else computed_steps[-1])   # computed steps: fills previous_residual
     barrier()
     _capi.ATTN_PROFILE = prof = _capi.AttnProfile()
     evs = []
@@ -166,22 +215,25 @@ def main():
         elapsed = float(tt.item())
     finite = bool(torch.isfinite(out.float()).all().item())
 
-    cls = {"c0": [], "c1": [], "skip": []}
+    cls = {}
     for i, e0, e1 in evs:
-        ms = e0.elapsed_time(e1)
-        key = "skip" if i not in NON_SKIP_STEPS else ("c0" if i <= 25 else "c1")
-        cls[key].append(ms)
+        cls.setdefault(klass(i), []).append(e0.elapsed_time(e1))
     mean = lambda v: sum(v) / len(v) if v else float("nan")
+    counts = {}
+    for i in range(50):
+        counts[klass(i)] = counts.get(klass(i), 0) + 1
     if sampled:
-        n_c0 = sum(1 for s in NON_SKIP_STEPS if s <= 25)
-        n_c1 = len(NON_SKIP_STEPS) - n_c0
-        n_skip = 50 - len(NON_SKIP_STEPS)
-        parts = [(n_c0, mean(cls["c0"])), (n_c1, mean(cls["c1"])), (n_skip, mean(cls["skip"]))]
         if world > 1:   # scale the per-class event times so that they sum to the max-over-ranks wall time
             scale = elapsed * 1e3 / max(sum(e0.elapsed_time(e1) for _, e0, e1 in evs), 1e-9)
         else:
             scale = 1.0
-        sec_per_video = sum(n * t for n, t in parts if n and t == t) * scale / 1e3
+        # a class that was not sampled (very small --steps) borrows the mean of the same kind from another stage
+        def class_ms(key):
+            if key in cls:
+                return mean(cls[key])
+            same = [mean(v) for kk, v in cls.items() if kk[1] == key[1]]
+            return same[-1] if same else 0.0
+        sec_per_video = sum(n * class_ms(key) for key, n in counts.items()) * scale / 1e3
     else:
         sec_per_video = elapsed * 50.0 / len(plan)
     ps = prof.summary()
@@ -198,14 +250,18 @@ def main():
         "value": round(sec_per_video, 3), "unit": "s/video", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": round(elapsed * 1e3 / max(len(plan), 1), 3), "higher_is_better": False, "scaling": "strong",
         "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-        "config": {"workload": "HunyuanVideo 720x1280x125f Jenga-Base, 1xMI355X-class GPU per rank: latent "
+        "config": {"workload": f"HunyuanVideo 720x1280x125f Jenga-{a.preset}, 1xMI355X-class GPU per rank: latent "
                                f"{T}x{Hh}x{W}, {len(model.double_blocks)} double + {len(model.single_blocks)} single "
                                "blocks, hidden 3072, 24 heads, S_img=%d S_txt=256" % ((T * Hh * W) // 4),
+                   "preset": a.preset, "res_rate_list": preset["res"], "step_rate_list": preset["steps"],
+                   "scheduler_shift_list": preset["shifts"],
+                   "stage_tokens": [(sh[0] * (sh[1] // 2) * (sh[2] // 2)) for sh in shapes],
                    "sa_drop_rates": a.rates, "p_remain_rates": a.p_remain, "valid_text_tokens": a.valid_text,
                    "schedule": "full 50-step loop" if not sampled else
-                   f"sampled steps {plan}; sec/video = 12*t(computed@rate0) + 11*t(computed@rate1) + 27*t(skipped)",
-                   "ms_computed_rate0": round(mean(cls["c0"]), 2), "ms_computed_rate1": round(mean(cls["c1"]), 2),
-                   "ms_skipped": round(mean(cls["skip"]), 2),
+                   f"sampled steps {plan}; sec/video = sum over (stage, computed|skipped) classes of "
+                   f"count x mean step time, counts {dict((f'{k[0]}{k[1]}', n) for k, n in counts.items())}",
+                   "ms_per_class": {f"stage{k[0]}_{'computed' if k[1] == 'c' else 'skipped'}": round(mean(v), 2)
+                                    for k, v in sorted(cls.items())},
                    "parallelism": "single GPU" if world == 1 else f"ulysses{world} (RCCL all-to-all)",
                    "weights": "random init N(0,0.02), seed 0", "finite_output": finite},
         "roofline": {"kernel": "jenga::bsattn_fwd_kernel<bf16>", "bound": "mfma", "achieved": round(ach, 1),
@@ -222,10 +278,10 @@ def main():
         cb = cpu_baseline(a.rates, a.p_remain)
         # pairs per video: measured pairs per launch by class -> 60 layers x 23 computed steps
         launches_per_step = len(model.double_blocks) + len(model.single_blocks)
-        computed = [i for i in plan if i in NON_SKIP_STEPS]
+        computed = [i for i in plan if i in computed_steps]
         if computed and ps["launches"]:
             pairs_per_step = ps["pairs"] / len(computed)
-            video_pairs = pairs_per_step * len(NON_SKIP_STEPS)
+            video_pairs = pairs_per_step * len(computed_steps)
             res["cpu_baseline"] = {"value": round(video_pairs / cb["pairs_per_s"], 1), "unit": "s/video",
                                    "cores": cb["cores"], "kind": "port", "sample": cb["sample"]}
     if rank == 0:

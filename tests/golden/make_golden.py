@@ -254,13 +254,59 @@ def gen_wan():
     np.savez_compressed(os.path.join(OUT, "wan_cases.npz"), **out)
 
 
+def gen_scheduler():
+    """FlowMatchDiscreteScheduler (diffusers absent -> its three imports are stubbed for the import only)."""
+    import dataclasses
+    for name in ("diffusers", "diffusers.configuration_utils", "diffusers.utils", "diffusers.schedulers",
+                 "diffusers.schedulers.scheduling_utils"):
+        sys.modules.setdefault(name, types.ModuleType(name))
+
+    class _Cfg:
+        pass
+
+    def register_to_config(init):
+        def wrapped(self, *a, **kw):
+            import inspect
+            sig = inspect.signature(init)
+            ba = sig.bind(self, *a, **kw)
+            ba.apply_defaults()
+            self.config = _Cfg()
+            for k, v in list(ba.arguments.items())[1:]:
+                setattr(self.config, k, v)
+            init(self, *a, **kw)
+        return wrapped
+
+    sys.modules["diffusers.configuration_utils"].ConfigMixin = type("ConfigMixin", (), {})
+    sys.modules["diffusers.configuration_utils"].register_to_config = register_to_config
+    sys.modules["diffusers.utils"].BaseOutput = type("BaseOutput", (), {})
+    sys.modules["diffusers.utils"].logging = types.SimpleNamespace(get_logger=lambda n: None)
+    sys.modules["diffusers.schedulers.scheduling_utils"].SchedulerMixin = type("SchedulerMixin", (), {})
+    m = _load("ref_sched", "hyvideo/diffusion/schedulers/scheduling_flow_match_discrete.py")
+    out = {}
+    gen = torch.Generator().manual_seed(3)
+    lat = torch.randn(1, 4, 3, 6, 8, generator=gen).to(torch.bfloat16)
+    npred = torch.randn(1, 4, 3, 6, 8, generator=gen).to(torch.bfloat16)
+    noise = torch.randn(1, 4, 3, 6, 8, generator=gen).to(torch.bfloat16)
+    out["lat"], out["npred"], out["noise"] = (t.float().numpy() for t in (lat, npred, noise))
+    for shift in (7.0, 9.0):
+        sch = m.FlowMatchDiscreteScheduler(shift=shift, reverse=True, solver="euler")
+        sch.set_timesteps(50)
+        out[f"sigmas_{int(shift)}"] = sch.sigmas.numpy()
+        out[f"timesteps_{int(shift)}"] = sch.timesteps.numpy()
+        t = sch.timesteps[25]
+        out[f"x0_{int(shift)}"] = sch.predict_x0_from_xt(npred, t, lat, return_dict=False)[0].numpy()
+        out[f"renoise_{int(shift)}"] = sch.add_noise_to_step(lat, noise, sch.timesteps[26]).prev_sample.numpy()
+        out[f"step_{int(shift)}"] = sch.step(npred, t, lat, return_dict=False)[0].numpy()
+    np.savez_compressed(os.path.join(OUT, "scheduler_cases.npz"), **out)
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--big", action="store_true", help="also hash the full-size curves (about 1 min)")
     ap.add_argument("--only", default="")
     a = ap.parse_args()
     torch.set_grad_enabled(False)
-    if a.only != "wan":
+    if a.only not in ("wan", "sched"):
         gen_gilbert(a.big)
     if a.only in ("", "select", "attn"):
         gen_select()
@@ -270,4 +316,6 @@ if __name__ == "__main__":
         gen_norm_rope()
     if a.only in ("", "wan"):
         gen_wan()
+    if a.only in ("", "sched"):
+        gen_scheduler()
     print("golden fixtures written to", OUT)
