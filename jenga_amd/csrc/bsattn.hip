@@ -109,7 +109,23 @@ __device__ __forceinline__ void stage_tile(const void* kbase, const void* vbase,
 // P = exp2(S - m~) costs one packed add per two scores; O and l are rescaled only in the (rare) raise path (keeping
 // -m~ in the MFMA C operand instead was tried: hipcc then copies the 32 C registers every tile, which costs more).  P <= 2^LAZY_THR keeps the storage dtype's relative
 // precision (power-of-two scaling commutes with rounding), so results match the eager max up to fp32 rounding.
+// Two measured-and-rejected variants of the softmax hot path, kept as switches (tools/micro/*.hip):
+// on a gfx950 SIMD the FP add/mul/convert ops of one wave are NOT hidden under the partner wave's MFMAs while v_mov,
+// integer ops, v_max, v_ldexp and (75 %) v_exp are -- but trading 32 FP subtracts for 32 register copies (CNEG: 997
+// TFLOP/s) or 16 v_cvt_pk for 80 integer ops (INTPACK: 967) lengthens the wave's own serial stream by more than it
+// frees on the shared pipe (baseline 1049).
+#ifndef JENGA_SM_CNEG
+#define JENGA_SM_CNEG 0      // 1: -m~ rides in the MFMA C operand; 0: subtracted with FP adds after the MFMAs
+#endif
+#ifndef JENGA_SM_INTPACK
+#define JENGA_SM_INTPACK 0   // 1: bf16 rounding/packing of P with integer ops; 0: v_cvt_pk_bf16_f32
+#endif
 constexpr float LAZY_THR = 8.0f;
+#if JENGA_SM_INTPACK
+#define PACKP pack2_int
+#else
+#define PACKP pack2
+#endif
 constexpr float RAISE_SUM = 256.0f;   // 2^LAZY_THR
 #ifndef JENGA_SETPRIO
 #define JENGA_SETPRIO 1
@@ -164,6 +180,9 @@ __device__ __forceinline__ void attn_block(const AttnParams& P, unsigned char* s
         for (int r = 0; r < 16; ++r) oacc[i][r] = 0.f;
     float l_i = 0.f;
     float neg_m = 0.f;      // -m~ (integer valued)
+    f32x16 cneg;            // MFMA C operand of the first K.Q^T step: -m~ splat (register copies are v_mov = free)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) cneg[r] = 0.f;
     f32x16 zero16;
 #pragma unroll
     for (int r = 0; r < 16; ++r) zero16[r] = 0.f;
@@ -215,8 +234,8 @@ __device__ __forceinline__ void attn_block(const AttnParams& P, unsigned char* s
                         ka[ds] = *reinterpret_cast<const uint4*>(cur + k_addr[ds]);                              \
                         kb[ds] = *reinterpret_cast<const uint4*>(cur + k_addr[ds] + 8192);                       \
                     }                                                                                            \
-                    s0 = mfma32<T>(ka[0], qf[0], zero16);                                                        \
-                    s1 = mfma32<T>(kb[0], qf[0], zero16);                                                        \
+                    s0 = mfma32<T>(ka[0], qf[0], (TEXT || !JENGA_SM_CNEG) ? zero16 : cneg);                     \
+                    s1 = mfma32<T>(kb[0], qf[0], (TEXT || !JENGA_SM_CNEG) ? zero16 : cneg);                     \
                     _Pragma("unroll") for (int ds = 1; ds < 8; ++ds) {                                           \
                         s0 = mfma32<T>(ka[ds], qf[ds], s0);                                                      \
                         s1 = mfma32<T>(kb[ds], qf[ds], s1);                                                      \
@@ -232,8 +251,8 @@ __device__ __forceinline__ void attn_block(const AttnParams& P, unsigned char* s
                 }                                                                                                \
                 if (TEXT) {                                                                                      \
                     _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                             \
-                        s0[r] *= P.qk_scale;                                                                     \
-                        s1[r] *= P.qk_scale;                                                                     \
+                        s0[r] = s0[r] * P.qk_scale + neg_m;                                                      \
+                        s1[r] = s1[r] * P.qk_scale + neg_m;                                                      \
                     }                                                                                            \
                 } else if (SLOW) {                                                                               \
                     if (blk >= P.text_block_start) {                                                             \
@@ -250,16 +269,26 @@ __device__ __forceinline__ void attn_block(const AttnParams& P, unsigned char* s
                         }                                                                                        \
                     }                                                                                            \
                 }                                                                                                \
-                if (pre) { /* first tile of the row block, or the careful re-run after an exp2 overflow */       \
-                    float tmax = fmaxf(s0[0], s1[0]);                                                            \
+                if (!TEXT && !JENGA_SM_CNEG) {                                                                   \
+                    _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                             \
+                        s0[r] += neg_m;                                                                          \
+                        s1[r] += neg_m;                                                                          \
+                    }                                                                                            \
+                }                                                                                                \
+                if (pre) { /* first tile of the row block */                                                     \
+                    float tmax = fmaxf(s0[0], s1[0]);   /* scores are already relative to m~ */                  \
                     _Pragma("unroll") for (int r = 1; r < 16; ++r) tmax = fmaxf(tmax, fmaxf(s0[r], s1[r]));      \
-                    tmax += neg_m;                                                                               \
                     tmax = fmaxf(tmax, __shfl_xor(tmax, 32));                                                    \
                     const bool go_ = first ? (tmax > -1e20f) : (tmax > LAZY_THR);                                \
                     const float delta = go_ ? ceilf(tmax) : 0.f;                                                 \
                     const float f2 = __builtin_amdgcn_exp2f(-delta);                                             \
                     neg_m -= delta;                                                                              \
                     l_i *= f2;                                                                                   \
+                    _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                             \
+                        s0[r] -= delta;                                                                          \
+                        s1[r] -= delta;                                                                          \
+                        cneg[r] = neg_m;                                                                         \
+                    }                                                                                            \
                     _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                \
                         _Pragma("unroll") for (int r = 0; r < 16; ++r) oacc[i][r] *= f2;                         \
                     first = false;                                                                               \
@@ -267,22 +296,11 @@ __device__ __forceinline__ void attn_block(const AttnParams& P, unsigned char* s
                 /* hot path: P = exp2(S - m~) and its row sum with packed adds, no row max.  P goes to its own   \
                    registers so that the raw scores survive until the check below. */                            \
                 f32x16 p0, p1;                                                                                   \
-                {                                                                                                \
-                    const f32x2 nm2 = {neg_m, neg_m};                                                            \
-                    f32x2 ps2 = {0.f, 0.f};                                                                      \
-                    _Pragma("unroll") for (int r = 0; r < 16; r += 2) {                                          \
-                        f32x2 a0 = {s0[r], s0[r + 1]}, a1 = {s1[r], s1[r + 1]};                                  \
-                        a0 += nm2;                                                                               \
-                        a1 += nm2;                                                                               \
-                        a0.x = __builtin_amdgcn_exp2f(a0.x);                                                     \
-                        a0.y = __builtin_amdgcn_exp2f(a0.y);                                                     \
-                        a1.x = __builtin_amdgcn_exp2f(a1.x);                                                     \
-                        a1.y = __builtin_amdgcn_exp2f(a1.y);                                                     \
-                        p0[r] = a0.x; p0[r + 1] = a0.y; p1[r] = a1.x; p1[r + 1] = a1.y;                          \
-                        ps2 += a0;                                                                               \
-                        ps2 += a1;                                                                               \
-                    }                                                                                            \
-                    psum = ps2.x + ps2.y;                                                                        \
+                psum = 0.f;                                                                                      \
+                _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                                 \
+                    p0[r] = __builtin_amdgcn_exp2f(s0[r]);   /* v_exp_f32 hides under the partner's MFMAs */     \
+                    p1[r] = __builtin_amdgcn_exp2f(s1[r]);                                                       \
+                    psum += p0[r] + p1[r];                   /* the only FP-pipe work left on the hot path */    \
                 }                                                                                                \
                 /* rare: any P > 2^THR implies a row sum > 2^THR (and an overflowed exp2 gives inf): raise m~ by  \
                    an integer step from the row max of the intact scores, then exponentiate again.  Exact; the   \
@@ -290,18 +308,18 @@ __device__ __forceinline__ void attn_block(const AttnParams& P, unsigned char* s
                 if (!pre && __any(!(psum <= RAISE_SUM))) {                                                       \
                     float tmax = fmaxf(s0[0], s1[0]);                                                            \
                     _Pragma("unroll") for (int r = 1; r < 16; ++r) tmax = fmaxf(tmax, fmaxf(s0[r], s1[r]));      \
-                    tmax += neg_m;                                                                               \
                     tmax = fmaxf(tmax, __shfl_xor(tmax, 32));                                                    \
                     const float delta = (tmax > LAZY_THR) ? ceilf(tmax) : 0.f;                                   \
                     const float f2 = __builtin_amdgcn_exp2f(-delta);                                             \
                     neg_m -= delta;                                                                              \
                     l_i *= f2;                                                                                   \
+                    _Pragma("unroll") for (int r = 0; r < 16; ++r) cneg[r] = neg_m;                              \
                     _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                \
                         _Pragma("unroll") for (int r = 0; r < 16; ++r) oacc[i][r] *= f2;                         \
                     psum = 0.f;                                                                                  \
                     _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                             \
-                        p0[r] = __builtin_amdgcn_exp2f(s0[r] + neg_m);                                           \
-                        p1[r] = __builtin_amdgcn_exp2f(s1[r] + neg_m);                                           \
+                        p0[r] = __builtin_amdgcn_exp2f(s0[r] - delta);                                           \
+                        p1[r] = __builtin_amdgcn_exp2f(s1[r] - delta);                                           \
                         psum += p0[r] + p1[r];                                                                   \
                     }                                                                                            \
                 }                                                                                                \
@@ -311,14 +329,14 @@ __device__ __forceinline__ void attn_block(const AttnParams& P, unsigned char* s
             l_i += psum;                                                                                         \
             /* P -> 16-bit operands: k-step ks = 2g + s uses C registers 8s..8s+7 of group g */                  \
             uint4 pf[4];                                                                                         \
-            pf[0] = make_uint4(pack2<T>(s0[0], s0[1]), pack2<T>(s0[2], s0[3]), pack2<T>(s0[4], s0[5]),           \
-                               pack2<T>(s0[6], s0[7]));                                                          \
-            pf[1] = make_uint4(pack2<T>(s0[8], s0[9]), pack2<T>(s0[10], s0[11]), pack2<T>(s0[12], s0[13]),       \
-                               pack2<T>(s0[14], s0[15]));                                                        \
-            pf[2] = make_uint4(pack2<T>(s1[0], s1[1]), pack2<T>(s1[2], s1[3]), pack2<T>(s1[4], s1[5]),           \
-                               pack2<T>(s1[6], s1[7]));                                                          \
-            pf[3] = make_uint4(pack2<T>(s1[8], s1[9]), pack2<T>(s1[10], s1[11]), pack2<T>(s1[12], s1[13]),       \
-                               pack2<T>(s1[14], s1[15]));                                                        \
+            pf[0] = make_uint4(PACKP<T>(s0[0], s0[1]), PACKP<T>(s0[2], s0[3]), PACKP<T>(s0[4], s0[5]),           \
+                               PACKP<T>(s0[6], s0[7]));                                                          \
+            pf[1] = make_uint4(PACKP<T>(s0[8], s0[9]), PACKP<T>(s0[10], s0[11]), PACKP<T>(s0[12], s0[13]),       \
+                               PACKP<T>(s0[14], s0[15]));                                                        \
+            pf[2] = make_uint4(PACKP<T>(s1[0], s1[1]), PACKP<T>(s1[2], s1[3]), PACKP<T>(s1[4], s1[5]),           \
+                               PACKP<T>(s1[6], s1[7]));                                                          \
+            pf[3] = make_uint4(PACKP<T>(s1[8], s1[9]), PACKP<T>(s1[10], s1[11]), PACKP<T>(s1[12], s1[13]),       \
+                               PACKP<T>(s1[14], s1[15]));                                                        \
             /* O^T += V^T P^T: four independent accumulator chains per k-step */                                 \
             {                                                                                                    \
                 uint4 va[4][4];                                                                                  \

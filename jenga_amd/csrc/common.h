@@ -41,6 +41,19 @@ template <> __device__ __forceinline__ uint32_t pack2<FP16>(float lo, float hi) 
     const f32x2 v = {lo, hi};
     return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, f16x2));
 }
+// Same packing with INTEGER instructions only (round-to-nearest-even add, then a byte permute).  On gfx950 the FP
+// add/mul/convert datapath is shared with the MFMA pipe of the SIMD (a v_cvt_pk_bf16_f32 of one wave is not hidden
+// under the partner wave's MFMAs), integer ALU ops are -- see tools/micro/valu_cost.hip.  Inputs must be finite
+// and non-negative-or-any-sign normal values (no NaN handling): used for softmax probabilities only.
+template <typename T> __device__ __forceinline__ uint32_t pack2_int(float lo, float hi);
+template <> __device__ __forceinline__ uint32_t pack2_int<BF16>(float lo, float hi) {
+    const uint32_t ul = __float_as_uint(lo), uh = __float_as_uint(hi);
+    const uint32_t rl = ul + 0x7FFFu + ((ul >> 16) & 1u);
+    const uint32_t rh = uh + 0x7FFFu + ((uh >> 16) & 1u);
+    return __builtin_amdgcn_perm(rh, rl, 0x07060302u);   // bytes {rl[2], rl[3], rh[2], rh[3]}
+}
+template <> __device__ __forceinline__ uint32_t pack2_int<FP16>(float lo, float hi) { return pack2<FP16>(lo, hi); }
+
 template <typename T> __device__ __forceinline__ float round_to(float f) { return to_f32<T>(from_f32<T>(f)); }
 
 template <typename T> __device__ __forceinline__ void unpack8(const uint4& v, float (&f)[8]) {
