@@ -113,7 +113,8 @@ __device__ __forceinline__ void stage_tile(const void* kbase, const void* vbase,
 // on a gfx950 SIMD the FP add/mul/convert ops of one wave are NOT hidden under the partner wave's MFMAs while v_mov,
 // integer ops, v_max, v_ldexp and (75 %) v_exp are -- but trading 32 FP subtracts for 32 register copies (CNEG: 997
 // TFLOP/s) or 16 v_cvt_pk for 80 integer ops (INTPACK: 967) lengthens the wave's own serial stream by more than it
-// frees on the shared pipe (baseline 1049).
+// frees on the shared pipe (baseline 1049); starting the chains with an inline-asm MFMA whose C is untied (CNEG=2: no
+// copies, no subtracts) is correct too but `asm volatile` pins the schedule and spills: 647.
 #ifndef JENGA_SM_CNEG
 #define JENGA_SM_CNEG 0      // 1: -m~ rides in the MFMA C operand; 0: subtracted with FP adds after the MFMAs
 #endif
@@ -234,19 +235,33 @@ __device__ __forceinline__ void attn_block(const AttnParams& P, unsigned char* s
                         ka[ds] = *reinterpret_cast<const uint4*>(cur + k_addr[ds]);                              \
                         kb[ds] = *reinterpret_cast<const uint4*>(cur + k_addr[ds] + 8192);                       \
                     }                                                                                            \
-                    s0 = mfma32<T>(ka[0], qf[0], (TEXT || !JENGA_SM_CNEG) ? zero16 : cneg);                     \
-                    s1 = mfma32<T>(kb[0], qf[0], (TEXT || !JENGA_SM_CNEG) ? zero16 : cneg);                     \
+                    if (!TEXT && JENGA_SM_CNEG == 2) { /* untied C: scores arrive as S - m~, no copies */       \
+                        s0 = mfma32_untied<T>(ka[0], qf[0], cneg);                                               \
+                        s1 = mfma32_untied<T>(kb[0], qf[0], cneg);                                               \
+                    } else {                                                                                     \
+                        s0 = mfma32<T>(ka[0], qf[0], (TEXT || !JENGA_SM_CNEG) ? zero16 : cneg);                 \
+                        s1 = mfma32<T>(kb[0], qf[0], (TEXT || !JENGA_SM_CNEG) ? zero16 : cneg);                 \
+                    }                                                                                            \
                     _Pragma("unroll") for (int ds = 1; ds < 8; ++ds) {                                           \
                         s0 = mfma32<T>(ka[ds], qf[ds], s0);                                                      \
                         s1 = mfma32<T>(kb[ds], qf[ds], s1);                                                      \
                     }                                                                                            \
                     /* issue order: LDS reads run 3 k-steps (6 reads) ahead of the MFMAs that consume them */    \
-                    __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);                                           \
-                    _Pragma("unroll") for (int g_ = 0; g_ < 5; ++g_) {                                           \
-                        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                                       \
-                        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);                                       \
+                    if (!TEXT && JENGA_SM_CNEG == 2) { /* the two asm MFMAs are invisible to the group masks */  \
+                        __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);                                       \
+                        _Pragma("unroll") for (int g_ = 0; g_ < 4; ++g_) {                                       \
+                            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                                   \
+                            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);                                   \
+                        }                                                                                        \
+                        __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);                                       \
+                    } else {                                                                                     \
+                        __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);                                       \
+                        _Pragma("unroll") for (int g_ = 0; g_ < 5; ++g_) {                                       \
+                            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                                   \
+                            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);                                   \
+                        }                                                                                        \
+                        __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);                                       \
                     }                                                                                            \
-                    __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);                                           \
                     MFMA_PRIO(0);                                                                                \
                 }                                                                                                \
                 if (TEXT) {                                                                                      \

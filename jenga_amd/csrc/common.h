@@ -85,6 +85,25 @@ template <> __device__ __forceinline__ f32x16 mfma32<FP16>(const uint4& a, const
                                                   0);
 }
 
+// MFMA whose accumulator input C is a DIFFERENT register block than its result D (hipcc always ties D to C for the
+// builtin and would copy a loop-invariant C into D with 16 v_mov first).  Used to start the K.Q^T chains from the
+// -m~ splat at no VALU cost.  "=&v": D must not partially overlap C.  The result is only read by the next MFMA of the
+// chain as its (tied) C operand, which needs no wait states (accumulate forwarding).
+template <typename T> __device__ __forceinline__ f32x16 mfma32_untied(const uint4& a, const uint4& b, const f32x16& c);
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+template <> __device__ __forceinline__ f32x16 mfma32_untied<BF16>(const uint4& a, const uint4& b, const f32x16& c) {
+    f32x16 d;
+    const i32x4 av = __builtin_bit_cast(i32x4, a), bv = __builtin_bit_cast(i32x4, b);
+    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %3" : "=&v"(d) : "v"(av), "v"(bv), "v"(c));
+    return d;
+}
+template <> __device__ __forceinline__ f32x16 mfma32_untied<FP16>(const uint4& a, const uint4& b, const f32x16& c) {
+    f32x16 d;
+    const i32x4 av = __builtin_bit_cast(i32x4, a), bv = __builtin_bit_cast(i32x4, b);
+    asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %3" : "=&v"(d) : "v"(av), "v"(bv), "v"(c));
+    return d;
+}
+
 // Key order inside a 32-key group as the P.V product consumes it: position p = hi*16 + s*8 + j  <->  key
 // crow(8*s + j, hi) with crow(r, hi) = (r&3) + 8*(r>>2) + 4*hi  (the row a lane holds in MFMA C-register r).
 __host__ __device__ __forceinline__ int pv_key_of_pos(int p) {
