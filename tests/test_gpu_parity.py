@@ -440,3 +440,84 @@ def test_fused_elementwise_vs_eager_chain(dev):
     want = F.gelu(src, approximate="tanh")
     assert_ulp_close(to_np(cat[..., C:]), to_np(want), "bfloat16", max_frac=2e-3, max_ulps=1)
     assert torch.count_nonzero(cat[..., :C]) == 0
+
+
+# ----------------------------------------------------------------------------------------------- full size (config 2)
+def test_full_size_properties_and_sampled_rows(dev):
+    """HunyuanVideo 720x1280x125f shape (S = 115200 + 256, real 32x45x80 curve neighbours), 2 heads to keep it quick:
+    (a) V == 1  ->  every output element is 1 (softmax weights sum to one through selection, kept lists, lazy max,
+        both 64-key halves and the dense text rows);
+    (b) kept lists are ascending, unique, contain the neighbours, the text blocks and at least top_k image blocks;
+    (c) sampled (head, query block) rows against the oracle evaluated on exactly those rows' kept blocks."""
+    from jenga_amd import _capi, gilbert as G
+    from jenga_amd.modules import attention_block_sparse as op
+    from oracle import attention as oa
+    t, h, w = 32, 45, 80
+    S_img, tb, H = t * h * w, 2, 2
+    nimg, nb = S_img // 128, S_img // 128 + tb
+    S = nb * 128
+    nbm = G.gilbert_block_neighbor_mapping(t, h, w, as_tensor=True)
+    g = torch.Generator(device=dev).manual_seed(77)
+    cent = torch.randn(1, nb, 1, H, 128, generator=g, device=dev) * 0.9          # clustered block means: peaky rows
+    q = (torch.randn(1, nb, 128, H, 128, generator=g, device=dev) + cent[:, torch.randint(0, nimg, (nb,), device=dev)])
+    k = (torch.randn(1, nb, 128, H, 128, generator=g, device=dev) + cent)
+    q = q.to(torch.bfloat16).view(1, S, H, 128)
+    k = k.to(torch.bfloat16).view(1, S, H, 128)
+    top_k = int((1 - 0.75) * nimg)
+    seqlens = torch.tensor([S], dtype=torch.int32, device=dev)
+    # (a) rows of a softmax sum to one
+    ones = torch.ones(1, S, H, 128, device=dev, dtype=torch.bfloat16)
+    vt1 = _capi.pack_v(ones, nb)
+    o1, idx, cnt = op.attencarve_packed(q, k, vt1, top_k, seqlens, tb, 0.2, 0.3, nbm, return_lists=True)
+    assert torch.all((o1.float() - 1).abs() <= 2 ** -7), (o1.float() - 1).abs().max().item()
+    # (b) list invariants
+    idx_c, cnt_c, nbm_c = idx.cpu(), cnt.cpu(), nbm.cpu()
+    assert int(cnt_c.min()) >= top_k + tb
+    for hh in range(H):
+        for m in (0, 1, 449, 898, 899):
+            n = int(cnt_c[0, hh, m])
+            row = idx_c[0, hh, m, :n]
+            assert torch.all(row[1:] > row[:-1]) and row[-2] == nimg and row[-1] == nimg + 1
+            kept = set(row.tolist())
+            assert set(torch.nonzero(nbm_c[m]).flatten().tolist()) <= kept
+    # (c) sampled rows vs the oracle on their own kept blocks
+    v = torch.randn(1, S, H, 128, generator=g, device=dev).to(torch.bfloat16)
+    vt = _capi.pack_v(v, nb)
+    o = op.attencarve_packed(q, k, vt, top_k, seqlens, tb, 0.2, 0.3, nbm)
+    for (hh, m) in [(0, 0), (1, 449), (0, 899), (1, 77)]:
+        n = int(cnt_c[0, hh, m])
+        blocks = idx_c[0, hh, m, :n].tolist()
+        rows = slice(m * 128, (m + 1) * 128)
+        kk = torch.cat([k[0, b * 128:(b + 1) * 128, hh] for b in blocks]).float().cpu().numpy()[None, None]
+        vv = torch.cat([v[0, b * 128:(b + 1) * 128, hh] for b in blocks]).float().cpu().numpy()[None, None]
+        qq = q[0, rows, hh].float().cpu().numpy()[None, None]
+        mask = np.ones((1, 1, 1, n), bool)
+        ref = oa.sparse_rows(qq, kk, vv, [n * 128], mask, 128 ** -0.5, "bfloat16", text_amp=0.2, text_block_start=n - tb)
+        got = o[0, rows, hh].float().cpu().numpy()
+        assert np.abs(got - ref[0, 0]).max() <= 2e-2, (hh, m, np.abs(got - ref[0, 0]).max())
+    # text query rows: dense over everything (flash_attn semantics), one head
+    ref_t = oa.text_rows(q[:, S_img:, 0:1].transpose(1, 2).float().cpu().numpy(), k[:, :, 0:1].transpose(1, 2).float().cpu().numpy(),
+                         v[:, :, 0:1].transpose(1, 2).float().cpu().numpy(), 128 ** -0.5, "bfloat16")
+    got_t = o[0, S_img:, 0].float().cpu().numpy()
+    assert np.abs(got_t - ref_t[0, 0]).max() <= 2e-2
+
+
+def test_full_size_gather_scatter_and_norm_rope_roundtrip(dev):
+    """Config-2 sizes: scatter(gather(x)) == x on [1,115200,3072]; RoPE is a rotation: per-pair norms are preserved and
+    applying the table built from (-angle) undoes it up to bf16 rounding."""
+    from jenga_amd import _capi, gilbert as G
+    from jenga_amd.modules.posemb_layers import get_nd_rotary_pos_embed
+    t, h, w = 32, 45, 80
+    l2h, h2l = G.gilbert_mapping(t, h, w, as_tensor=True)
+    x = torch.randn(1, t * h * w, 3072, device=dev).to(torch.bfloat16)
+    y = _capi.gather_rows(x, h2l)
+    assert torch.equal(_capi.gather_rows(y, l2h), x) and not torch.equal(y, x)
+    cos, sin = get_nd_rotary_pos_embed([16, 56, 56], [t, h, w], theta=256, use_real=True, theta_rescale_factor=1)
+    cos, sin = cos.to(dev), sin.to(dev)
+    qh = x.view(1, t * h * w, 24, 128)
+    r = _capi.rmsnorm_rope(qh, None, cos, sin, eps=-1.0)
+    back = _capi.rmsnorm_rope(r, None, cos, -sin, eps=-1.0)
+    assert (back.float() - qh.float()).abs().max().item() <= 0.07          # two bf16 roundings at |x| <= ~5
+    n0 = qh.float().view(-1, 64, 2).norm(dim=-1)
+    n1 = r.float().view(-1, 64, 2).norm(dim=-1)
+    assert (n0 - n1).abs().max().item() <= 0.05
