@@ -40,6 +40,7 @@ def main():
     ap.add_argument("--attn-only", action="store_true")
     ap.add_argument("--l2-resident", type=int, default=0,
                     help="N>0: every query block reads the same N kv blocks repeatedly (same pair count): isolates MFMA/LDS work from L2-miss fill traffic")
+    ap.add_argument("--k-head-major", action="store_true", help="K (and Q) stored [B,H,S,D]: contiguous 16 KiB K tiles")
     ap.add_argument("--flags", type=int, default=None, help="jenga_bsattn_fwd flags (1 = XCD remap, 2 = ping-pong)")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
@@ -81,6 +82,9 @@ def main():
         n = int(cnt.float().mean().item())
         idx = (torch.arange(nb, device=dev, dtype=torch.int32) % a.l2_resident).expand(1, H, nimg, nb).contiguous()
         cnt = torch.full_like(cnt, n)
+    if a.k_head_major:
+        k = k.permute(0, 2, 1, 3).contiguous().permute(0, 2, 1, 3)
+        q = q.permute(0, 2, 1, 3).contiguous().permute(0, 2, 1, 3)
     kept = int(cnt.sum().item())
     pairs = kept + H * tb * nb
     flops = 4 * 128 ** 3 * pairs
