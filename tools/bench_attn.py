@@ -40,6 +40,8 @@ def main():
     ap.add_argument("--attn-only", action="store_true")
     ap.add_argument("--l2-resident", type=int, default=0,
                     help="N>0: every query block reads the same N kv blocks repeatedly (same pair count): isolates MFMA/LDS work from L2-miss fill traffic")
+    ap.add_argument("--window", type=int, default=0,
+                    help="experiment: every query block keeps a random 31.6 %% of the kv blocks [0, WINDOW) only")
     ap.add_argument("--k-head-major", action="store_true", help="K (and Q) stored [B,H,S,D]: contiguous 16 KiB K tiles")
     ap.add_argument("--flags", type=int, default=None, help="jenga_bsattn_fwd flags (1 = XCD remap, 2 = ping-pong)")
     a = ap.parse_args()
@@ -81,6 +83,13 @@ def main():
     if a.l2_resident:
         n = int(cnt.float().mean().item())
         idx = (torch.arange(nb, device=dev, dtype=torch.int32) % a.l2_resident).expand(1, H, nimg, nb).contiguous()
+        cnt = torch.full_like(cnt, n)
+    if a.window:
+        n = max(1, int(0.316 * a.window))
+        r = torch.rand(1, H, nimg, a.window, device=dev)
+        sel = r.topk(n, dim=-1).indices.sort(dim=-1).values.to(torch.int32)
+        idx = torch.zeros(1, H, nimg, nb, dtype=torch.int32, device=dev)
+        idx[..., :n] = sel
         cnt = torch.full_like(cnt, n)
     if a.k_head_major:
         k = k.permute(0, 2, 1, 3).contiguous().permute(0, 2, 1, 3)
