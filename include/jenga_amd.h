@@ -100,6 +100,21 @@ int jenga_gate_residual(void* stream, const void* res, const void* y, const void
 int jenga_gelu_tanh(void* stream, const void* x, void* out, int64_t rows, int64_t C, int64_t x_row_stride,
                     int64_t o_row_stride, int dtype);
 
+/* Wan2.1 flavour of the same glue (wan/modules/model_mul.py:323-343): the residual stream x is fp32 (x + y*e is
+ * evaluated under autocast(float32)), the inputs of the q/k/v, cross-attention and ffn GEMMs are its LayerNorm rounded
+ * to the 16-bit dtype by autocast.
+ * jenga_wan_ln_modulate: y = cast( LN(x) [*weight + bias] [*(1 + scale) + shift] )  -- norm1/norm2 with the (shift,
+ *   scale) rows of `self.modulation + e` (:331-333, :339), norm3 with its affine (weight, bias) and no modulation
+ *   (:338); all vectors fp32 [C]; either pair may be NULL; C % 4 == 0, C <= 6144.  round_ln != 0 rounds the
+ *   LayerNorm result to the 16-bit dtype before the modulation: WanLayerNorm returns `.type_as(x)` (:99-104) and the
+ *   first block receives the 16-bit patch embedding.
+ * jenga_wan_gate_residual: out = x + float(y) [* gate]  (:334-335, :338, :340-341); out may alias x. */
+int jenga_wan_ln_modulate(void* stream, const float* x, void* y, const float* weight, const float* bias,
+                          const float* shift, const float* scale, int64_t rows, int64_t C, int64_t x_row_stride,
+                          int64_t y_row_stride, float eps, int out_dtype, int round_ln);
+int jenga_wan_gate_residual(void* stream, const float* x, const void* y, const float* gate, float* out, int64_t rows,
+                            int64_t C, int64_t x_row_stride, int64_t y_row_stride, int64_t o_row_stride, int y_dtype);
+
 /* ---------------------------------------------------------------------------------------------------
  * Block selection.  Replaces _build_block_index_with_importance_optimized
  * (hyvideo/modules/attention_block_triton_diffres.py:198-295; Wan first_frame_blocks rule

@@ -29,6 +29,8 @@ SIGNATURES = {
     "jenga_ln_modulate": (_i32, [_vp] * 8 + [_i64] * 4 + [_f32, _i32]),
     "jenga_gate_residual": (_i32, [_vp] * 7 + [_i64] * 5 + [_i32]),
     "jenga_gelu_tanh": (_i32, [_vp, _vp, _vp] + [_i64] * 4 + [_i32]),
+    "jenga_wan_ln_modulate": (_i32, [_vp] * 7 + [_i64] * 4 + [_f32, _i32, _i32]),
+    "jenga_wan_gate_residual": (_i32, [_vp] * 5 + [_i64] * 5 + [_i32]),
     "jenga_block_pool": (_i32, [_vp, _vp, _vp] + [_i64] * 6 + [_i32]),
     "jenga_block_select": (_i32, [_vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp] + [_i64] * 6 + [_f32, _i64, _i32]),
     "jenga_pack_v_bytes": (ctypes.c_size_t, [_i64, _i64, _i64]),
@@ -272,6 +274,41 @@ def gelu_tanh(x, out=None):
     with torch.cuda.device(x.device):
         _check(lib().jenga_gelu_tanh(_stream(x.device), _p(x2), _p(o2), rows, C, xrs, ors, dtype_code(x.dtype)),
                "jenga_gelu_tanh")
+    return out
+
+
+def wan_ln_modulate(x, weight=None, bias=None, shift=None, scale=None, eps=1e-6, out_dtype=torch.bfloat16,
+                    round_ln=False):
+    """Wan block glue: x fp32 [1,S,C] -> out_dtype( LN(x) [*weight+bias] [*(1+scale)+shift] ), vectors fp32 [C]."""
+    _need_gpu(x, "wan_ln_modulate")
+    if x.dtype != torch.float32:
+        raise ValueError("wan_ln_modulate: the Wan residual stream is float32")
+    x2, rows, C, xrs = _rows2d(x)
+    out = torch.empty(x.shape, dtype=out_dtype, device=x.device)
+    o2, _, _, ors = _rows2d(out)
+    v = lambda t: None if t is None else t.reshape(-1).to(dtype=torch.float32).contiguous()
+    w, b, sh, sc = v(weight), v(bias), v(shift), v(scale)
+    with torch.cuda.device(x.device):
+        _check(lib().jenga_wan_ln_modulate(_stream(x.device), _p(x2), _p(o2), _p(w), _p(b), _p(sh), _p(sc), rows, C,
+                                           xrs, ors, float(eps), dtype_code(out_dtype), int(bool(round_ln))),
+               "jenga_wan_ln_modulate")
+    return out
+
+
+def wan_gate_residual(x, y, gate=None, out=None):
+    """x fp32 + float(y) [* gate] -> fp32; out=x updates the residual stream in place."""
+    _need_gpu(x, "wan_gate_residual")
+    if x.dtype != torch.float32:
+        raise ValueError("wan_gate_residual: the Wan residual stream is float32")
+    x2, rows, C, xrs = _rows2d(x)
+    y2, _, _, yrs = _rows2d(y)
+    if out is None:
+        out = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+    o2, _, _, ors = _rows2d(out)
+    g = None if gate is None else gate.reshape(-1).to(dtype=torch.float32).contiguous()
+    with torch.cuda.device(x.device):
+        _check(lib().jenga_wan_gate_residual(_stream(x.device), _p(x2), _p(y2), _p(g), _p(o2), rows, C, xrs, yrs, ors,
+                                             dtype_code(y.dtype)), "jenga_wan_gate_residual")
     return out
 
 

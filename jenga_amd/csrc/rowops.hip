@@ -168,6 +168,96 @@ inline int grid_for(long long work_items, int cap = 16384) {
     return (int)(work_items > cap ? cap : work_items);
 }
 
+// ---- Wan flavour of the block glue: the residual stream is fp32 (x + y*e under autocast(float32),
+//      wan/modules/model_mul.py:331-343), the GEMM inputs are its LayerNorm rounded to the 16-bit dtype by autocast.
+// y = cast( LN(x) [*w + b] [*(1 + scale) + shift] ); all arithmetic fp32 in the eager order (no contraction).
+template <typename T>
+__global__ void __launch_bounds__(256) wan_ln_modulate_kernel(const float* __restrict__ x, uint16_t* __restrict__ y,
+                                                              const float* __restrict__ w,
+                                                              const float* __restrict__ b,
+                                                              const float* __restrict__ shift,
+                                                              const float* __restrict__ scale, long long rows, int C,
+                                                              long long x_rs, long long y_rs, float eps, int round_ln) {
+    __shared__ float red[2][4];
+    for (long long row = blockIdx.x; row < rows; row += gridDim.x) {
+        const float* xr = x + row * x_rs;
+        float f[6][4];   // up to 6144 channels: 256 threads x 4 floats x 6
+        float s1 = 0.f;
+#pragma unroll
+        for (int nv = 0; nv < 6; ++nv) {
+            const int c = threadIdx.x * 4 + nv * 1024;
+            if (c >= C) break;
+            const float4 v = *reinterpret_cast<const float4*>(xr + c);
+            f[nv][0] = v.x; f[nv][1] = v.y; f[nv][2] = v.z; f[nv][3] = v.w;
+            s1 += (v.x + v.y) + (v.z + v.w);
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) s1 += __shfl_xor(s1, o);
+        if ((threadIdx.x & 63) == 0) red[0][threadIdx.x >> 6] = s1;
+        __syncthreads();
+        const float mean = ((red[0][0] + red[0][1]) + (red[0][2] + red[0][3])) / (float)C;
+        float s2 = 0.f;   // two-pass variance: the residual stream grows over 40 layers, E[x^2]-mean^2 would cancel
+#pragma unroll
+        for (int nv = 0; nv < 6; ++nv) {
+            const int c = threadIdx.x * 4 + nv * 1024;
+            if (c >= C) break;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float d = f[nv][e] - mean;
+                s2 += d * d;
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) s2 += __shfl_xor(s2, o);
+        if ((threadIdx.x & 63) == 0) red[1][threadIdx.x >> 6] = s2;
+        __syncthreads();
+        const float var = ((red[1][0] + red[1][1]) + (red[1][2] + red[1][3])) / (float)C;
+        const float rstd = 1.0f / sqrtf(var + eps);
+        __syncthreads();
+#pragma unroll
+        for (int nv = 0; nv < 6; ++nv) {
+            const int c = threadIdx.x * 4 + nv * 1024;
+            if (c >= C) break;
+            float o[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float t = (f[nv][e] - mean) * rstd;
+                if (w) t = t * w[c + e] + b[c + e];
+                if (round_ln) t = round_to<T>(t);   // LayerNorm(...).type_as(x) of a 16-bit x (first block)
+                if (scale) t = t * (1.0f + scale[c + e]) + shift[c + e];
+                o[e] = t;
+            }
+            uint2 pk;
+            pk.x = pack2<T>(o[0], o[1]);
+            pk.y = pack2<T>(o[2], o[3]);
+            *reinterpret_cast<uint2*>(y + row * y_rs + c) = pk;
+        }
+    }
+}
+
+// out = x + float(y) [* gate]   (x, out fp32; y 16-bit; gate fp32 [C] or null)
+template <typename T>
+__global__ void wan_gate_residual_kernel(const float* x, const uint16_t* __restrict__ y,
+                                         const float* __restrict__ gate, float* out, long long rows,
+                                         int C, long long x_rs, long long y_rs, long long o_rs) {
+    const int vpr = C / 8;
+    const long long total = rows * vpr;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const long long row = i / vpr;
+        const int c = (int)(i % vpr) * 8;
+        float yv[8];
+        unpack8<T>(*reinterpret_cast<const uint4*>(y + row * y_rs + c), yv);
+        const float4 a0 = *reinterpret_cast<const float4*>(x + row * x_rs + c);
+        const float4 a1 = *reinterpret_cast<const float4*>(x + row * x_rs + c + 4);
+        float a[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+#pragma unroll
+        for (int e = 0; e < 8; ++e) a[e] = a[e] + (gate ? yv[e] * gate[c + e] : yv[e]);
+        *reinterpret_cast<float4*>(out + row * o_rs + c) = make_float4(a[0], a[1], a[2], a[3]);
+        *reinterpret_cast<float4*>(out + row * o_rs + c + 4) = make_float4(a[4], a[5], a[6], a[7]);
+    }
+}
+
 }  // namespace
 }  // namespace jenga
 
@@ -638,5 +728,53 @@ extern "C" int jenga_gelu_tanh(void* stream, const void* x, void* out, int64_t r
         hipLaunchKernelGGL(gelu_tanh_kernel<FP16>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)x,
                            (uint16_t*)out, (long long)rows, (int)C, (long long)x_row_stride, (long long)o_row_stride);
     JENGA_CHECK_LAUNCH("jenga_gelu_tanh");
+    return JENGA_OK;
+}
+
+extern "C" int jenga_wan_ln_modulate(void* stream, const float* x, void* y, const float* weight, const float* bias,
+                                     const float* shift, const float* scale, int64_t rows, int64_t C,
+                                     int64_t x_row_stride, int64_t y_row_stride, float eps, int out_dtype,
+                                     int round_ln) {
+    if (!x || !y || rows < 0 || C <= 0 || (C & 3) || C > 6144 || (x_row_stride & 3) || (y_row_stride & 3) ||
+        (!weight != !bias) || (!shift != !scale)) {
+        set_error("jenga_wan_ln_modulate: bad arguments (C must be a multiple of 4 and <= 6144)");
+        return JENGA_EINVAL;
+    }
+    if (out_dtype != JENGA_BF16 && out_dtype != JENGA_FP16) {
+        set_error("jenga_wan_ln_modulate: out dtype must be bf16 or fp16");
+        return JENGA_EUNSUPPORTED;
+    }
+    if (rows == 0) return JENGA_OK;
+#define LAUNCH_WLM(T)                                                                                             \
+    hipLaunchKernelGGL(wan_ln_modulate_kernel<T>, dim3(grid_for(rows, 65536)), dim3(256), 0, (hipStream_t)stream, \
+                       x, (uint16_t*)y, weight, bias, shift, scale, (long long)rows, (int)C,                      \
+                       (long long)x_row_stride, (long long)y_row_stride, eps, round_ln)
+    if (out_dtype == JENGA_BF16) LAUNCH_WLM(BF16); else LAUNCH_WLM(FP16);
+#undef LAUNCH_WLM
+    JENGA_CHECK_LAUNCH("jenga_wan_ln_modulate");
+    return JENGA_OK;
+}
+
+extern "C" int jenga_wan_gate_residual(void* stream, const float* x, const void* y, const float* gate, float* out,
+                                       int64_t rows, int64_t C, int64_t x_row_stride, int64_t y_row_stride,
+                                       int64_t o_row_stride, int y_dtype) {
+    if (!x || !y || !out || rows < 0 || C <= 0 || (C & 7) || (x_row_stride & 3) || (y_row_stride & 7) ||
+        (o_row_stride & 3)) {
+        set_error("jenga_wan_gate_residual: bad arguments");
+        return JENGA_EINVAL;
+    }
+    if (y_dtype != JENGA_BF16 && y_dtype != JENGA_FP16) {
+        set_error("jenga_wan_gate_residual: y dtype must be bf16 or fp16");
+        return JENGA_EUNSUPPORTED;
+    }
+    if (rows == 0) return JENGA_OK;
+    const int grid = grid_for((rows * (C / 8) + 255) / 256, 32768);
+#define LAUNCH_WGR(T)                                                                                             \
+    hipLaunchKernelGGL(wan_gate_residual_kernel<T>, dim3(grid), dim3(256), 0, (hipStream_t)stream, x,             \
+                       (const uint16_t*)y, gate, out, (long long)rows, (int)C, (long long)x_row_stride,            \
+                       (long long)y_row_stride, (long long)o_row_stride)
+    if (y_dtype == JENGA_BF16) LAUNCH_WGR(BF16); else LAUNCH_WGR(FP16);
+#undef LAUNCH_WGR
+    JENGA_CHECK_LAUNCH("jenga_wan_gate_residual");
     return JENGA_OK;
 }

@@ -75,15 +75,17 @@ class TeaCache:
 
 
 @torch.no_grad()
-def teacache_forward(tokens, e, e0, blocks, tea, hilbert_order, linear_to_hilbert, seq_len=None, **block_kwargs):
-    """tokens [B, L, C] patch embeddings (L = f*h*w); pads to seq_len, gathers into curve order, runs the blocks or adds
+def teacache_forward(tokens, t_emb, t_emb0, blocks, tea, hilbert_order, linear_to_hilbert, seq_len=None,
+                     **block_kwargs):
+    """tokens [B, L, C] patch embeddings (L = f*h*w), t_emb [B, dim] / t_emb0 [B, 6, dim] the time embeddings the skip
+    decision looks at (block_kwargs may carry its own `e`); pads to seq_len, gathers into curve order, runs the blocks or adds
     the cached residual of this CFG stream, scatters back.  Returns [B, seq_len, C]."""
     B, L, C = tokens.shape
     seq_len = seq_len or L
     if seq_len > L:
         tokens = torch.cat([tokens, tokens.new_zeros(B, seq_len - L, C)], dim=1)
     x = _capi.gather_rows(tokens.contiguous(), hilbert_order)
-    calc, parity = tea.decide(e, e0)
+    calc, parity = tea.decide(t_emb, t_emb0)
     if not calc:
         x = x + tea.residual[parity]
     else:

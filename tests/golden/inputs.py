@@ -90,3 +90,38 @@ def op_inputs():
     v = torch.randn(1, S, s["H"], 128, generator=gen).half()
     cu = torch.tensor([0, s["nb_img"] * 128 + s["valid_text"], S], dtype=torch.int32)
     return q, k, v, cu
+
+
+# ---- Wan attention block (wan/modules/model_mul.py:252-346) -------------------------------------------------------
+WAN_BLOCK = dict(dim=256, ffn_dim=512, num_heads=2, grid=(2, 8, 8), ctx_len=96, eps=1e-6)
+
+
+def wan_block_inputs():
+    """Seeded state dict (reference parameter names), x fp32 [1,128,256] (bf16-representable: the first block sees
+    the 16-bit patch embedding), e fp32 [1,6,256], context bf16 [1,96,256], freq_remap (a permutation of the
+    tokens).  Linear weights are bf16-representable so that autocast's on-the-fly cast is exact."""
+    c = WAN_BLOCK
+    dim, ffn = c["dim"], c["ffn_dim"]
+    gen = torch.Generator().manual_seed(4242)
+    bf = lambda t: t.to(torch.bfloat16).float()
+    sd = {}
+    for pre in ("self_attn", "cross_attn"):
+        for n in ("q", "k", "v", "o"):
+            sd[f"{pre}.{n}.weight"] = bf(torch.randn(dim, dim, generator=gen) * 0.06)
+            sd[f"{pre}.{n}.bias"] = bf(torch.randn(dim, generator=gen) * 0.05)
+        sd[f"{pre}.norm_q.weight"] = 1 + 0.1 * torch.randn(dim, generator=gen)
+        sd[f"{pre}.norm_k.weight"] = 1 + 0.1 * torch.randn(dim, generator=gen)
+    sd["norm3.weight"] = 1 + 0.1 * torch.randn(dim, generator=gen)
+    sd["norm3.bias"] = 0.1 * torch.randn(dim, generator=gen)
+    sd["ffn.0.weight"] = bf(torch.randn(ffn, dim, generator=gen) * 0.06)
+    sd["ffn.0.bias"] = bf(torch.randn(ffn, generator=gen) * 0.05)
+    sd["ffn.2.weight"] = bf(torch.randn(dim, ffn, generator=gen) * 0.05)
+    sd["ffn.2.bias"] = bf(torch.randn(dim, generator=gen) * 0.05)
+    sd["modulation"] = torch.randn(1, 6, dim, generator=gen) / dim ** 0.5
+    f, h, w = c["grid"]
+    L = f * h * w
+    x = bf(torch.randn(1, L, dim, generator=gen) * 1.3)
+    e = torch.randn(1, 6, dim, generator=gen) * 0.3
+    ctx = (torch.randn(1, c["ctx_len"], dim, generator=gen)).to(torch.bfloat16)
+    remap = torch.randperm(L, generator=gen)
+    return dict(state=sd, x=x, e=e, context=ctx, remap=remap)

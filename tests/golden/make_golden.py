@@ -254,6 +254,68 @@ def gen_wan():
     np.savez_compressed(os.path.join(OUT, "wan_cases.npz"), **out)
 
 
+def gen_wan_block():
+    """The reference's WanAttentionBlock (wan/modules/model_mul.py:252-346) run on CPU under torch.autocast("cpu",
+    bfloat16) -- the same rounding points as the CUDA autocast it ships with (linear inputs/outputs 16-bit, LayerNorm
+    and the residual stream fp32).  Only `flash_attention` (a thin wrapper over the absent flash-attn package that
+    asserts CUDA) is replaced by an fp32 softmax on its half()-cast inputs.  Dense path (sa_drop_rate = 0): the
+    sparse path is pinned separately by the op-level fixtures."""
+    for name in ("diffusers", "diffusers.configuration_utils", "diffusers.models", "diffusers.models.modeling_utils"):
+        sys.modules.setdefault(name, types.ModuleType(name))
+    sys.modules["diffusers.configuration_utils"].ConfigMixin = object
+    sys.modules["diffusers.configuration_utils"].register_to_config = lambda f: f
+    sys.modules["diffusers.models.modeling_utils"].ModelMixin = torch.nn.Module
+    _install_flash_stub()
+    if "refwan" not in sys.modules:
+        pkg = types.ModuleType("refwan"); pkg.__path__ = [os.path.join(REF, "wan", "modules")]
+        sys.modules["refwan"] = pkg
+    import importlib
+    mm = importlib.import_module("refwan.model_mul")
+
+    def cpu_flash(q, k, v, q_lens=None, k_lens=None, dropout_p=0., softmax_scale=None, q_scale=None, causal=False,
+                  window_size=(-1, -1), deterministic=False, dtype=torch.bfloat16, version=None):
+        out_dtype = q.dtype
+        half = lambda t: t if t.dtype in (torch.float16, torch.bfloat16) else t.to(dtype)
+        qh, kh, vh = half(q), half(k), half(v)
+        qh, kh = qh.to(vh.dtype), kh.to(vh.dtype)
+        B, Lq, N, D = qh.shape
+        s = torch.einsum("bqnd,bknd->bnqk", qh.float(), kh.float()) * (softmax_scale or D ** -0.5)
+        if k_lens is not None:
+            kl = torch.as_tensor(k_lens).view(B, 1, 1, 1)
+            s = s.masked_fill(torch.arange(kh.shape[1]).view(1, 1, 1, -1) >= kl, float("-inf"))
+        o = torch.einsum("bnqk,bknd->bqnd", torch.softmax(s, dim=-1), vh.float()).to(vh.dtype)
+        return o.type(out_dtype)
+
+    mm.flash_attention = cpu_flash
+    c = inputs.WAN_BLOCK
+    inp = inputs.wan_block_inputs()
+    blk = mm.WanAttentionBlock("t2v_cross_attn", c["dim"], c["ffn_dim"], c["num_heads"], qk_norm=True,
+                               cross_attn_norm=True, eps=c["eps"])
+    missing = blk.load_state_dict(inp["state"], strict=True)
+    d = c["dim"] // c["num_heads"]
+    freqs = torch.cat([mm.rope_params(1024, d - 4 * (d // 6)), mm.rope_params(1024, 2 * (d // 6)),
+                       mm.rope_params(1024, 2 * (d // 6))], dim=1)
+    f, h, w = c["grid"]
+    cap = {}
+    blk.self_attn.register_forward_hook(lambda m, a, o: cap.update(h1=a[0].detach().clone(), y1=o.detach().clone()))
+    blk.cross_attn.register_forward_hook(lambda m, a, o: cap.update(h3=a[0].detach().clone(), y3=o.detach().clone()))
+    blk.ffn.register_forward_hook(lambda m, a, o: cap.update(h2=a[0].detach().clone(), y2=o.detach().clone()))
+    out = {}
+    for tag, x_in in (("first", inp["x"].to(torch.bfloat16)), ("later", inp["x"] * 1.7 + 0.123)):
+        with torch.autocast("cpu", dtype=torch.bfloat16):
+            y = blk(x_in, inp["e"], torch.tensor([f * h * w]), torch.tensor([[f, h, w]]), freqs, inp["context"], None,
+                    sa_drop_rate=0.0, freq_remap=inp["remap"], block_neighbor_list=None, p_remain_rates=0.8)
+        assert y.dtype == torch.float32
+        out[f"{tag}_out"] = y.numpy()
+        keep = ("h1",) if tag == "first" else ("h1", "h3", "h2", "y1", "y3")
+        for k_ in keep:   # h*: fp32 module inputs, stored as what autocast feeds the GEMM (RN to bf16); y*: bf16 outputs
+            assert cap[k_].dtype == (torch.float32 if k_[0] == "h" else torch.bfloat16), (k_, cap[k_].dtype)
+            out[f"{tag}_{k_}"] = cap[k_].to(torch.bfloat16).contiguous().view(torch.uint16).numpy()
+    out["inputs_sha"] = np.array(sha(np.concatenate([inp["x"].numpy().ravel(), inp["e"].numpy().ravel(),
+                                                     inp["state"]["ffn.2.weight"].numpy().ravel()])))
+    np.savez_compressed(os.path.join(OUT, "wan_block_case.npz"), **out)
+
+
 def gen_scheduler():
     """FlowMatchDiscreteScheduler (diffusers absent -> its three imports are stubbed for the import only)."""
     import dataclasses
@@ -306,7 +368,7 @@ if __name__ == "__main__":
     ap.add_argument("--only", default="")
     a = ap.parse_args()
     torch.set_grad_enabled(False)
-    if a.only not in ("wan", "sched"):
+    if a.only not in ("wan", "sched", "wanblock"):
         gen_gilbert(a.big)
     if a.only in ("", "select", "attn"):
         gen_select()
@@ -316,6 +378,8 @@ if __name__ == "__main__":
         gen_norm_rope()
     if a.only in ("", "wan"):
         gen_wan()
+    if a.only in ("", "wan", "wanblock"):
+        gen_wan_block()
     if a.only in ("", "sched"):
         gen_scheduler()
     print("golden fixtures written to", OUT)

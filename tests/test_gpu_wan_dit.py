@@ -1,0 +1,158 @@
+"""GPU (-m gpu): the Wan2.1 DiT harness -- the two fp32-residual glue kernels against the oracle,
+WanAttentionBlock against tensors captured inside the reference's own block (tests/golden/wan_block_case.npz), and the
+WanDiT forward (patchify, time/text embeddings, TeaCache driver, head, unpatchify) end to end on a small grid."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import assert_ulp_close, from_bits, to_np
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+import inputs  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+@pytest.mark.parametrize("C,rows", [(256, 300), (1536, 257), (5120, 130)])
+def test_wan_glue_kernels_vs_oracle(dev, C, rows):
+    from jenga_amd import _capi
+    from oracle import wan as ow
+    g = torch.Generator().manual_seed(C)
+    x = torch.randn(1, rows, C, generator=g) * 3 + 0.5
+    w, b = 1 + 0.1 * torch.randn(C, generator=g), 0.1 * torch.randn(C, generator=g)
+    sh, sc = 0.3 * torch.randn(1, C, generator=g), 0.3 * torch.randn(1, C, generator=g)
+    xd = x.to(dev)
+    for kw, okw in ((dict(shift=sh, scale=sc), (None, None, sh[0].numpy(), sc[0].numpy())),
+                    (dict(weight=w, bias=b), (w.numpy(), b.numpy(), None, None)),
+                    (dict(weight=w, bias=b, shift=sh, scale=sc), (w.numpy(), b.numpy(), sh[0].numpy(), sc[0].numpy()))):
+        for rl in (False, True):
+            got = _capi.wan_ln_modulate(xd, eps=1e-6, round_ln=rl, **{k: v.to(dev) for k, v in kw.items()})
+            assert got.dtype == torch.bfloat16
+            ref = ow.ln_modulate(x.numpy(), *okw, 1e-6, "bfloat16", round_ln=rl)
+            # equal up to rare last-place flips; where shift cancels the scaled norm the result is tiny and an fp32-level
+            # difference of the LayerNorm statistics is worth several of ITS ulps, so the ulp is floored at |t| = 2^-5
+            # (and with round_ln a flip of the intermediate 16-bit rounding is scaled by 1 + scale: allow 3 such ulps)
+            a, b_ = to_np(got), ref
+            diff = a != b_
+            assert diff.mean() <= 3e-3, diff.mean()
+            if diff.any():
+                mag = np.maximum(np.maximum(np.abs(a[diff]), np.abs(b_[diff])), 2.0 ** -5 if not rl else 1.0)
+                ulp = np.exp2(np.floor(np.log2(mag)) - 7)
+                assert (np.abs(a[diff] - b_[diff]) / ulp).max() <= (3.001 if rl else 1.001)
+    y = (torch.randn(1, rows, C, generator=g)).to(torch.bfloat16)
+    gate = torch.randn(1, C, generator=g)
+    out = _capi.wan_gate_residual(xd, y.to(dev), gate.to(dev))
+    assert out.dtype == torch.float32 and out.data_ptr() != xd.data_ptr()
+    assert np.array_equal(out.cpu().numpy(), ow.gate_residual(x.numpy(), to_np(y), gate[0].numpy()))       # bit-exact
+    x2 = xd.clone()
+    _capi.wan_gate_residual(x2, y.to(dev), None, out=x2)                                                      # in place
+    assert np.array_equal(x2.cpu().numpy(), ow.gate_residual(x.numpy(), to_np(y)))
+
+
+def _block(dev):
+    from jenga_amd.wan_dit import WanAttentionBlock
+    from jenga_amd.modules.wan import wan_freqs
+    c = inputs.WAN_BLOCK
+    inp = inputs.wan_block_inputs()
+    blk = WanAttentionBlock("t2v_cross_attn", c["dim"], c["ffn_dim"], c["num_heads"], qk_norm=True,
+                            cross_attn_norm=True, eps=c["eps"], dtype=torch.bfloat16, device=dev)
+    missing, unexpected = blk.load_state_dict(inp["state"], strict=False)
+    assert not unexpected and not missing, (missing, unexpected)
+    return blk, inp, wan_freqs(c["dim"] // c["num_heads"]), c
+
+
+def test_wan_block_vs_reference_block(dev):
+    """Same weights, inputs and RoPE remap as the reference block run on CPU (dense path, sa_drop_rate = 0).  The
+    captured intermediates are bf16: the kernels must agree to the ulp; the fp32 block output carries the hipBLASLt vs
+    CPU GEMM summation-order noise of three bf16 branches (|y| ~ 1, one bf16 ulp = 2^-8)."""
+    blk, inp, freqs, c = _block(dev)
+    g = np.load(os.path.join(GOLD, "wan_block_case.npz"))
+    f, h, w = c["grid"]
+    cap = {}
+    blk.self_attn.register_forward_hook(lambda m, a, o: cap.update(h1=a[0].clone(), y1=o.clone()))
+    blk.cross_attn.register_forward_hook(lambda m, a, o: cap.update(h3=a[0].clone(), y3=o.clone()))
+    blk.ffn[0].register_forward_hook(lambda m, a, o: cap.update(h2=a[0].clone()))
+    kw = dict(seq_lens=torch.tensor([f * h * w]), grid_sizes=torch.tensor([[f, h, w]]), freqs=freqs,
+              context=inp["context"].to(dev), context_lens=None, sa_drop_rate=0.0, freq_remap=inp["remap"].to(dev),
+              block_neighbor_list=None, p_remain_rates=0.8)
+    for tag, x_in, was16 in (("first", inp["x"], True), ("later", inp["x"] * 1.7 + 0.123, False)):
+        x_dev = x_in.to(dev)
+        keep = x_dev.clone()
+        y = blk(x_dev, inp["e"].to(dev), x_was_16bit=was16, **kw)
+        assert y.dtype == torch.float32 and torch.equal(x_dev, keep), "the block must not modify its input"
+        assert_ulp_close(to_np(cap["h1"]), to_np(from_bits(g[f"{tag}_h1"], "bfloat16")), "bfloat16", max_frac=3e-3)
+        ref = g[f"{tag}_out"]
+        err = np.abs(y.cpu().numpy() - ref)
+        assert err.max() <= 6e-2 and err.mean() <= 4e-3, (tag, err.max(), err.mean())
+        if tag == "later":
+            for k_, tol in (("y1", 3e-2), ("y3", 3e-2)):
+                d = np.abs(to_np(cap[k_]) - to_np(from_bits(g[f"later_{k_}"], "bfloat16")))
+                assert d.max() <= tol, (k_, d.max())
+            # the modulated norms downstream see slightly different residuals: compare loosely
+            for k_ in ("h3", "h2"):
+                d = np.abs(to_np(cap[k_]) - to_np(from_bits(g[f"later_{k_}"], "bfloat16")))
+                assert d.max() <= 8e-2 and d.mean() <= 4e-3, (k_, d.max(), d.mean())
+
+
+def test_wan_block_sparse_path_runs_and_matches_dense_when_everything_is_kept(dev):
+    """sa_drop_rate > 0.25 takes the block-sparse kernels; with a drop rate that keeps every block (top_k = all) the
+    result must equal the dense path's (same kernels underneath, dense == all blocks kept)."""
+    blk, inp, freqs, c = _block(dev)
+    f, h, w = c["grid"]
+    kw = dict(seq_lens=torch.tensor([f * h * w]), grid_sizes=torch.tensor([[f, h, w]]), freqs=freqs,
+              context=inp["context"].to(dev), context_lens=None, freq_remap=inp["remap"].to(dev), p_remain_rates=1.0)
+    x = (inp["x"] * 1.7 + 0.123).to(dev)
+    nbm = torch.ones(1, 1, dtype=torch.bool)
+    dense = blk(x, inp["e"].to(dev), sa_drop_rate=0.0, block_neighbor_list=None, **kw)
+    sparse = blk(x, inp["e"].to(dev), sa_drop_rate=0.3, block_neighbor_list=nbm, **kw)
+    assert torch.equal(dense, sparse)
+
+
+def test_wan_dit_forward_end_to_end(dev):
+    """Small WanDiT: two CFG streams per step through the TeaCache driver, sliced-Gilbert reorder, head + unpatchify.
+    Checks shapes, finiteness, that the reorder is transparent (identity curve == sliced curve up to the attention's
+    block structure being dense here) and that a cached step replays the stored residual."""
+    from jenga_amd import gilbert as G
+    from jenga_amd.wan_dit import WanDiT
+    torch.manual_seed(0)
+    m = WanDiT(dim=256, ffn_dim=512, num_heads=2, num_layers=2, text_dim=64, text_len=32, dtype=torch.bfloat16,
+               device=dev)
+    for p_ in m.parameters():
+        if p_.dim() >= 2:
+            torch.nn.init.normal_(p_, std=0.05)
+    F_, H_, W_ = 3, 16, 16
+    grid = (F_, H_ // 2, W_ // 2)
+    L = grid[0] * grid[1] * grid[2]
+    l2h, h2l = G.sliced_gilbert_mapping(*grid, as_tensor=True)
+    nbm = G.sliced_gilbert_block_neighbor_mapping(*grid, as_tensor=True)
+    x = [torch.randn(16, F_, H_, W_, device=dev)]
+    ctx = [torch.randn(20, 64, device=dev)]
+    t = torch.tensor([900.0], device=dev)
+    outs = {}
+    for name, (a, b) in (("curve", (l2h, h2l)), ("ident", (torch.arange(L, device=dev), torch.arange(L, device=dev)))):
+        m.set_curve(a, b, nbm)
+        m.enable_teacache(num_steps=4, thresh=0.0, task="t2v-1.3B", enable=False)
+        y = m(x, t, ctx, seq_len=L, sa_drop_rate=0.0)[0]
+        assert y.shape == (16, F_, H_, W_) and y.dtype == torch.float32 and torch.isfinite(y).all()
+        outs[name] = y
+    # dense attention is permutation-equivariant: the curve only changes summation order inside the kernels
+    assert (outs["curve"] - outs["ident"]).abs().max().item() <= 5e-2 * outs["ident"].abs().max().item()
+    # TeaCache: with a huge threshold the third call of a stream (cnt = 4, even) is skipped and replays the residual
+    m.set_curve(l2h, h2l, nbm)
+    m.enable_teacache(num_steps=6, thresh=1e9, task="t2v-1.3B", enable=True)
+    calls = []
+    for i in range(6):
+        before = m.tea.cnt
+        m(x, torch.tensor([900.0 - 10 * (i // 2)], device=dev), ctx, seq_len=L, sa_drop_rate=0.0)
+        calls.append((before, m.tea.residual[before % 2] is not None))
+    assert m.tea.cnt == 6 and all(r for _, r in calls)

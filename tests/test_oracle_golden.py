@@ -147,3 +147,28 @@ def test_wan_preops_bit_exact(golden_dir):
     assert np.array_equal(ow.rope_apply(x, (3, 4, 5), fr, g["remap"]), g["rope_remap"])
     y = ow.wan_rmsnorm(to_np(from_bits(g["norm_x"], "bfloat16")), g["norm_w"], "bfloat16", 1e-6)
     assert_ulp_close(y, g["norm_y"], "bfloat16", max_ulps=2)
+
+
+def test_wan_block_glue_against_reference_block(golden_dir):
+    """oracle.wan.ln_modulate / gate_residual against tensors captured inside the reference's WanAttentionBlock
+    (tests/golden/make_golden.py gen_wan_block): the modulated LayerNorms that feed self-attention, cross-attention and
+    the ffn, and the three residual updates (checked through the block output)."""
+    from oracle import wan as ow
+    g = np.load(os.path.join(golden_dir, "wan_block_case.npz"))
+    inp = inputs.wan_block_inputs()
+    sd = {k: v.numpy() for k, v in inp["state"].items()}
+    em = (sd["modulation"] + inp["e"].numpy()).astype(np.float32)[0]           # [6, C]
+    x_first = inp["x"].numpy()
+    h1 = ow.ln_modulate(x_first, None, None, em[0], em[1], 1e-6, "bfloat16", round_ln=True)
+    assert_ulp_close(h1, to_np(from_bits(g["first_h1"], "bfloat16")), "bfloat16", max_frac=2e-3)
+    x_later = (inp["x"] * 1.7 + 0.123).numpy()
+    h1 = ow.ln_modulate(x_later, None, None, em[0], em[1], 1e-6, "bfloat16")
+    assert_ulp_close(h1, to_np(from_bits(g["later_h1"], "bfloat16")), "bfloat16", max_frac=2e-3)
+    # replay the residual chain with the reference's own branch outputs
+    y1 = to_np(from_bits(g["later_y1"], "bfloat16"))
+    x1 = ow.gate_residual(x_later, y1, em[2])
+    h3 = ow.ln_modulate(x1, sd["norm3.weight"], sd["norm3.bias"], None, None, 1e-6, "bfloat16")
+    assert_ulp_close(h3, to_np(from_bits(g["later_h3"], "bfloat16")), "bfloat16", max_frac=2e-3)
+    x2 = ow.gate_residual(x1, to_np(from_bits(g["later_y3"], "bfloat16")))
+    h2 = ow.ln_modulate(x2, None, None, em[3], em[4], 1e-6, "bfloat16")
+    assert_ulp_close(h2, to_np(from_bits(g["later_h2"], "bfloat16")), "bfloat16", max_frac=2e-3)
