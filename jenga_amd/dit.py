@@ -265,6 +265,9 @@ class JengaHYVideoDiT(nn.Module):
         self.sa_drop_rate = 0.0
         self.text_amp = 0.0
         self.p_remain_rates = 0.3
+        # HunyuanVideo-I2V (jenga_hyi2v.py:79-92, 124-130): "token_replace" conditions the first latent frame's tokens
+        # with the modulation of timestep 0; None = text-to-video
+        self.i2v_condition_type = None
 
     @torch.no_grad()
     def init_synthetic_weights(self, std=0.02, seed=0):
@@ -328,6 +331,14 @@ class JengaHYVideoDiT(nn.Module):
         img = _capi.gather_rows(img, self.hilbert_order)
         freqs_cos = _capi.gather_rows(freqs_cos.unsqueeze(0), self.hilbert_order)[0]
         freqs_sin = _capi.gather_rows(freqs_sin.unsqueeze(0), self.hilbert_order)[0]
+        token_replace_vec = first_frame_mask = None
+        if self.i2v_condition_type == "token_replace":
+            token_replace_vec = self.time_in(self._sinusoid(torch.zeros_like(t)).to(dt)) + self.vector_in(text_states_2.to(dt))
+            first_frame_mask = (self.hilbert_order < th * tw)          # == mask[:th*tw] = 1 gathered into curve order
+        elif self.i2v_condition_type is not None:
+            raise ValueError(f"unsupported i2v_condition_type {self.i2v_condition_type!r}")
+        if txt_seq_len % 128:
+            raise ValueError("the text length must be a multiple of 128 (2 blocks for T2V, 4 for I2V)")
         sp = self.double_blocks[0].hybrid_seq_parallel_attn if len(self.double_blocks) else None
         if sp:
             n, r = ulysses.get_sequence_parallel_world_size(), ulysses.get_sequence_parallel_rank()
@@ -335,6 +346,8 @@ class JengaHYVideoDiT(nn.Module):
             img = torch.chunk(img, n, dim=1)[r].contiguous()
             freqs_cos = torch.chunk(freqs_cos, n, dim=0)[r].contiguous()
             freqs_sin = torch.chunk(freqs_sin, n, dim=0)[r].contiguous()
+            if first_frame_mask is not None:
+                first_frame_mask = torch.chunk(first_frame_mask, n, dim=0)[r].contiguous()
         loc_len = img.shape[1]
         cu_seqlens_q = get_cu_seqlens(text_mask, loc_len)
         cu_seqlens_kv = cu_seqlens_q
@@ -352,11 +365,15 @@ class JengaHYVideoDiT(nn.Module):
             freqs = (freqs_cos, freqs_sin)
             for block in self.double_blocks:
                 img, txt = block(img, txt, vec, cu_seqlens_q, cu_seqlens_kv, max_seqlen_q, max_seqlen_kv, freqs,
-                                 self.sa_drop_rate, self.text_amp, self.curve_sel, self.p_remain_rates)
+                                 self.sa_drop_rate, self.text_amp, self.curve_sel, self.p_remain_rates,
+                                 txt_block_num=txt_seq_len // 128, token_replace_vec=token_replace_vec,
+                                 first_frame_mask=first_frame_mask)
             xcat = torch.cat((img, txt), 1)
             for block in self.single_blocks:
                 xcat = block(xcat, vec, txt_seq_len, cu_seqlens_q, cu_seqlens_kv, max_seqlen_q, max_seqlen_kv, freqs,
-                             self.sa_drop_rate, self.text_amp, self.curve_sel, self.p_remain_rates)
+                             self.sa_drop_rate, self.text_amp, self.curve_sel, self.p_remain_rates,
+                             txt_block_num=txt_seq_len // 128, token_replace_vec=token_replace_vec,
+                             first_frame_mask=first_frame_mask)
             img = xcat[:, :loc_len]
             if self.enable_skip:
                 self.previous_residual = img - ori_img

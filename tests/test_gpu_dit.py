@@ -195,3 +195,71 @@ def test_wan_teacache_forward_gather_scatter_and_cache(dev):
     assert [c for _, c in outs] == [True, True, False, False, False, False]
     for y, calc in outs:
         assert y.shape == (1, seq_len, 64) and torch.equal(y, computed if calc else cached)
+
+
+def test_i2v_token_replace_block_and_forward(dev):
+    """HunyuanVideo-I2V flavour (hyvideo_i2v/modules/models_mul.py:393-506, jenga_hyi2v.py:79-92, 124-130): first-frame
+    tokens take shift/scale/gate from the timestep-0 vector, four text blocks.  Block against an eager per-row
+    composition + the oracle's attention; model forward: mask in curve order, txt_block_num, finite output that differs
+    from the T2V forward."""
+    from jenga_amd import dit
+    from oracle import gilbert as og
+    from oracle import norm_rope as onr
+    m = _tiny_model(dev)
+    blk = m.single_blocks[0]
+    S_img, S_txt, C, H = 512, 512, 256, 2
+    g = torch.Generator(device=dev).manual_seed(11)
+    x = torch.randn(1, S_img + S_txt, C, generator=g, device=dev, dtype=torch.bfloat16)
+    vec = torch.randn(1, C, generator=g, device=dev, dtype=torch.bfloat16)
+    trv = torch.randn(1, C, generator=g, device=dev, dtype=torch.bfloat16)
+    ffm = torch.rand(S_img, generator=g, device=dev) < 0.25
+    nbm = og.gilbert_block_neighbor_mapping(2, 8, 32, 128)
+    cos, sin = onr.rope_tables([16, 56, 56], [2, 8, 32], 256.0)
+    cos_t, sin_t = torch.from_numpy(cos).to(dev), torch.from_numpy(sin).to(dev)
+    cu = torch.tensor([0, S_img + 300, S_img + S_txt], dtype=torch.int32, device=dev)
+    curve = [[None, None, torch.from_numpy(nbm).to(dev)]]
+    out = blk(x, vec, S_txt, cu, cu, S_img + S_txt, S_img + S_txt, (cos_t, sin_t), 0.5, 0.3, curve, 0.3,
+              txt_block_num=4, token_replace_vec=trv, first_frame_mask=ffm)
+    torch.set_grad_enabled(False)
+    full = torch.cat([ffm, torch.zeros(S_txt, dtype=torch.bool, device=dev)])[None, :, None]
+    a, b = blk.modulation(vec).chunk(3, dim=-1), blk.modulation(trv).chunk(3, dim=-1)
+    pre = blk.pre_norm(x)
+    lin1 = blk.linear1(torch.where(full, dit.modulate(pre, b[0], b[1]), dit.modulate(pre, a[0], a[1])))
+    qkv = lin1[..., :3 * C].reshape(1, S_img + S_txt, 3, H, 128)
+    q = onr.rmsnorm(to_np(qkv[:, :, 0]), to_np(blk.q_norm.weight), "bfloat16")
+    k = onr.rmsnorm(to_np(qkv[:, :, 1]), to_np(blk.k_norm.weight), "bfloat16")
+    q[:, :S_img] = onr.apply_rotary_emb(q[:, :S_img], cos, sin, "bfloat16")
+    k[:, :S_img] = onr.apply_rotary_emb(k[:, :S_img], cos, sin, "bfloat16")
+    attn = _oracle_attention(torch.from_numpy(q), torch.from_numpy(k), qkv[:, :, 2].cpu(), int(0.5 * 4), S_img + 300, 4,
+                             0.3, 0.3, nbm).to(dev)
+    y = blk.linear2(torch.cat((attn, F.gelu(lin1[..., 3 * C:], approximate="tanh")), 2))
+    ref = x + torch.where(full, y * b[2].unsqueeze(1), y * a[2].unsqueeze(1))
+    err = (out.float() - ref.float()).abs()
+    bound = 2 * torch.exp2(torch.floor(torch.log2(ref.float().abs().clamp_min(1e-3))) - 7) + 0.02
+    assert (err <= bound).all() and err.mean().item() <= 2e-3, (err.max().item(), err.mean().item())
+    # ---- model forward
+    x_lat, _, text2, _ = _inputs(dev)
+    text = torch.randn(1, 512, 64, generator=g, device=dev, dtype=torch.bfloat16)
+    mask = torch.zeros(1, 512, dtype=torch.int64, device=dev)
+    mask[:, :300] = 1
+    cos_m, sin_m = m.set_stage((4, 16, 32), dev)
+    m.sa_drop_rate, m.text_amp, m.p_remain_rates, m.enable_skip = 0.5, 0.0, 0.3, False
+    t, gd = torch.tensor([900.0], device=dev), torch.tensor([6000.0], device=dev)
+    seen = {}
+    orig = m.single_blocks[0].forward
+
+    def spy(*a_, **kw):
+        seen.update(kw)
+        return orig(*a_, **kw)
+
+    m.single_blocks[0].forward = spy
+    y_t2v = m(x_lat, t, text, mask, text2, cos_m, sin_m, gd, return_dict=False)
+    assert seen["token_replace_vec"] is None and seen["txt_block_num"] == 4
+    m.i2v_condition_type = "token_replace"
+    y_i2v = m(x_lat, t, text, mask, text2, cos_m, sin_m, gd, return_dict=False)
+    th_tw = (16 // 2) * (32 // 2)
+    expect = torch.zeros(4 * th_tw, dtype=torch.bool, device=dev)
+    expect[:th_tw] = True
+    assert torch.equal(seen["first_frame_mask"], expect[m.hilbert_order]) and seen["token_replace_vec"] is not None
+    assert torch.isfinite(y_i2v.float()).all() and not torch.equal(y_i2v, y_t2v)
+    m.i2v_condition_type = None
