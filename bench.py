@@ -46,6 +46,9 @@ def parse():
     ap.add_argument("--latent", type=int, nargs=3, default=[32, 90, 160], help="latent T H W (720x1280x125f)")
     ap.add_argument("--depth", type=int, nargs=2, default=None, help="override (double, single) block counts (debug only)")
     ap.add_argument("--valid-text", type=int, default=64)
+    ap.add_argument("--i2v", action="store_true",
+                    help="HunyuanVideo-I2V flavour: token_replace modulation of the first latent frame, 512 text tokens "
+                         "(4 text blocks) -- BASELINE.json configs[4] with --preset 3stage")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     return ap.parse_args()
 
@@ -147,12 +150,14 @@ def main():
     computed_steps = sorted(set(NON_SKIP_STEPS) | forced)
     sched = prores.FlowMatchSchedule(50, shift=preset["shifts"][0])
     g2 = torch.Generator(device=dev).manual_seed(43)
-    text = torch.randn(1, 256, 4096, generator=g2, device=dev, dtype=torch.bfloat16)
+    n_txt = 512 if a.i2v else 256
+    text = torch.randn(1, n_txt, 4096, generator=g2, device=dev, dtype=torch.bfloat16)
     text2 = torch.randn(1, 768, generator=g2, device=dev, dtype=torch.bfloat16)
-    text_mask = torch.zeros(1, 256, dtype=torch.int64, device=dev)
+    text_mask = torch.zeros(1, n_txt, dtype=torch.int64, device=dev)
     text_mask[:, : a.valid_text] = 1
     guidance = torch.tensor([6000.0], device=dev)
     model.p_remain_rates = a.p_remain
+    model.i2v_condition_type = "token_replace" if a.i2v else None
     model.text_amp = 0.0
     model.num_steps = 50
     model.enable_skip = True
@@ -181,13 +186,15 @@ def main():
         plan = [i % 50 for i in range(a.steps)]      # whole loop(s); sec/video = elapsed * 50 / steps
         sampled = False
     else:
-        # class-balanced sample of the schedule: per stage two computed steps and one skipped one
-        pattern = []
+        # class-balanced sample of the schedule: one computed + one skipped step of EVERY stage first, then a second
+        # computed step per stage -- so that the default K = 6 covers every class of a three-stage preset
+        comp_k, skip_k = [], []
         for k in range(len(stages)):
             ids = [i for i in range(50) if stage_of(i, split) == k]
-            comp = [i for i in ids if i in computed_steps]
-            skip = [i for i in ids if i not in computed_steps]
-            pattern += comp[:1] + skip[:1] + comp[1:2]
+            comp_k.append([i for i in ids if i in computed_steps])
+            skip_k.append([i for i in ids if i not in computed_steps])
+        # (a skipped step replays the residual of the last computed step, so it has to follow one of ITS stage)
+        pattern = [i for c, s_ in zip(comp_k, skip_k) for i in c[:1] + s_[:1]] + [c[1] for c in comp_k if len(c) > 1]
         plan = [pattern[j % len(pattern)] for j in range(a.steps)]
         sampled = True
 
@@ -236,8 +243,10 @@ def main():
             same = [mean(v) for kk, v in cls.items() if kk[1] == key[1]]
             return same[-1] if same else 0.0
         sec_per_video = sum(n * class_ms(key) for key, n in counts.items()) * scale / 1e3
+        unsampled = sorted(f"{k}{c}" for (k, c) in counts if (k, c) not in cls)
     else:
         sec_per_video = elapsed * 50.0 / len(plan)
+        unsampled = []
     ps = prof.summary()
     traffic = None
     try:   # HBM-side bytes per launch from the committed PMC passes (profiles/), scaled by this run's kept pairs
@@ -254,7 +263,8 @@ def main():
         "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
         "config": {"workload": f"HunyuanVideo 720x1280x125f Jenga-{a.preset}, 1xMI355X-class GPU per rank: latent "
                                f"{T}x{Hh}x{W}, {len(model.double_blocks)} double + {len(model.single_blocks)} single "
-                               "blocks, hidden 3072, 24 heads, S_img=%d S_txt=256" % ((T * Hh * W) // 4),
+                               "blocks, hidden 3072, 24 heads, S_img=%d S_txt=%d%s" % ((T * Hh * W) // 4, 512 if a.i2v else 256,
+                                                                                  " (I2V token_replace)" if a.i2v else ""),
                    "preset": a.preset, "res_rate_list": preset["res"], "step_rate_list": preset["steps"],
                    "scheduler_shift_list": preset["shifts"],
                    "stage_tokens": [(sh[0] * (sh[1] // 2) * (sh[2] // 2)) for sh in shapes],
@@ -264,6 +274,7 @@ def main():
                    f"count x mean step time, counts {dict((f'{k[0]}{k[1]}', n) for k, n in counts.items())}",
                    "ms_per_class": {f"stage{k[0]}_{'computed' if k[1] == 'c' else 'skipped'}": round(mean(v), 2)
                                     for k, v in sorted(cls.items())},
+                   "classes_not_sampled": unsampled,     # non-empty only for very small --steps: they borrow a neighbour's mean
                    "parallelism": "single GPU" if world == 1 else f"ulysses{world} (RCCL all-to-all)",
                    "weights": "random init N(0,0.02), seed 0", "finite_output": finite},
         "roofline": {"kernel": "jenga::bsattn_fwd_kernel<bf16>", "bound": "mfma", "achieved": round(ach, 1),
