@@ -521,3 +521,55 @@ def test_full_size_gather_scatter_and_norm_rope_roundtrip(dev):
     n0 = qh.float().view(-1, 64, 2).norm(dim=-1)
     n1 = r.float().view(-1, 64, 2).norm(dim=-1)
     assert (n0 - n1).abs().max().item() <= 0.05
+
+
+# ----------------------------------------------------------------------------------------------- edge cases
+@pytest.mark.parametrize("valid_text,top_k", [(0, 3), (256, 0), (1, 1), (255, 11)])
+def test_whole_op_edge_cases_vs_oracle(dev, valid_text, top_k):
+    """No valid text token at all (every text key masked for image rows, text rows still dense), a fully valid text,
+    top_k = 0 (the probability rule alone decides), top_k > number of image blocks (everything kept)."""
+    from jenga_amd.modules.attention_block_sparse import block_sparse_attention
+    from oracle import attention as oa
+    from oracle import gilbert as og
+    gen = torch.Generator().manual_seed(100 + valid_text + top_k)
+    H, grid = 2, (2, 8, 32)
+    S_img, S_txt = grid[0] * grid[1] * grid[2], 256
+    S = S_img + S_txt
+    q = (torch.randn(1, S, H, 128, generator=gen) * 1.3).to(torch.bfloat16)
+    k = (torch.randn(1, S, H, 128, generator=gen) * 1.3).to(torch.bfloat16)
+    v = torch.randn(1, S, H, 128, generator=gen).to(torch.bfloat16)
+    nbm = og.gilbert_block_neighbor_mapping(*grid, 128)
+    cu = torch.tensor([0, S_img + valid_text, S], dtype=torch.int32)
+    o = block_sparse_attention(q.to(dev), k.to(dev), v.to(dev), top_k=top_k, cu_seqlens_q=cu.to(dev),
+                               cu_seqlens_kv=cu.to(dev), text_blocks=2, text_amp=0.25,
+                               block_neighbor_list=torch.from_numpy(nbm), p_remain_rates=0.4)
+    ref = oa.block_sparse_attention(to_np(q), to_np(k), to_np(v), top_k, "bfloat16", cu_seqlens_q=cu.numpy(),
+                                    text_blocks=2, text_amp=0.25, block_neighbor_list=nbm, p_remain_rates=0.4)
+    got = o.float().cpu().numpy().reshape(ref.shape)
+    assert np.isfinite(got).all()
+    assert np.abs(got - ref).max() <= 2e-2, np.abs(got - ref).max()
+
+
+def test_c_abi_rejects_bad_arguments_on_device(dev):
+    """The C entry points validate before launching: misaligned pointers / strides, bad dtype codes, missing lists."""
+    from jenga_amd import _capi
+    L = _capi.lib()
+    st = _capi._stream(dev)
+    q = torch.zeros(1, 256, 1, 128, device=dev, dtype=torch.bfloat16)
+    vt = torch.zeros(1, 1, 4, 128, 64, device=dev, dtype=torch.bfloat16)
+    o = torch.empty_like(q)
+    sl = torch.tensor([256], dtype=torch.int32, device=dev)
+    idx = torch.zeros(1, 1, 2, 2, dtype=torch.int32, device=dev)
+    cnt = torch.ones(1, 1, 2, dtype=torch.int32, device=dev)
+    p = _capi._p
+    args = lambda qq=q, dtype=0, ss=128: (st, p(qq), p(q), p(vt), p(o), p(sl), p(idx), p(cnt), 1, 1, 2, 2, 256 * 128, ss, 128,
+                                          256 * 128, 128, 128, 256 * 128, 128, 128, 0.088, 0.0, 2, dtype, 1)
+    assert L.jenga_bsattn_fwd(*args()) == 0
+    torch.cuda.synchronize()
+    assert L.jenga_bsattn_fwd(*args(dtype=7)) != 0 and b"dtype" in L.jenga_last_error()
+    assert L.jenga_bsattn_fwd(*args(ss=129)) != 0 and b"stride" in L.jenga_last_error()
+    q_mis = torch.zeros(256 * 128 + 8, device=dev, dtype=torch.bfloat16)[4:]
+    assert L.jenga_bsattn_fwd(*args(qq=q_mis)) != 0 and b"aligned" in L.jenga_last_error()
+    bad = list(args())
+    bad[6] = None
+    assert L.jenga_bsattn_fwd(*bad) != 0 and b"idx" in L.jenga_last_error()
