@@ -250,7 +250,7 @@ def main():
     ps = prof.summary()
     traffic = None
     try:   # HBM-side bytes per launch from the committed PMC passes (profiles/), scaled by this run's kept pairs
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_bsattn.json")))
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_bsattn_final.json")))
         traffic = int(pmc["derived"]["traffic_bytes_per_kept_pair"] * ps["pairs"] / max(ps["launches"], 1))
     except Exception:
         pass
@@ -280,7 +280,7 @@ def main():
         "roofline": {"kernel": "jenga::bsattn_fwd_kernel<bf16>", "bound": "mfma", "achieved": round(ach, 1),
                      "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_PEAK_TFLOPS, 4),
                      "traffic": traffic,
-                     "traffic_source": "profiles/r01_pmc_bsattn.json: (2*FETCH_SIZE + WRITE_SIZE) per kept block pair "
+                     "traffic_source": "profiles/r01_pmc_bsattn_final.json: (2*FETCH_SIZE + WRITE_SIZE) per kept block pair "
                                        "from separate rocprofv3 --pmc passes, x this run's pairs per launch",
                      "launches": ps["launches"],
                      "avg_launch_ms": round(ps["total_ms"] / max(ps["launches"], 1), 3),
