@@ -50,6 +50,10 @@ def parse():
                     help="HunyuanVideo-I2V flavour: token_replace modulation of the first latent frame, 512 text tokens "
                          "(4 text blocks) -- BASELINE.json configs[4] with --preset 3stage")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--simulate-ranks", type=int, default=0,
+                    help="diagnostic, single process: run rank 0's share of an N-rank Ulysses job (per-rank shapes, "
+                         "pack / unpack kernels, 24/N heads) with the exchanges replaced by local copies -- the "
+                         "compute-side time of one rank; NOT a multi-GPU measurement")
     return ap.parse_args()
 
 
@@ -116,6 +120,16 @@ def main():
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=dev)
+    sim = a.simulate_ranks if world == 1 else 0
+    if sim > 1:
+        from torch.testing._internal.distributed.fake_pg import FakeStore
+        dist.init_process_group(backend="fake", rank=0, world_size=sim, store=FakeStore())
+        dist.all_to_all_single = lambda out, inp, group=None, **kw: out.copy_(inp)      # same shapes by construction
+
+        def _gather(parts, x, group=None, **kw):
+            for p_ in parts:
+                p_.copy_(x)
+        dist.all_gather = _gather
 
     from jenga_amd import _capi
     from jenga_amd.dit import NON_SKIP_STEPS, JengaHYVideoDiT
@@ -126,7 +140,7 @@ def main():
     if a.depth:
         kw = dict(depth_double=a.depth[0], depth_single=a.depth[1])
     model = JengaHYVideoDiT(dtype=torch.bfloat16, device=dev, **kw).init_synthetic_weights(0.02, seed=0)
-    if world > 1:
+    if world > 1 or sim > 1:
         ulysses.init_sequence_parallel()
         for blk in list(model.double_blocks) + list(model.single_blocks):
             blk.hybrid_seq_parallel_attn = ulysses.UlyssesAttenCarve()
@@ -275,7 +289,8 @@ def main():
                    "ms_per_class": {f"stage{k[0]}_{'computed' if k[1] == 'c' else 'skipped'}": round(mean(v), 2)
                                     for k, v in sorted(cls.items())},
                    "classes_not_sampled": unsampled,     # non-empty only for very small --steps: they borrow a neighbour's mean
-                   "parallelism": "single GPU" if world == 1 else f"ulysses{world} (RCCL all-to-all)",
+                   "parallelism": (f"rank 0 of a simulated ulysses{sim} job on ONE GPU, exchanges replaced by local copies"
+                                   if sim > 1 else "single GPU" if world == 1 else f"ulysses{world} (RCCL all-to-all)"),
                    "weights": "random init N(0,0.02), seed 0", "finite_output": finite},
         "roofline": {"kernel": "jenga::bsattn_fwd_kernel<bf16>", "bound": "mfma", "achieved": round(ach, 1),
                      "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_PEAK_TFLOPS, 4),
@@ -299,7 +314,7 @@ def main():
                                    "cores": cb["cores"], "kind": "port", "sample": cb["sample"]}
     if rank == 0:
         print(json.dumps(res))
-    if world > 1:
+    if world > 1 or sim > 1:
         dist.destroy_process_group()
 
 
