@@ -140,11 +140,14 @@ class MMDoubleStreamBlock(nn.Module):
         _capi.rmsnorm_rope(txt_qkv[:, :, 0], self.txt_attn_q_norm.weight, None, None, out=q[:, S_img:])
         _capi.rmsnorm_rope(txt_qkv[:, :, 1], self.txt_attn_k_norm.weight, None, None, out=k[:, S_img:])
         if self.hybrid_seq_parallel_attn:
-            v = torch.cat((img_qkv[:, :, 2], txt_qkv[:, :, 2]), dim=1)
-            attn = my_parallel_attention(self.hybrid_seq_parallel_attn, q, k, v, img_q_len=S_img, img_kv_len=S_img,
-                                         cu_seqlens_q=cu_seqlens_q, cu_seqlens_kv=cu_seqlens_kv,
-                                         top_k=ulysses.get_sequence_parallel_world_size() * top_k, text_amp=txt_amp,
-                                         block_neighbor_list=block_neighbor_list, p_remain_rates=p_remain_rates)
+            # my_parallel_attention's argument convention (attenion.py:159-195) without concatenating V first: the
+            # exchange packs the image part and slices the text part separately anyway
+            attn = self.hybrid_seq_parallel_attn(
+                None, q[:, :S_img], k[:, :S_img], img_qkv[:, :, 2], dropout_p=0.0, causal=False,
+                joint_tensor_query=q[:, S_img:], joint_tensor_key=k[:, S_img:], joint_tensor_value=txt_qkv[:, :, 2],
+                joint_strategy="rear", top_k=ulysses.get_sequence_parallel_world_size() * top_k,
+                cu_seqlens_q=cu_seqlens_q, cu_seqlens_kv=cu_seqlens_kv, text_amp=txt_amp,
+                block_neighbor_list=block_neighbor_list, p_remain_rates=p_remain_rates).reshape(B, S_img + S_txt, -1)
         elif sa_drop_rate == 0.0:
             v = torch.cat((img_qkv[:, :, 2], txt_qkv[:, :, 2]), dim=1)
             attn = dense_attention(q, k, v, cu_seqlens_q=cu_seqlens_q, cu_seqlens_kv=cu_seqlens_kv)
