@@ -14,7 +14,10 @@ SHAPES = [  # (M, K, N, name)
     (115456, 3072, 21504, "single.linear1"),
     (115456, 15360, 3072, "single.linear2"),
 ]
-if len(sys.argv) > 1:
+if len(sys.argv) > 1 and sys.argv[1].startswith("--ranks="):      # per-rank token counts of an N-rank Ulysses job
+    n = int(sys.argv[1].split("=")[1])
+    SHAPES = [(115200 // n + (256 if name.startswith("single") else 0), K, N, f"{name}/N{n}") for M, K, N, name in SHAPES]
+elif len(sys.argv) > 1:
     SHAPES = [s for s in SHAPES if s[3] in sys.argv[1:]]
 tot = 0.0
 for M, K, N, name in SHAPES:
