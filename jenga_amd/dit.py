@@ -75,7 +75,7 @@ class MLP(nn.Module):
 
     def forward(self, x):
         h = self.fc1(x)
-        return self.fc2(_capi.gelu_tanh(h, out=h) if h.is_cuda else F.gelu(h, approximate="tanh"))
+        return self.fc2(_capi.gelu_tanh(h, out=h))
 
 
 def _select_top_k(sa_drop_rate, img_block_num):

@@ -59,21 +59,13 @@ def get_sequence_parallel_rank():
 
 
 def _pack_heads(t, N):
-    """[B,S_loc,H,D] -> peer-major [N,B,S_loc,H/N,D] (pure data movement: HIP kernel on the GPU, torch views on CPU so
-    that the exchange logic can be exercised with the gloo backend)."""
-    if t.is_cuda:
-        return _capi.ulysses_pack_heads(t if t.stride(-1) == 1 else t.contiguous(), N)
-    B, S, H, D = t.shape
-    return t.reshape(B, S, N, H // N, D).permute(2, 0, 1, 3, 4).contiguous()
+    """[B,S_loc,H,D] -> peer-major [N,B,S_loc,H/N,D]: the HIP re-tiling kernel (device tensors only)."""
+    return _capi.ulysses_pack_heads(t if t.stride(-1) == 1 else t.contiguous(), N)
 
 
 def _unpack_heads(recv, N, out):
-    """peer-major [N,B,S_loc,H/N,D] -> out [B,S_loc,H,D] (may be a strided view)."""
-    if recv.is_cuda:
-        return _capi.ulysses_unpack_heads(recv, N, out=out)
-    Np, B, S, Hn, D = recv.shape
-    out.copy_(recv.permute(1, 2, 0, 3, 4).reshape(B, S, Np * Hn, D))
-    return out
+    """peer-major [N,B,S_loc,H/N,D] -> out [B,S_loc,H,D] (may be a strided view): HIP kernel (device tensors only)."""
+    return _capi.ulysses_unpack_heads(recv, N, out=out)
 
 
 def _hip_attention(q_all, k_all, v_all, top_k, seqlens, text_blocks, text_amp, p, neighbors):
@@ -87,13 +79,18 @@ class UlyssesAttenCarve(torch.nn.Module):
     """Callable with the signature of xFuserLongContextAttention.forward (xdit_ring_atten.py:61-85); assign an
     instance to `block.hybrid_seq_parallel_attn` exactly as jenga_hyvideo_multigpu.py:181-182 does.
 
-    attn_fn(q_all, k_all, v_all, top_k, seqlens, text_blocks, text_amp, p, neighbors) -> [1,S,H/N,D] is injectable so
-    the world_size>1 exchange can be tested on CPU (gloo) against the oracle; the default is the HIP path."""
+    The three local steps are injectable so that the world_size > 1 exchange logic can be exercised on CPU tensors over
+    gloo against the oracle (tests/test_ulysses_gloo.py supplies oracle stand-ins); the defaults are the HIP kernels and
+    raise on CPU tensors -- there is no CPU path in the product:
+      attn_fn(q_all, k_all, v_all, top_k, seqlens, text_blocks, text_amp, p, neighbors) -> [1,S,H/N,D]
+      pack_fn(t [B,S_loc,H,D], N) -> [N,B,S_loc,H/N,D];  unpack_fn(recv [N,B,S_loc,H/N,D], N, out [B,S_loc,H,D])"""
 
-    def __init__(self, group=None, attn_fn=None):
+    def __init__(self, group=None, attn_fn=None, pack_fn=None, unpack_fn=None):
         super().__init__()
         self.group = group
         self.attn_fn = attn_fn or _hip_attention
+        self.pack_fn = pack_fn or _pack_heads
+        self.unpack_fn = unpack_fn or _unpack_heads
 
     def _pg(self):
         return self.group if self.group is not None else get_sp_group().group
@@ -126,7 +123,7 @@ class UlyssesAttenCarve(torch.nn.Module):
         gathered = []
         for t, joint in ((query, joint_tensor_query), (key, joint_tensor_key), (value, joint_tensor_value)):
             full = torch.empty((B, S, Hn, D), dtype=dt, device=dev)
-            dist.all_to_all_single(full[0, :S_img].view(N, S_loc, Hn, D), _pack_heads(t, N).view(N, S_loc, Hn, D),
+            dist.all_to_all_single(full[0, :S_img].view(N, S_loc, Hn, D), self.pack_fn(t, N).view(N, S_loc, Hn, D),
                                    group=pg)
             full[:, S_img:] = joint[:, :, hs]      # text is replicated on every rank: slice my heads, no exchange
             gathered.append(full)
@@ -143,7 +140,7 @@ class UlyssesAttenCarve(torch.nn.Module):
         o_recv = torch.empty((N, S_loc, Hn, D), dtype=dt, device=dev)
         dist.all_to_all_single(o_recv, o_img, group=pg)
         result = torch.empty((B, S_loc + S_txt, H, D), dtype=dt, device=dev)
-        _unpack_heads(o_recv.view(N, B, S_loc, Hn, D), N, result[:, :S_loc])
+        self.unpack_fn(o_recv.view(N, B, S_loc, Hn, D), N, result[:, :S_loc])
         txt_parts = [torch.empty((B, S_txt, Hn, D), dtype=dt, device=dev) for _ in range(N)]
         dist.all_gather(txt_parts, out[:, S_img:].contiguous(), group=pg)
         result[:, S_loc:] = torch.cat(txt_parts, dim=2)

@@ -42,3 +42,19 @@ def simulate(q_shards, k_shards, v_shards, q_txt, k_txt, v_txt, top_k, n_valid_t
         txt = np.concatenate([outs[p_][:, S_img:] for p_ in range(N)], axis=2)
         results.append(np.concatenate([img, txt], axis=1))
     return results
+
+
+def pack_heads(t, n_ranks):
+    """Stand-in for jenga_ulysses_pack_heads on CPU tensors (tests only): [B,S_loc,H,D] -> peer-major
+    [N,B,S_loc,H/N,D], rank r receives the contiguous head slice [r*H/N, (r+1)*H/N)."""
+    B, S, H, D = t.shape
+    return t.reshape(B, S, n_ranks, H // n_ranks, D).permute(2, 0, 1, 3, 4).contiguous()
+
+
+def unpack_heads(recv, n_ranks, out):
+    """Stand-in for jenga_ulysses_unpack_heads on CPU tensors (tests only): peer-major [N,B,S_loc,H/N,D] -> out
+    [B,S_loc,H,D]."""
+    Np, B, S, Hn, D = recv.shape
+    out.copy_(recv.permute(1, 2, 0, 3, 4).reshape(B, S, Np * Hn, D))
+    return out
+

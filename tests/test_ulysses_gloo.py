@@ -62,7 +62,8 @@ def _worker(rank, world, port, ret):
         n_valid = 70
         cu = torch.tensor([0, S_loc + n_valid, S_loc + tb * 128], dtype=torch.int32)
         top_k_local = int((1 - 0.5) * (S_loc // 128))                   # models_mul...:242 on the LOCAL block count
-        sp = ulysses.UlyssesAttenCarve(attn_fn=_oracle_attn)
+        from oracle import ulysses as ou
+        sp = ulysses.UlyssesAttenCarve(attn_fn=_oracle_attn, pack_fn=ou.pack_heads, unpack_fn=ou.unpack_heads)
         out = my_parallel_attention(sp, loc(q), loc(k), loc(v), img_q_len=S_loc, img_kv_len=S_loc, cu_seqlens_q=cu,
                                     cu_seqlens_kv=cu, top_k=world * top_k_local, text_amp=0.25,
                                     block_neighbor_list=torch.from_numpy(nbm), p_remain_rates=0.3)
