@@ -125,3 +125,46 @@ def wan_block_inputs():
     ctx = (torch.randn(1, c["ctx_len"], dim, generator=gen)).to(torch.bfloat16)
     remap = torch.randperm(L, generator=gen)
     return dict(state=sd, x=x, e=e, context=ctx, remap=remap)
+
+
+# ---- HunyuanVideo DiT blocks (hyvideo/modules/models_mul_block_gc_ha_multigpu.py:41-316, 318-500) -----------------
+HY_BLOCK = dict(hidden=256, heads=2, mlp_ratio=4, grid=(2, 8, 32), s_txt=256, valid_txt=70, sa_drop_rate=0.5,
+                txt_amp=0.3, p_remain=0.3, dtype="float16")
+
+
+def _lin(gen, out_f, in_f, std):
+    return torch.randn(out_f, in_f, generator=gen) * std, torch.randn(out_f, generator=gen) * 0.02
+
+
+def hy_block_inputs():
+    """Seeded fp16 state dicts with the reference's parameter names for one MMSingleStreamBlock and one
+    MMDoubleStreamBlock, their inputs and cu_seqlens.  fp16 because the reference's Triton kernel only runs in fp16
+    under the CPU interpreter."""
+    c = HY_BLOCK
+    C, H = c["hidden"], c["heads"]
+    M = C * c["mlp_ratio"]
+    gen = torch.Generator().manual_seed(777)
+    h = lambda t: t.to(torch.float16)
+    single = {}
+    w, b = _lin(gen, 3 * C + M, C, 0.06); single["linear1.weight"], single["linear1.bias"] = h(w), h(b)
+    w, b = _lin(gen, C, C + M, 0.05); single["linear2.weight"], single["linear2.bias"] = h(w), h(b)
+    single["q_norm.weight"] = h(1 + 0.1 * torch.randn(128, generator=gen))
+    single["k_norm.weight"] = h(1 + 0.1 * torch.randn(128, generator=gen))
+    w, b = _lin(gen, 3 * C, C, 0.04); single["modulation.linear.weight"], single["modulation.linear.bias"] = h(w), h(b)
+    double = {}
+    for s_ in ("img", "txt"):
+        w, b = _lin(gen, 6 * C, C, 0.04); double[f"{s_}_mod.linear.weight"], double[f"{s_}_mod.linear.bias"] = h(w), h(b)
+        w, b = _lin(gen, 3 * C, C, 0.06); double[f"{s_}_attn_qkv.weight"], double[f"{s_}_attn_qkv.bias"] = h(w), h(b)
+        double[f"{s_}_attn_q_norm.weight"] = h(1 + 0.1 * torch.randn(128, generator=gen))
+        double[f"{s_}_attn_k_norm.weight"] = h(1 + 0.1 * torch.randn(128, generator=gen))
+        w, b = _lin(gen, C, C, 0.06); double[f"{s_}_attn_proj.weight"], double[f"{s_}_attn_proj.bias"] = h(w), h(b)
+        w, b = _lin(gen, M, C, 0.06); double[f"{s_}_mlp.fc1.weight"], double[f"{s_}_mlp.fc1.bias"] = h(w), h(b)
+        w, b = _lin(gen, C, M, 0.04); double[f"{s_}_mlp.fc2.weight"], double[f"{s_}_mlp.fc2.bias"] = h(w), h(b)
+    f_, hh, ww = c["grid"]
+    S_img = f_ * hh * ww
+    x = h(torch.randn(1, S_img + c["s_txt"], C, generator=gen))
+    img = h(torch.randn(1, S_img, C, generator=gen))
+    txt = h(torch.randn(1, c["s_txt"], C, generator=gen))
+    vec = h(torch.randn(1, C, generator=gen))
+    cu = torch.tensor([0, S_img + c["valid_txt"], S_img + c["s_txt"]], dtype=torch.int32)
+    return dict(single=single, double=double, x=x, img=img, txt=txt, vec=vec, cu=cu, S_img=S_img)

@@ -316,6 +316,57 @@ def gen_wan_block():
     np.savez_compressed(os.path.join(OUT, "wan_block_case.npz"), **out)
 
 
+def gen_hy_blocks():
+    """The reference's MMSingleStreamBlock / MMDoubleStreamBlock (models_mul_block_gc_ha_multigpu.py) run on CPU in
+    fp16 with the Jenga path on: real Gilbert neighbours, block selection, the Triton kernel under TRITON_INTERPRET=1,
+    text rows through the SDPA stand-in for flash_attn_func.  diffusers / xfuser are absent and only supply base
+    classes / group accessors: stubbed for the import."""
+    for name in ("diffusers", "diffusers.configuration_utils", "diffusers.models", "xfuser", "xfuser.core",
+                 "xfuser.core.distributed"):
+        sys.modules.setdefault(name, types.ModuleType(name))
+    sys.modules["diffusers.configuration_utils"].ConfigMixin = type("ConfigMixinStub", (), {})
+    sys.modules["diffusers.configuration_utils"].register_to_config = lambda f: f
+    sys.modules["diffusers.models"].ModelMixin = type("ModelMixinStub", (torch.nn.Module,), {})
+    xd = sys.modules["xfuser.core.distributed"]
+    xd.get_sequence_parallel_world_size = lambda: 1
+    xd.get_sequence_parallel_rank = lambda: 0
+    xd.get_sp_group = lambda: None
+    _install_flash_stub()
+    torch.cuda.device = lambda *_a, **_k: contextlib.nullcontext()
+    for name, sub in (("refhyv", ""), ("refhyv.modules", "modules"), ("refhyv.utils", "utils")):
+        pkg = types.ModuleType(name)
+        pkg.__path__ = [os.path.join(REF, "hyvideo", sub)]
+        sys.modules[name] = pkg
+    import importlib
+    mm = importlib.import_module("refhyv.modules.models_mul_block_gc_ha_multigpu")
+    pe = importlib.import_module("refhyv.modules.posemb_layers")
+    g = sys.modules.get("ref_gilbert") or _load("ref_gilbert", "gilbert.py")
+    c = inputs.HY_BLOCK
+    inp = inputs.hy_block_inputs()
+    dt = torch.float16
+    nbm = g.gilbert_block_neighbor_mapping(*c["grid"], block_size=128)
+    l2h, h2l = g.gilbert_mapping(*c["grid"])
+    curve = [[torch.tensor(l2h), torch.tensor(h2l), nbm]]
+    cos, sin = pe.get_nd_rotary_pos_embed([16, 56, 56], list(c["grid"]), theta=256, use_real=True,
+                                          theta_rescale_factor=1)
+    S = inp["S_img"] + c["s_txt"]
+    sb = mm.MMSingleStreamBlock(c["hidden"], c["heads"], mlp_width_ratio=c["mlp_ratio"], dtype=dt)
+    sb.load_state_dict(inp["single"], strict=True)
+    db = mm.MMDoubleStreamBlock(c["hidden"], c["heads"], c["mlp_ratio"], qkv_bias=True, dtype=dt)
+    db.load_state_dict(inp["double"], strict=True)
+    out = {}
+    y = sb(inp["x"], inp["vec"], c["s_txt"], inp["cu"], inp["cu"], S, S, (cos, sin), c["sa_drop_rate"], c["txt_amp"],
+           curve, c["p_remain"])
+    out["single_out"] = y.numpy()
+    yi, yt = db(inp["img"], inp["txt"], inp["vec"], inp["cu"], inp["cu"], S, S, (cos, sin), c["sa_drop_rate"],
+                c["txt_amp"], curve, c["p_remain"])
+    out["double_img"], out["double_txt"] = yi.numpy(), yt.numpy()
+    out["neighbors"] = nbm.numpy()
+    out["inputs_sha"] = np.array(sha(np.concatenate([inp["x"].numpy().ravel(), inp["vec"].numpy().ravel(),
+                                                     inp["double"]["txt_mlp.fc2.weight"].numpy().ravel()])))
+    np.savez_compressed(os.path.join(OUT, "hy_blocks_case.npz"), **out)
+
+
 def gen_scheduler():
     """FlowMatchDiscreteScheduler (diffusers absent -> its three imports are stubbed for the import only)."""
     import dataclasses
@@ -368,7 +419,7 @@ if __name__ == "__main__":
     ap.add_argument("--only", default="")
     a = ap.parse_args()
     torch.set_grad_enabled(False)
-    if a.only not in ("wan", "sched", "wanblock"):
+    if a.only not in ("wan", "sched", "wanblock", "hyblocks"):
         gen_gilbert(a.big)
     if a.only in ("", "select", "attn"):
         gen_select()
@@ -380,6 +431,8 @@ if __name__ == "__main__":
         gen_wan()
     if a.only in ("", "wan", "wanblock"):
         gen_wan_block()
+    if a.only in ("", "hyblocks"):
+        gen_hy_blocks()
     if a.only in ("", "sched"):
         gen_scheduler()
     print("golden fixtures written to", OUT)

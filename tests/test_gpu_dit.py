@@ -263,3 +263,43 @@ def test_i2v_token_replace_block_and_forward(dev):
     assert torch.equal(seen["first_frame_mask"], expect[m.hilbert_order]) and seen["token_replace_vec"] is not None
     assert torch.isfinite(y_i2v.float()).all() and not torch.equal(y_i2v, y_t2v)
     m.i2v_condition_type = None
+
+
+def test_hy_blocks_vs_reference_blocks(dev):
+    """MMSingleStreamBlock / MMDoubleStreamBlock against the reference's own blocks run on CPU in fp16 with the Jenga
+    path on (tests/golden/make_golden.py gen_hy_blocks: real neighbours, block selection, the Triton kernel under the
+    interpreter).  Same state dict (the parameter names are the reference's), same inputs.  fp16 outputs at |x| <= ~6:
+    the bound is two fp16 ulps of the value plus the GEMM summation-order noise of the block's branches."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import inputs
+    from jenga_amd import dit
+    from jenga_amd.modules.posemb_layers import get_nd_rotary_pos_embed
+    c = inputs.HY_BLOCK
+    inp = inputs.hy_block_inputs()
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "hy_blocks_case.npz"))
+    dt = torch.float16
+    nbm = torch.from_numpy(g["neighbors"]).to(dev)
+    curve = [[None, None, nbm]]
+    cos, sin = get_nd_rotary_pos_embed([16, 56, 56], list(c["grid"]), theta=256, use_real=True, theta_rescale_factor=1)
+    cos, sin = cos.to(dev), sin.to(dev)
+    S = inp["S_img"] + c["s_txt"]
+    cu = inp["cu"].to(dev)
+    sb = dit.MMSingleStreamBlock(c["hidden"], c["heads"], c["mlp_ratio"], dtype=dt, device=dev)
+    missing, unexpected = sb.load_state_dict(inp["single"], strict=False)
+    assert not missing and not unexpected, (missing, unexpected)
+    db = dit.MMDoubleStreamBlock(c["hidden"], c["heads"], c["mlp_ratio"], dtype=dt, device=dev)
+    missing, unexpected = db.load_state_dict(inp["double"], strict=False)
+    assert not missing and not unexpected, (missing, unexpected)
+    y = sb(inp["x"].to(dev), inp["vec"].to(dev), c["s_txt"], cu, cu, S, S, (cos, sin), c["sa_drop_rate"], c["txt_amp"],
+           curve, c["p_remain"])
+    yi, yt = db(inp["img"].to(dev), inp["txt"].to(dev), inp["vec"].to(dev), cu, cu, S, S, (cos, sin),
+                c["sa_drop_rate"], c["txt_amp"], curve, c["p_remain"])
+    for name, got, ref in (("single", y, g["single_out"]), ("double_img", yi, g["double_img"]),
+                           ("double_txt", yt, g["double_txt"])):
+        got = got.float().cpu().numpy()
+        ref = ref.astype(np.float32)
+        assert got.shape == ref.shape, (name, got.shape, ref.shape)
+        err = np.abs(got - ref)
+        bound = 2 * np.exp2(np.floor(np.log2(np.maximum(np.abs(ref), 1e-3))) - 10) + 1.2e-2
+        assert (err <= bound).all() and err.mean() <= 1.5e-3, (name, err.max(), err.mean())
