@@ -152,6 +152,7 @@ class WanDiT(nn.Module):
         self.p_remain_rates = 0.8
         self.hilbert_order = self.linear_to_hilbert = self.block_neighbor_list = None
         self.tea = None
+        self.last_computed = None      # whether the last forward ran the blocks (False: TeaCache replayed a residual)
 
     def set_curve(self, linear_to_hilbert, hilbert_order, block_neighbor_list):
         self.linear_to_hilbert, self.hilbert_order, self.block_neighbor_list = (linear_to_hilbert, hilbert_order,
@@ -204,7 +205,7 @@ class WanDiT(nn.Module):
                 return out
             return call
 
-        out, _ = teacache_forward(tokens.float(), e, e0, [run_block(b) for b in self.blocks], self.tea,
+        out, self.last_computed = teacache_forward(tokens.float(), e, e0, [run_block(b) for b in self.blocks], self.tea,
                                   self.hilbert_order, self.linear_to_hilbert, seq_len=seq_len, e=e0, seq_lens=seq_lens,
                                   grid_sizes=grid_sizes, freqs=self.freqs, context=ctx, context_lens=None,
                                   sa_drop_rate=sa_drop_rate, freq_remap=self.hilbert_order,

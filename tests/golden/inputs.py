@@ -168,3 +168,32 @@ def hy_block_inputs():
     vec = h(torch.randn(1, C, generator=gen))
     cu = torch.tensor([0, S_img + c["valid_txt"], S_img + c["s_txt"]], dtype=torch.int32)
     return dict(single=single, double=double, x=x, img=img, txt=txt, vec=vec, cu=cu, S_img=S_img)
+
+
+# ---- Wan2.1 model forward (wan/modules/model_mul.py WanModel + jenga_wan.py teacache_forward) -----------------------
+WAN_MODEL = dict(dim=256, ffn_dim=512, num_heads=2, num_layers=2, text_dim=64, text_len=32, in_dim=16, out_dim=16,
+                 freq_dim=256, latent=(3, 8, 16), steps=7, thresh=0.15, ctx_len=(20, 7))
+
+
+def wan_param(key, shape):
+    """Deterministic tensor for the parameter `key` (reference names), independent of iteration order: linear weights
+    and biases are bf16-representable (autocast's cast of them is then exact), norms / modulation stay fp32."""
+    import zlib
+    gen = torch.Generator().manual_seed(zlib.crc32(key.encode()) & 0x7FFFFFFF)
+    t = torch.randn(*shape, generator=gen)
+    if key.endswith("modulation"):
+        return t / shape[-1] ** 0.5
+    if "norm" in key:
+        return (1 + 0.1 * t) if key.endswith("weight") else 0.1 * t
+    if key.startswith(("time_embedding", "time_projection", "head.head")):      # run in fp32 (autocast(float32))
+        return t * (0.05 if key.endswith("weight") else 0.02)
+    return (t * (0.05 if key.endswith("weight") else 0.02)).to(torch.bfloat16).float()
+
+
+def wan_model_inputs():
+    c = WAN_MODEL
+    gen = torch.Generator().manual_seed(99)
+    x = torch.randn(c["in_dim"], *c["latent"], generator=gen)
+    ctx = [torch.randn(n, c["text_dim"], generator=gen) for n in c["ctx_len"]]      # cond / uncond prompts
+    ts = [900.0, 899.95, 899.9, 899.8, 899.5, 899.0, 898.0][: c["steps"]]
+    return dict(x=x, context=ctx, timesteps=ts)

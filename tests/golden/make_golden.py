@@ -367,6 +367,88 @@ def gen_hy_blocks():
     np.savez_compressed(os.path.join(OUT, "hy_blocks_case.npz"), **out)
 
 
+def gen_wan_forward():
+    """The reference WanModel (small) driven by the reference's own Jenga forward: `teacache_forward` is taken out of
+    jenga_wan.py by name (the script itself imports the whole pipeline zoo) and bound to the model with the attributes
+    its main() sets (:1066-1098).  CPU autocast stands in for the CUDA one: bfloat16 outside, disabled where the
+    reference asks for float32.  Dense attention (sa_drop_rate 0); two CFG streams per step."""
+    import ast
+    import importlib
+    for name in ("diffusers", "diffusers.configuration_utils", "diffusers.models", "diffusers.models.modeling_utils"):
+        sys.modules.setdefault(name, types.ModuleType(name))
+    sys.modules["diffusers.configuration_utils"].ConfigMixin = type("ConfigMixinStub2", (), {})
+    sys.modules["diffusers.configuration_utils"].register_to_config = lambda f: f
+    sys.modules["diffusers.models.modeling_utils"].ModelMixin = torch.nn.Module
+    _install_flash_stub()
+    if "refwan" not in sys.modules:
+        pkg = types.ModuleType("refwan"); pkg.__path__ = [os.path.join(REF, "wan", "modules")]
+        sys.modules["refwan"] = pkg
+    mm = importlib.import_module("refwan.model_mul")
+    g = sys.modules.get("ref_gilbert") or _load("ref_gilbert", "gilbert.py")
+
+    def cpu_autocast(dtype=None, enabled=True):
+        if not enabled or dtype == torch.float32:
+            return torch.autocast("cpu", enabled=False)
+        return torch.autocast("cpu", dtype=dtype)
+
+    amp_cpu = types.SimpleNamespace(autocast=cpu_autocast)
+    mm.amp = amp_cpu
+
+    def cpu_flash(q, k, v, q_lens=None, k_lens=None, dropout_p=0., softmax_scale=None, q_scale=None, causal=False,
+                  window_size=(-1, -1), deterministic=False, dtype=torch.bfloat16, version=None):
+        out_dtype = q.dtype
+        half = lambda t: t if t.dtype in (torch.float16, torch.bfloat16) else t.to(dtype)
+        qh, kh, vh = half(q), half(k), half(v)
+        qh, kh = qh.to(vh.dtype), kh.to(vh.dtype)
+        B, Lq, N, D = qh.shape
+        sc = torch.einsum("bqnd,bknd->bnqk", qh.float(), kh.float()) * (softmax_scale or D ** -0.5)
+        if k_lens is not None:
+            kl = torch.as_tensor(k_lens).view(B, 1, 1, 1)
+            sc = sc.masked_fill(torch.arange(kh.shape[1]).view(1, 1, 1, -1) >= kl, float("-inf"))
+        o = torch.einsum("bnqk,bknd->bqnd", torch.softmax(sc, dim=-1), vh.float()).to(vh.dtype)
+        return o.type(out_dtype)
+
+    mm.flash_attention = cpu_flash
+    src = open(os.path.join(REF, "jenga_wan.py")).read()
+    fn = next(n for n in ast.parse(src).body if isinstance(n, ast.FunctionDef) and n.name == "teacache_forward")
+    ns = {"torch": torch, "np": np, "amp": amp_cpu, "sinusoidal_embedding_1d": mm.sinusoidal_embedding_1d}
+    exec(compile(ast.Module(body=[fn], type_ignores=[]), "jenga_wan.py:teacache_forward", "exec"), ns)
+    c = inputs.WAN_MODEL
+    inp = inputs.wan_model_inputs()
+    model = mm.WanModel(model_type="t2v", patch_size=(1, 2, 2), text_len=c["text_len"], in_dim=c["in_dim"],
+                        dim=c["dim"], ffn_dim=c["ffn_dim"], freq_dim=c["freq_dim"], text_dim=c["text_dim"],
+                        out_dim=c["out_dim"], num_heads=c["num_heads"], num_layers=c["num_layers"],
+                        cross_attn_norm=True)
+    sd = {k_: inputs.wan_param(k_, tuple(v_.shape)) for k_, v_ in model.state_dict().items()}
+    model.load_state_dict(sd, strict=True)
+    F_, H_, W_ = c["latent"]
+    grid = (F_, H_ // 2, W_ // 2)
+    l2h, h2l = g.sliced_gilbert_mapping(*grid)
+    nbm = g.sliced_gilbert_block_neighbor_mapping(*grid)
+    K = type(model)
+    K.enable_teacache, K.cnt, K.num_steps, K.teacache_thresh = True, 0, c["steps"] * 2, c["thresh"]
+    K.accumulated_rel_l1_distance_even = K.accumulated_rel_l1_distance_odd = 0
+    K.previous_e0_even = K.previous_e0_odd = K.previous_residual_even = K.previous_residual_odd = None
+    K.use_ref_steps, K.use_cache, K.stage_start = False, False, False
+    K.linear_to_hilbert, K.hilbert_order = torch.tensor(l2h, dtype=torch.long), torch.tensor(h2l, dtype=torch.long)
+    K.block_neighbor_list, K.p_remain_rates = nbm, 0.8
+    K.coefficients = [2.39676752e+03, -1.31110545e+03, 2.01331979e+02, -8.29855975e+00, 1.37887774e-01]
+    K.ret_steps, K.cutoff_steps = 1 * 2, c["steps"] * 2 - 2
+    L = grid[0] * grid[1] * grid[2]
+    out, used_cache = {}, []
+    with torch.autocast("cpu", dtype=torch.bfloat16):
+        for i, t in enumerate(inp["timesteps"]):
+            for j, ctx in enumerate(inp["context"]):
+                y = ns["teacache_forward"](model, [inp["x"]], t=torch.tensor([t]), context=[ctx], seq_len=L,
+                                           sa_drop_rate=0.0)[0]
+                out[f"out_{i}_{j}"] = y.numpy()
+                used_cache.append(bool(model.use_cache))
+    out["used_cache"] = np.array(used_cache)
+    out["inputs_sha"] = np.array(sha(np.concatenate([inp["x"].numpy().ravel(), sd["blocks.1.ffn.2.weight"].numpy().ravel()])))
+    print("teacache used_cache per call:", used_cache)
+    np.savez_compressed(os.path.join(OUT, "wan_forward_case.npz"), **out)
+
+
 def gen_scheduler():
     """FlowMatchDiscreteScheduler (diffusers absent -> its three imports are stubbed for the import only)."""
     import dataclasses
@@ -419,7 +501,7 @@ if __name__ == "__main__":
     ap.add_argument("--only", default="")
     a = ap.parse_args()
     torch.set_grad_enabled(False)
-    if a.only not in ("wan", "sched", "wanblock", "hyblocks"):
+    if a.only not in ("wan", "sched", "wanblock", "hyblocks", "wanforward"):
         gen_gilbert(a.big)
     if a.only in ("", "select", "attn"):
         gen_select()
@@ -433,6 +515,8 @@ if __name__ == "__main__":
         gen_wan_block()
     if a.only in ("", "hyblocks"):
         gen_hy_blocks()
+    if a.only in ("", "wan", "wanforward"):
+        gen_wan_forward()
     if a.only in ("", "sched"):
         gen_scheduler()
     print("golden fixtures written to", OUT)

@@ -156,3 +156,43 @@ def test_wan_dit_forward_end_to_end(dev):
         m(x, torch.tensor([900.0 - 10 * (i // 2)], device=dev), ctx, seq_len=L, sa_drop_rate=0.0)
         calls.append((before, m.tea.residual[before % 2] is not None))
     assert m.tea.cnt == 6 and all(r for _, r in calls)
+
+
+def test_wan_dit_forward_vs_reference_model_and_teacache(dev):
+    """WanDiT against the reference WanModel driven by the reference's own `teacache_forward` (jenga_wan.py) on CPU:
+    same parameters (reference state-dict names; the Conv3d patch kernel flattened), 7 steps x 2 CFG streams with
+    timesteps chosen so that the TeaCache rule skips some forwards.  The skip decisions must be identical, the outputs
+    equal up to bf16 GEMM noise through two blocks."""
+    from jenga_amd import gilbert as G
+    from jenga_amd.wan_dit import WanDiT
+    c = inputs.WAN_MODEL
+    inp = inputs.wan_model_inputs()
+    g = np.load(os.path.join(GOLD, "wan_forward_case.npz"))
+    m = WanDiT(text_len=c["text_len"], in_dim=c["in_dim"], dim=c["dim"], ffn_dim=c["ffn_dim"], freq_dim=c["freq_dim"],
+               text_dim=c["text_dim"], out_dim=c["out_dim"], num_heads=c["num_heads"], num_layers=c["num_layers"],
+               cross_attn_norm=True, dtype=torch.bfloat16, device=dev)
+    sd = {}
+    for k_, v_ in m.state_dict().items():
+        if k_ == "patch_embedding.weight":
+            sd[k_] = inputs.wan_param(k_, (c["dim"], c["in_dim"], 1, 2, 2)).reshape(c["dim"], -1)
+        else:
+            sd[k_] = inputs.wan_param(k_, tuple(v_.shape))
+    m.load_state_dict(sd, strict=True)
+    F_, H_, W_ = c["latent"]
+    grid = (F_, H_ // 2, W_ // 2)
+    L = grid[0] * grid[1] * grid[2]
+    l2h, h2l = G.sliced_gilbert_mapping(*grid, as_tensor=True)
+    m.set_curve(l2h, h2l, G.sliced_gilbert_block_neighbor_mapping(*grid, as_tensor=True))
+    m.enable_teacache(num_steps=c["steps"], thresh=c["thresh"], task="t2v-1.3B", use_ret_steps=False, enable=True)
+    used_cache = []
+    call = 0
+    for i, t in enumerate(inp["timesteps"]):
+        for j, ctx in enumerate(inp["context"]):
+            y = m([inp["x"].to(dev)], torch.tensor([t], device=dev), [ctx.to(dev)], seq_len=L, sa_drop_rate=0.0)[0]
+            used_cache.append(not m.last_computed)
+            ref = g[f"out_{i}_{j}"]
+            err = np.abs(y.cpu().numpy() - ref)
+            assert err.max() <= 4e-2 * max(1.0, np.abs(ref).max()) and err.mean() <= 4e-3, (i, j, err.max(), err.mean())
+            call += 1
+    assert used_cache == g["used_cache"].tolist(), (used_cache, g["used_cache"].tolist())
+    assert any(used_cache) and not all(used_cache)
