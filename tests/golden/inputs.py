@@ -197,3 +197,31 @@ def wan_model_inputs():
     ctx = [torch.randn(n, c["text_dim"], generator=gen) for n in c["ctx_len"]]      # cond / uncond prompts
     ts = [900.0, 899.95, 899.9, 899.8, 899.5, 899.0, 898.0][: c["steps"]]
     return dict(x=x, context=ctx, timesteps=ts)
+
+
+# ---- HunyuanVideo Jenga forward (jenga_hyvideo.py ra_forward) -------------------------------------------------------
+HY_FORWARD = dict(hidden=256, heads=2, mlp_ratio=4, depth=(1, 1), latent=(4, 16, 32), text_len=256, text_dim=64,
+                  text_dim_2=32, valid_txt=70, sa_drop_rate=0.5, txt_amp=0.2, p_remain=0.3, dtype="float16",
+                  steps=((0, 900.0), (5, 820.0), (7, 700.0)))       # (cnt, timestep): computed, skipped, computed
+
+
+def hy_param(key, shape):
+    """Deterministic fp16-representable tensor for parameter `key` of the tiny DiT (names shared by the reference
+    blocks and jenga_amd.dit)."""
+    import zlib
+    gen = torch.Generator().manual_seed(zlib.crc32(("hy:" + key).encode()) & 0x7FFFFFFF)
+    t = torch.randn(*shape, generator=gen)
+    if "_norm.weight" in key or key.endswith("norm.weight"):
+        return (1 + 0.1 * t).to(torch.float16)
+    return (t * (0.05 if len(shape) >= 2 else 0.02)).to(torch.float16)
+
+
+def hy_forward_inputs():
+    c = HY_FORWARD
+    gen = torch.Generator().manual_seed(2024)
+    x = torch.randn(1, 16, *c["latent"], generator=gen).to(torch.float16)
+    text = torch.randn(1, c["text_len"], c["text_dim"], generator=gen).to(torch.float16)
+    text2 = torch.randn(1, c["text_dim_2"], generator=gen).to(torch.float16)
+    mask = torch.zeros(1, c["text_len"], dtype=torch.int64)
+    mask[:, : c["valid_txt"]] = 1
+    return dict(x=x, text=text, text2=text2, mask=mask, guidance=6000.0)

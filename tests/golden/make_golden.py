@@ -449,6 +449,109 @@ def gen_wan_forward():
     np.savez_compressed(os.path.join(OUT, "wan_forward_case.npz"), **out)
 
 
+def gen_hy_forward():
+    """The reference's Jenga forward `ra_forward` (lifted out of jenga_hyvideo.py by name, together with its
+    `non_skip_steps` list) run over the reference's own DiT blocks on CPU in fp16.  `self` is a harness module whose
+    embedders / final layer are the plain-linear stand-ins jenga_amd.dit uses in place of the token refiner etc. (they
+    are outside the hot path); everything ra_forward itself does -- curve gather of tokens and RoPE rows, cu_seqlens,
+    the 12-argument block calls, the step-skip residual cache, scatter, unpatchify -- is the reference's code."""
+    import ast
+    import importlib
+    import math
+    from typing import Optional
+    gen_hy_blocks_env = sys.modules.get("refhyv.modules.models_mul_block_gc_ha_multigpu")
+    if gen_hy_blocks_env is None:
+        gen_hy_blocks()                      # installs the stubs / synthetic packages and imports the module
+    mm = sys.modules["refhyv.modules.models_mul_block_gc_ha_multigpu"]
+    pe = importlib.import_module("refhyv.modules.posemb_layers")
+    g = sys.modules.get("ref_gilbert") or _load("ref_gilbert", "gilbert.py")
+    tree = ast.parse(open(os.path.join(REF, "jenga_hyvideo.py")).read())
+    fn = next(n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == "ra_forward")
+    nss = next(n for n in tree.body if isinstance(n, ast.Assign) and getattr(n.targets[0], "id", "") == "non_skip_steps")
+
+    def get_cu_seqlens_cpu(text_mask, img_len):      # attenion.py:34-57 hard-codes device="cuda"; same arithmetic
+        B, L = text_mask.shape
+        cu = torch.zeros(2 * B + 1, dtype=torch.int32)
+        for i in range(B):
+            s = int(text_mask[i].sum()) + img_len
+            cu[2 * i + 1] = i * (L + img_len) + s
+            cu[2 * i + 2] = (i + 1) * (L + img_len)
+        return cu
+
+    ns = {"torch": torch, "Optional": Optional, "get_cu_seqlens": get_cu_seqlens_cpu}
+    exec(compile(ast.Module(body=[nss, fn], type_ignores=[]), "jenga_hyvideo.py:ra_forward", "exec"), ns)
+    c = inputs.HY_FORWARD
+    inp = inputs.hy_forward_inputs()
+    dt = torch.float16
+    C = c["hidden"]
+
+    class Harness(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.patch_size, self.unpatchify_channels = [1, 2, 2], 16
+            self.guidance_embed, self.text_projection, self.use_attention_mask = True, "linear", True
+            lin = lambda i, o: torch.nn.Linear(i, o, dtype=dt)
+            self.img_in_l, self.txt_in, self.vector_in = lin(64, C), lin(c["text_dim"], C), lin(c["text_dim_2"], C)
+            self.time_in_l, self.guidance_in_l = lin(256, C), lin(256, C)
+            self.final_mod, self.final_linear = lin(C, 2 * C), lin(C, 64)
+            self.double_blocks = torch.nn.ModuleList(
+                [mm.MMDoubleStreamBlock(C, c["heads"], c["mlp_ratio"], qkv_bias=True, dtype=dt) for _ in range(c["depth"][0])])
+            self.single_blocks = torch.nn.ModuleList(
+                [mm.MMSingleStreamBlock(C, c["heads"], mlp_width_ratio=c["mlp_ratio"], dtype=dt) for _ in range(c["depth"][1])])
+
+        @staticmethod
+        def sinus(t, dim=256):
+            half = dim // 2
+            f = torch.exp(-math.log(10000) * torch.arange(half, dtype=torch.float32) / half)
+            a = t.float()[:, None] * f[None]
+            return torch.cat([a.cos(), a.sin()], dim=-1)
+
+        def time_in(self, t):
+            return self.time_in_l(self.sinus(t).to(dt))
+
+        def guidance_in(self, gd):
+            return self.guidance_in_l(self.sinus(gd).to(dt))
+
+        def img_in(self, x):
+            B, Cc, T, Hh, W = x.shape
+            x = x.view(B, Cc, T, 1, Hh // 2, 2, W // 2, 2).permute(0, 2, 4, 6, 1, 3, 5, 7)
+            return self.img_in_l(x.reshape(B, T * (Hh // 2) * (W // 2), Cc * 4))
+
+        def final_layer(self, img, vec):
+            shift, scale = self.final_mod(torch.nn.functional.silu(vec)).chunk(2, dim=1)
+            n = torch.nn.functional.layer_norm(img, (C,), eps=1e-6)
+            return self.final_linear(n * (1 + scale.unsqueeze(1)) + shift.unsqueeze(1))
+
+        unpatchify = mm.HYVideoDiffusionTransformer.unpatchify
+
+    h = Harness()
+    rename = {"img_in_l": "img_in", "time_in_l": "time_in", "guidance_in_l": "guidance_in"}
+    sd = {}
+    for k_, v_ in h.state_dict().items():
+        head = k_.split(".")[0]
+        sd[k_] = inputs.hy_param(k_.replace(head, rename.get(head, head), 1), tuple(v_.shape))
+    h.load_state_dict(sd, strict=True)
+    T, Hh, W = c["latent"]
+    grid = (T, Hh // 2, W // 2)
+    l2h, h2l = g.gilbert_mapping(*grid)
+    nbm = g.gilbert_block_neighbor_mapping(*grid, block_size=128)
+    h.linear_to_hilbert, h.hilbert_order = torch.tensor(l2h, dtype=torch.long), torch.tensor(h2l, dtype=torch.long)
+    h.curve_sel = [[h.linear_to_hilbert, h.hilbert_order, nbm]]
+    h.enable_skip, h.num_steps, h.start_stage, h.previous_residual = True, 50, False, None
+    h.sa_drop_rate, h.text_amp, h.p_remain_rates = c["sa_drop_rate"], c["txt_amp"], c["p_remain"]
+    cos, sin = pe.get_nd_rotary_pos_embed([16, 56, 56], list(grid), theta=256, use_real=True, theta_rescale_factor=1)
+    out = {"non_skip_steps": np.array(ns["non_skip_steps"])}
+    for cnt, t in c["steps"]:
+        h.cnt = cnt
+        y = ns["ra_forward"](h, inp["x"], torch.tensor([t]), text_states=inp["text"], text_mask=inp["mask"],
+                             text_states_2=inp["text2"], freqs_cos=cos, freqs_sin=sin,
+                             guidance=torch.tensor([inp["guidance"]]), return_dict=False)
+        out[f"out_cnt{cnt}"] = y.numpy()
+        assert h.cnt == cnt + 1
+    out["inputs_sha"] = np.array(sha(np.concatenate([inp["x"].numpy().ravel(), sd["final_linear.weight"].numpy().ravel()])))
+    np.savez_compressed(os.path.join(OUT, "hy_forward_case.npz"), **out)
+
+
 def gen_scheduler():
     """FlowMatchDiscreteScheduler (diffusers absent -> its three imports are stubbed for the import only)."""
     import dataclasses
@@ -501,7 +604,7 @@ if __name__ == "__main__":
     ap.add_argument("--only", default="")
     a = ap.parse_args()
     torch.set_grad_enabled(False)
-    if a.only not in ("wan", "sched", "wanblock", "hyblocks", "wanforward"):
+    if a.only not in ("wan", "sched", "wanblock", "hyblocks", "wanforward", "hyforward"):
         gen_gilbert(a.big)
     if a.only in ("", "select", "attn"):
         gen_select()
@@ -515,6 +618,8 @@ if __name__ == "__main__":
         gen_wan_block()
     if a.only in ("", "hyblocks"):
         gen_hy_blocks()
+    if a.only in ("", "hyforward"):
+        gen_hy_forward()
     if a.only in ("", "wan", "wanforward"):
         gen_wan_forward()
     if a.only in ("", "sched"):

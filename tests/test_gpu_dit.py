@@ -303,3 +303,40 @@ def test_hy_blocks_vs_reference_blocks(dev):
         err = np.abs(got - ref)
         bound = 2 * np.exp2(np.floor(np.log2(np.maximum(np.abs(ref), 1e-3))) - 10) + 1.2e-2
         assert (err <= bound).all() and err.mean() <= 1.5e-3, (name, err.max(), err.mean())
+
+
+def test_jenga_forward_vs_reference_ra_forward(dev):
+    """JengaHYVideoDiT.forward against the reference's `ra_forward` (taken out of jenga_hyvideo.py) run over the
+    reference's own blocks on CPU in fp16 (tests/golden/make_golden.py gen_hy_forward): a computed step, a skipped step
+    replaying the cached residual, another computed step.  Pins the curve gather of tokens and RoPE rows, cu_seqlens,
+    the block-call convention, the non_skip_steps list, scatter and unpatchify."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import inputs
+    from jenga_amd import dit
+    c = inputs.HY_FORWARD
+    inp = inputs.hy_forward_inputs()
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "hy_forward_case.npz"))
+    assert list(g["non_skip_steps"]) == list(dit.NON_SKIP_STEPS)
+    dit.HUNYUAN_VIDEO_CONFIG["tiny_fwd"] = dict(mm_double_blocks_depth=c["depth"][0], mm_single_blocks_depth=c["depth"][1],
+                                                rope_dim_list=[16, 56, 56], hidden_size=c["hidden"],
+                                                heads_num=c["heads"], mlp_width_ratio=c["mlp_ratio"], guidance_embed=True)
+    m = dit.JengaHYVideoDiT(config="tiny_fwd", text_states_dim=c["text_dim"], text_states_dim_2=c["text_dim_2"],
+                            dtype=torch.float16, device=dev)
+    sd = {k_: inputs.hy_param(k_, tuple(v_.shape)) for k_, v_ in m.state_dict().items()}
+    m.load_state_dict(sd, strict=True)
+    cos, sin = m.set_stage(c["latent"], dev)
+    m.enable_skip, m.num_steps, m.start_stage, m.previous_residual = True, 50, False, None
+    m.sa_drop_rate, m.text_amp, m.p_remain_rates = c["sa_drop_rate"], c["txt_amp"], c["p_remain"]
+    gd = torch.tensor([inp["guidance"]], device=dev)
+    for cnt, t in c["steps"]:
+        m.cnt = cnt
+        y = m(inp["x"].to(dev), torch.tensor([t], device=dev), inp["text"].to(dev), inp["mask"].to(dev),
+              inp["text2"].to(dev), cos, sin, gd, return_dict=False)
+        assert m.cnt == cnt + 1
+        ref = g[f"out_cnt{cnt}"].astype(np.float32)
+        got = y.float().cpu().numpy()
+        assert got.shape == ref.shape
+        err = np.abs(got - ref)
+        bound = 2 * np.exp2(np.floor(np.log2(np.maximum(np.abs(ref), 1e-3))) - 10) + 1.5e-2
+        assert (err <= bound).all() and err.mean() <= 2e-3, (cnt, err.max(), err.mean())
