@@ -225,3 +225,26 @@ def hy_forward_inputs():
     mask = torch.zeros(1, c["text_len"], dtype=torch.int64)
     mask[:, : c["valid_txt"]] = 1
     return dict(x=x, text=text, text2=text2, mask=mask, guidance=6000.0)
+
+
+# ---- HunyuanVideo-I2V single-stream block with token_replace (hyvideo_i2v/modules/models_mul.py:393-506) -----------
+I2V_BLOCK = dict(hidden=256, heads=2, mlp_ratio=4, grid=(2, 8, 32), s_txt=512, valid_txt=300, sa_drop_rate=0.5,
+                 txt_amp=0.3, p_remain=0.3, dtype="float16")
+
+
+def i2v_block_inputs():
+    c = I2V_BLOCK
+    C = c["hidden"]
+    M = C * c["mlp_ratio"]
+    keys = {"linear1.weight": (3 * C + M, C), "linear1.bias": (3 * C + M,), "linear2.weight": (C, C + M),
+            "linear2.bias": (C,), "q_norm.weight": (128,), "k_norm.weight": (128,),
+            "modulation.linear.weight": (3 * C, C), "modulation.linear.bias": (3 * C,)}
+    sd = {k_: hy_param("i2v." + k_, shp) for k_, shp in keys.items()}
+    gen = torch.Generator().manual_seed(31337)
+    f_, hh, ww = c["grid"]
+    S_img = f_ * hh * ww
+    x = torch.randn(1, S_img + c["s_txt"], C, generator=gen).to(torch.float16)
+    vec = torch.randn(1, C, generator=gen).to(torch.float16)
+    trv = torch.randn(1, C, generator=gen).to(torch.float16)
+    cu = torch.tensor([0, S_img + c["valid_txt"], S_img + c["s_txt"]], dtype=torch.int32)
+    return dict(state=sd, x=x, vec=vec, token_replace_vec=trv, cu=cu, S_img=S_img)

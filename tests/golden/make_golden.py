@@ -552,6 +552,60 @@ def gen_hy_forward():
     np.savez_compressed(os.path.join(OUT, "hy_forward_case.npz"), **out)
 
 
+def gen_i2v_block():
+    """The reference's HunyuanVideo-I2V MMSingleStreamBlock (hyvideo_i2v/modules/models_mul.py) with
+    condition_type="token_replace" on CPU in fp16: first-frame tokens (in curve order) modulated / gated by the
+    timestep-0 vector, the I2V op flavour (pads, text_blocks = 4) with the Triton kernel under the interpreter."""
+    import importlib
+    for name in ("diffusers", "diffusers.configuration_utils", "diffusers.models"):
+        sys.modules.setdefault(name, types.ModuleType(name))
+    if not hasattr(sys.modules["diffusers.configuration_utils"], "ConfigMixin"):
+        sys.modules["diffusers.configuration_utils"].ConfigMixin = type("ConfigMixinStub3", (), {})
+        sys.modules["diffusers.configuration_utils"].register_to_config = lambda f: f
+    if not hasattr(sys.modules["diffusers.models"], "ModelMixin"):
+        sys.modules["diffusers.models"].ModelMixin = type("ModelMixinStub3", (torch.nn.Module,), {})
+    _install_flash_stub()
+    torch.cuda.device = lambda *_a, **_k: contextlib.nullcontext()
+    sys.modules.setdefault("deepspeed", types.ModuleType("deepspeed"))        # imported by utils/helpers.py, unused here
+    try:
+        importlib.import_module("torch.utils.tensorboard")
+    except Exception:
+        tb = types.ModuleType("torch.utils.tensorboard")
+        tb.SummaryWriter = object
+        sys.modules["torch.utils.tensorboard"] = tb
+    for name, sub in (("refi2v", ""), ("refi2v.modules", "modules"), ("refi2v.utils", "utils")):
+        pkg = types.ModuleType(name)
+        pkg.__path__ = [os.path.join(REF, "hyvideo_i2v", sub)]
+        sys.modules[name] = pkg
+    mm = importlib.import_module("refi2v.modules.models_mul")
+    pe = importlib.import_module("refi2v.modules.posemb_layers")
+    g = sys.modules.get("ref_gilbert") or _load("ref_gilbert", "gilbert.py")
+    c = inputs.I2V_BLOCK
+    inp = inputs.i2v_block_inputs()
+    nbm = g.gilbert_block_neighbor_mapping(*c["grid"], block_size=128)
+    l2h, h2l = g.gilbert_mapping(*c["grid"])
+    h2l_t = torch.tensor(h2l, dtype=torch.long)
+    th_tw = c["grid"][1] * c["grid"][2]
+    ffm = torch.zeros(inp["S_img"], dtype=torch.bool)
+    ffm[:th_tw] = True
+    ffm = ffm[h2l_t]                                            # jenga_hyi2v.py:124-126
+    full = torch.zeros(inp["S_img"] + c["s_txt"], dtype=torch.bool)
+    full[: inp["S_img"]] = ffm                                  # :129-130
+    cos, sin = pe.get_nd_rotary_pos_embed([16, 56, 56], list(c["grid"]), theta=256, use_real=True,
+                                          theta_rescale_factor=1)
+    cos, sin = cos[h2l_t], sin[h2l_t]
+    sb = mm.MMSingleStreamBlock(c["hidden"], c["heads"], mlp_width_ratio=c["mlp_ratio"], dtype=torch.float16)
+    sb.load_state_dict(inp["state"], strict=True)
+    S = inp["S_img"] + c["s_txt"]
+    y = sb(inp["x"], inp["vec"], c["s_txt"], inp["cu"], inp["cu"], S, S, (cos, sin), c["sa_drop_rate"], full,
+           "token_replace", inp["token_replace_vec"], th_tw, c["txt_amp"],
+           [[torch.tensor(l2h), h2l_t, nbm]], c["p_remain"])
+    np.savez_compressed(os.path.join(OUT, "i2v_block_case.npz"), out=y.numpy(), neighbors=nbm.numpy(),
+                        first_frame_mask=ffm.numpy(), hilbert_order=h2l_t.numpy(),
+                        inputs_sha=np.array(sha(np.concatenate([inp["x"].numpy().ravel(),
+                                                                inp["state"]["linear2.weight"].numpy().ravel()]))))
+
+
 def gen_scheduler():
     """FlowMatchDiscreteScheduler (diffusers absent -> its three imports are stubbed for the import only)."""
     import dataclasses
@@ -604,7 +658,7 @@ if __name__ == "__main__":
     ap.add_argument("--only", default="")
     a = ap.parse_args()
     torch.set_grad_enabled(False)
-    if a.only not in ("wan", "sched", "wanblock", "hyblocks", "wanforward", "hyforward"):
+    if a.only not in ("wan", "sched", "wanblock", "hyblocks", "wanforward", "hyforward", "i2vblock"):
         gen_gilbert(a.big)
     if a.only in ("", "select", "attn"):
         gen_select()
@@ -620,6 +674,8 @@ if __name__ == "__main__":
         gen_hy_blocks()
     if a.only in ("", "hyforward"):
         gen_hy_forward()
+    if a.only in ("", "i2vblock"):
+        gen_i2v_block()
     if a.only in ("", "wan", "wanforward"):
         gen_wan_forward()
     if a.only in ("", "sched"):

@@ -340,3 +340,34 @@ def test_jenga_forward_vs_reference_ra_forward(dev):
         err = np.abs(got - ref)
         bound = 2 * np.exp2(np.floor(np.log2(np.maximum(np.abs(ref), 1e-3))) - 10) + 1.5e-2
         assert (err <= bound).all() and err.mean() <= 2e-3, (cnt, err.max(), err.mean())
+
+
+def test_i2v_single_block_vs_reference_block(dev):
+    """MMSingleStreamBlock with token_replace against the reference's HunyuanVideo-I2V block
+    (hyvideo_i2v/modules/models_mul.py) run on CPU in fp16: first-frame mask in curve order, four text blocks, the I2V op
+    flavour with the Triton kernel under the interpreter (tests/golden/make_golden.py gen_i2v_block)."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import inputs
+    from jenga_amd import dit
+    from jenga_amd.modules.posemb_layers import get_nd_rotary_pos_embed
+    c = inputs.I2V_BLOCK
+    inp = inputs.i2v_block_inputs()
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "i2v_block_case.npz"))
+    h2l = torch.from_numpy(g["hilbert_order"]).to(dev)
+    cos, sin = get_nd_rotary_pos_embed([16, 56, 56], list(c["grid"]), theta=256, use_real=True, theta_rescale_factor=1)
+    cos, sin = cos.to(dev)[h2l], sin.to(dev)[h2l]
+    sb = dit.MMSingleStreamBlock(c["hidden"], c["heads"], c["mlp_ratio"], dtype=torch.float16, device=dev)
+    missing, unexpected = sb.load_state_dict(inp["state"], strict=False)
+    assert not missing and not unexpected, (missing, unexpected)
+    S = inp["S_img"] + c["s_txt"]
+    cu = inp["cu"].to(dev)
+    y = sb(inp["x"].to(dev), inp["vec"].to(dev), c["s_txt"], cu, cu, S, S, (cos, sin), c["sa_drop_rate"], c["txt_amp"],
+           [[None, None, torch.from_numpy(g["neighbors"]).to(dev)]], c["p_remain"], txt_block_num=4,
+           token_replace_vec=inp["token_replace_vec"].to(dev),
+           first_frame_mask=torch.from_numpy(g["first_frame_mask"]).to(dev))
+    got, ref = y.float().cpu().numpy(), g["out"].astype(np.float32)
+    assert got.shape == ref.shape
+    err = np.abs(got - ref)
+    bound = 2 * np.exp2(np.floor(np.log2(np.maximum(np.abs(ref), 1e-3))) - 10) + 1.2e-2
+    assert (err <= bound).all() and err.mean() <= 1.5e-3, (err.max(), err.mean())
