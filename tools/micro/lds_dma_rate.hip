@@ -38,9 +38,14 @@ __global__ void __launch_bounds__(256, 2) k(const unsigned char* src, size_t spa
     for (int i = 0; i < tiles; ++i) {
         const unsigned char* tile = src + t * 32768 + wave * 8192;
         const unsigned slot = smem_base + (i % 2) * 32768 + wave * 8192;
-        if (MODE == 0) {
-            dma8(tile, slot, lane * 16);
-            dma8(tile + 4096, slot + 4096, lane * 16);
+        if (MODE == 0 || MODE == 2 || MODE == 3) {
+            // MODE 2: the attention kernel's source-side XOR swizzle (lane -> row lane>>4, chunk (lane&15)^row) inside
+            // each contiguous 1 KiB; MODE 3: the same with rows 6 KiB apart ([S,H,D] K layout, 24 heads)
+            unsigned off = lane * 16;
+            if (MODE == 2) off = (lane >> 4) * 256 + (((lane & 15) ^ ((lane >> 4) + 1)) << 4);
+            if (MODE == 3) off = (lane >> 4) * 6144 + (((lane & 15) ^ ((lane >> 4) + 1)) << 4);
+            dma8(tile, slot, off);
+            dma8(tile + 4096, slot + 4096, off);
             asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // previous tile landed, this one in flight
         } else {
             uint4 r[8];
@@ -71,12 +76,14 @@ template <int MODE> void run(const unsigned char* src, size_t span_tiles, int ti
            bytes / ms / 1e9, bytes / 256 / (ms * 1e-3 * 2.0e9));
 }
 int main() {
-    const size_t maxbytes = 2048ull << 20;
+    const size_t maxbytes = (2048ull << 20) + (1 << 20);
     unsigned char* src; hipMalloc(&src, maxbytes); hipMemset(src, 1, maxbytes);
     float* out; hipMalloc(&out, 512 * 256 * 4);
     const int tiles = 2000;
     for (size_t mb : {1ul, 16ul, 128ul, 2048ul}) {
         run<0>(src, (mb << 20) / 32768, tiles, out, "LDS-DMA");
+        run<2>(src, (mb << 20) / 32768, tiles, out, "LDS-DMA, XOR-swizzled source");
+        run<3>(src, (mb << 20) / 32768, tiles, out, "LDS-DMA, swizzled + 6 KiB rows");
         run<1>(src, (mb << 20) / 32768, tiles, out, "global_load + ds_write");
     }
     return 0;
