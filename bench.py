@@ -140,6 +140,14 @@ def main():
     if a.depth:
         kw = dict(depth_double=a.depth[0], depth_single=a.depth[1])
     model = JengaHYVideoDiT(dtype=torch.bfloat16, device=dev, **kw).init_synthetic_weights(0.02, seed=0)
+    if world > 1:
+        # create the RCCL communicator and its channels now, whatever --warmup says (lazy creation costs seconds)
+        w_ = torch.ones(world, 16, device=dev)
+        r_ = torch.empty_like(w_)
+        dist.all_to_all_single(r_, w_)
+        dist.all_gather([torch.empty(16, device=dev) for _ in range(world)], w_[0].contiguous())
+        dist.all_reduce(w_)
+        torch.cuda.synchronize()
     if world > 1 or sim > 1:
         ulysses.init_sequence_parallel()
         for blk in list(model.double_blocks) + list(model.single_blocks):
