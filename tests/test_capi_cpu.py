@@ -54,3 +54,22 @@ def test_argument_errors_mirror_the_reference_contract():
 
 def test_pack_v_bytes():
     assert _capi.lib().jenga_pack_v_bytes(1, 24, 902) == 24 * 902 * 128 * 128 * 2
+
+
+def test_header_is_c99_and_library_links_from_plain_c(tmp_path):
+    """include/jenga_amd.h compiled as C99 (-Wall -Wextra -pedantic) by gcc, linked against libjenga_amd.so and run:
+    the ABI is usable without C++ or Python on the calling side."""
+    import shutil
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        pytest.skip("gcc not available")
+    exe = str(tmp_path / "abi_smoke")
+    libdir = os.path.join(root, "jenga_amd")
+    r = subprocess.run([gcc, "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I" + os.path.join(root, "include"),
+                        os.path.join(root, "tests", "c", "abi_smoke.c"), "-o", exe, "-L" + libdir, "-ljenga_amd",
+                        "-Wl,-rpath," + libdir], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    r = subprocess.run([exe], capture_output=True, text=True)
+    assert r.returncode == 0 and r.stdout.startswith("ok abi="), (r.returncode, r.stdout, r.stderr)
