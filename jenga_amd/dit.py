@@ -17,7 +17,7 @@ Weights are synthetic (random init; there are no checkpoints in this environment
 real model (timestep MLPs, token refiner) are replaced by one linear each -- they run once per step on <= 256 tokens.
 """
 import math
-from typing import Optional, Tuple
+from typing import Tuple
 
 import torch
 import torch.nn as nn

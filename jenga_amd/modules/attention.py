@@ -2,7 +2,6 @@
 import torch
 
 from .. import _capi
-from . import attention_block_sparse as _op
 
 
 def get_cu_seqlens(text_mask, img_len):

@@ -10,7 +10,6 @@ Everything numeric runs in libjenga_amd.so (HIP, gfx950) through jenga_amd._capi
   jenga_pack_v + jenga_bsattn_fwd        (reference :38-196, :371-380)   image rows + text rows in one launch
 torch is used for allocation, views and zero-padding only.  No CPU fallback.
 """
-from typing import Optional
 
 import torch
 

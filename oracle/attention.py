@@ -12,7 +12,6 @@ Follows /root/reference/hyvideo/modules/attention_block_triton_diffres.py
   block_sparse_attention  <- block_sparse_attention_combined / alias        :298-424 (HY); I2V/Wan pad+slice variants
                              hyvideo_i2v/...:323-328,385 and wan/...:448-463,519-532
 """
-import math
 
 import numpy as np
 

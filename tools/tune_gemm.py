@@ -1,6 +1,5 @@
 """Time the DiT's large GEMM shapes with the default hipBLASLt pick, and (with PYTORCH_TUNABLEOP_ENABLED=1 in the
 environment) with TunableOp's pick; prints ms and TFLOP/s per shape.  Results file: $PYTORCH_TUNABLEOP_FILENAME."""
-import os
 import sys
 import time
 import torch
