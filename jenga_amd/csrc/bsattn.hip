@@ -48,7 +48,6 @@ struct AttnParams {
 constexpr int KT = 64;                      // keys per LDS tile
 constexpr int K_TILE_BYTES = KT * 128 * 2;  // 16 KiB
 constexpr int V_TILE_BYTES = 128 * KT * 2;  // 16 KiB
-constexpr int BUF_BYTES = K_TILE_BYTES + V_TILE_BYTES;
 // 4-wave kernel LDS: K ring of 3 slots (tile t in slot t % 3, fetched two tiles ahead) + V^T ring of 2 slots
 // (fetched one tile ahead, first read in the second half of its tile): 80 KiB, two workgroups fill the CU's 160 KiB.
 constexpr int W4_V_RING = 3 * K_TILE_BYTES;

@@ -37,7 +37,7 @@ template <typename T>
 __global__ void __launch_bounds__(256)
 block_select_kernel(const uint16_t* __restrict__ qpool, const uint16_t* __restrict__ kpool,
                     const uint8_t* __restrict__ neighbors, int nb_rows, int nb_cols, uint8_t* __restrict__ mask,
-                    int32_t* __restrict__ idx, int32_t* __restrict__ cnt, int H, int nq, int nk_img, int text_blocks,
+                    int32_t* __restrict__ idx, int32_t* __restrict__ cnt, int /*H*/, int nq, int nk_img, int text_blocks,
                     int top_k, float p_thr, int first_frame_blocks, int npow2) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t* keys = reinterpret_cast<uint32_t*>(smem);                 // [npow2]
