@@ -175,12 +175,19 @@ WAN_MODEL = dict(dim=256, ffn_dim=512, num_heads=2, num_layers=2, text_dim=64, t
                  freq_dim=256, latent=(3, 8, 16), steps=7, thresh=0.15, ctx_len=(20, 7))
 
 
-def wan_param(key, shape):
+def wan_param(key, shape, fan_in_gain=None):
     """Deterministic tensor for the parameter `key` (reference names), independent of iteration order: linear weights
-    and biases are bf16-representable (autocast's cast of them is then exact), norms / modulation stay fp32."""
+    and biases are bf16-representable (autocast's cast of them is then exact), norms / modulation stay fp32.
+    fan_in_gain: weights get std = gain / sqrt(fan_in) instead of 0.05 (full-size models)."""
     import zlib
     gen = torch.Generator().manual_seed(zlib.crc32(key.encode()) & 0x7FFFFFFF)
     t = torch.randn(*shape, generator=gen)
+    if fan_in_gain is not None and key.endswith("weight") and len(shape) >= 2 and "norm" not in key:
+        fan_in = 1
+        for d in shape[1:]:
+            fan_in *= d
+        w = t * (fan_in_gain / fan_in ** 0.5)
+        return w if key.startswith(("time_embedding", "time_projection", "head.head")) else w.to(torch.bfloat16).float()
     if key.endswith("modulation"):
         return t / shape[-1] ** 0.5
     if "norm" in key:
@@ -248,3 +255,16 @@ def i2v_block_inputs():
     trv = torch.randn(1, C, generator=gen).to(torch.float16)
     cu = torch.tensor([0, S_img + c["valid_txt"], S_img + c["s_txt"]], dtype=torch.int32)
     return dict(state=sd, x=x, vec=vec, token_replace_vec=trv, cu=cu, S_img=S_img)
+
+
+# ---- BASELINE.json configs[0]: Wan2.1-1.3B T2V 256x256x17f, dense, the reference's CPU-eager case -----------------
+WAN_1P3B = dict(dim=1536, ffn_dim=8960, num_heads=12, num_layers=30, text_dim=4096, text_len=512, in_dim=16, out_dim=16,
+                freq_dim=256, latent=(5, 32, 32), ctx_len=40, timestep=999.0, gain=0.8)
+
+
+def wan_1p3b_inputs():
+    c = WAN_1P3B
+    gen = torch.Generator().manual_seed(1313)
+    x = torch.randn(c["in_dim"], *c["latent"], generator=gen)
+    ctx = torch.randn(c["ctx_len"], c["text_dim"], generator=gen)
+    return dict(x=x, context=ctx)

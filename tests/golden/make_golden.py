@@ -367,11 +367,9 @@ def gen_hy_blocks():
     np.savez_compressed(os.path.join(OUT, "hy_blocks_case.npz"), **out)
 
 
-def gen_wan_forward():
-    """The reference WanModel (small) driven by the reference's own Jenga forward: `teacache_forward` is taken out of
-    jenga_wan.py by name (the script itself imports the whole pipeline zoo) and bound to the model with the attributes
-    its main() sets (:1066-1098).  CPU autocast stands in for the CUDA one: bfloat16 outside, disabled where the
-    reference asks for float32.  Dense attention (sa_drop_rate 0); two CFG streams per step."""
+def _wan_forward_env():
+    """Import the reference Wan model module with CPU stand-ins for CUDA autocast / flash_attention and lift
+    `teacache_forward` out of jenga_wan.py by name (the script itself imports the whole pipeline zoo)."""
     import ast
     import importlib
     for name in ("diffusers", "diffusers.configuration_utils", "diffusers.models", "diffusers.models.modeling_utils"):
@@ -413,6 +411,14 @@ def gen_wan_forward():
     fn = next(n for n in ast.parse(src).body if isinstance(n, ast.FunctionDef) and n.name == "teacache_forward")
     ns = {"torch": torch, "np": np, "amp": amp_cpu, "sinusoidal_embedding_1d": mm.sinusoidal_embedding_1d}
     exec(compile(ast.Module(body=[fn], type_ignores=[]), "jenga_wan.py:teacache_forward", "exec"), ns)
+    return mm, g, ns
+
+
+def gen_wan_forward():
+    """The reference WanModel (small) driven by the reference's own Jenga forward, bound to the model with the
+    attributes its main() sets (:1066-1098).  CPU autocast stands in for the CUDA one: bfloat16 outside, disabled where
+    the reference asks for float32.  Dense attention (sa_drop_rate 0); two CFG streams per step."""
+    mm, g, ns = _wan_forward_env()
     c = inputs.WAN_MODEL
     inp = inputs.wan_model_inputs()
     model = mm.WanModel(model_type="t2v", patch_size=(1, 2, 2), text_len=c["text_len"], in_dim=c["in_dim"],
@@ -606,6 +612,49 @@ def gen_i2v_block():
                                                                 inp["state"]["linear2.weight"].numpy().ravel()]))))
 
 
+def _wan_set_jenga_attrs(model, g, grid, steps, thresh, enable):
+    l2h, h2l = g.sliced_gilbert_mapping(*grid)
+    nbm = g.sliced_gilbert_block_neighbor_mapping(*grid)
+    K = type(model)
+    K.enable_teacache, K.cnt, K.num_steps, K.teacache_thresh = enable, 0, steps * 2, thresh
+    K.accumulated_rel_l1_distance_even = K.accumulated_rel_l1_distance_odd = 0
+    K.previous_e0_even = K.previous_e0_odd = K.previous_residual_even = K.previous_residual_odd = None
+    K.use_ref_steps, K.use_cache, K.stage_start = False, False, False
+    K.linear_to_hilbert, K.hilbert_order = torch.tensor(l2h, dtype=torch.long), torch.tensor(h2l, dtype=torch.long)
+    K.block_neighbor_list, K.p_remain_rates = nbm, 0.8
+    K.coefficients = [2.39676752e+03, -1.31110545e+03, 2.01331979e+02, -8.29855975e+00, 1.37887774e-01]
+    K.ret_steps, K.cutoff_steps = 1 * 2, steps * 2 - 2
+
+
+def gen_wan_1p3b():
+    """BASELINE.json configs[0], the reference's own CPU-runnable case: the FULL Wan2.1-1.3B architecture (30 layers,
+    dim 1536, 12 heads, ffn 8960, text 512 x 4096) on a 256x256x17f latent (5x16x16 = 1280 tokens, dense attention),
+    one forward of the reference model through its Jenga `teacache_forward` on the CPU.  Seeded weights (1.4 G
+    parameters are regenerated from their names by tests/golden/inputs.py, not stored)."""
+    mm, g, ns = _wan_forward_env()
+    c = inputs.WAN_1P3B
+    inp = inputs.wan_1p3b_inputs()
+    model = mm.WanModel(model_type="t2v", patch_size=(1, 2, 2), text_len=c["text_len"], in_dim=c["in_dim"],
+                        dim=c["dim"], ffn_dim=c["ffn_dim"], freq_dim=c["freq_dim"], text_dim=c["text_dim"],
+                        out_dim=c["out_dim"], num_heads=c["num_heads"], num_layers=c["num_layers"],
+                        cross_attn_norm=True)
+    sd = {k_: inputs.wan_param(k_, tuple(v_.shape), fan_in_gain=c["gain"]) for k_, v_ in model.state_dict().items()}
+    model.load_state_dict(sd, strict=True)
+    F_, H_, W_ = c["latent"]
+    grid = (F_, H_ // 2, W_ // 2)
+    _wan_set_jenga_attrs(model, g, grid, steps=10, thresh=0.15, enable=True)
+    L = grid[0] * grid[1] * grid[2]
+    import time
+    t0 = time.time()
+    with torch.autocast("cpu", dtype=torch.bfloat16):
+        y = ns["teacache_forward"](model, [inp["x"]], t=torch.tensor([c["timestep"]]), context=[inp["context"]],
+                                   seq_len=L, sa_drop_rate=0.0)[0]
+    print("reference Wan-1.3B forward on CPU: %.1f s, |y| max %.3f mean %.3f" % (time.time() - t0, y.abs().max(), y.abs().mean()))
+    np.savez_compressed(os.path.join(OUT, "wan_1p3b_forward.npz"), out=y.numpy().astype(np.float32),
+                        inputs_sha=np.array(sha(np.concatenate([inp["x"].numpy().ravel(),
+                                                                sd["blocks.29.ffn.2.bias"].numpy().ravel()]))))
+
+
 def gen_scheduler():
     """FlowMatchDiscreteScheduler (diffusers absent -> its three imports are stubbed for the import only)."""
     import dataclasses
@@ -658,7 +707,7 @@ if __name__ == "__main__":
     ap.add_argument("--only", default="")
     a = ap.parse_args()
     torch.set_grad_enabled(False)
-    if a.only not in ("wan", "sched", "wanblock", "hyblocks", "wanforward", "hyforward", "i2vblock"):
+    if a.only not in ("wan", "sched", "wanblock", "hyblocks", "wanforward", "hyforward", "i2vblock", "wan1p3b"):
         gen_gilbert(a.big)
     if a.only in ("", "select", "attn"):
         gen_select()
@@ -676,6 +725,8 @@ if __name__ == "__main__":
         gen_hy_forward()
     if a.only in ("", "i2vblock"):
         gen_i2v_block()
+    if a.only in ("wan1p3b",) or (a.only == "" and a.big):
+        gen_wan_1p3b()
     if a.only in ("", "wan", "wanforward"):
         gen_wan_forward()
     if a.only in ("", "sched"):

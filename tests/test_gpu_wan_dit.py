@@ -196,3 +196,40 @@ def test_wan_dit_forward_vs_reference_model_and_teacache(dev):
             call += 1
     assert used_cache == g["used_cache"].tolist(), (used_cache, g["used_cache"].tolist())
     assert any(used_cache) and not all(used_cache)
+
+
+def test_wan_1p3b_full_model_vs_reference_cpu_forward(dev):
+    """BASELINE.json configs[0]: the full Wan2.1-1.3B architecture (30 layers, dim 1536, 12 heads, ffn 8960, 512 x 4096
+    text) on the 256x256x17f latent (1280 tokens, dense attention) against ONE forward of the reference model through
+    its own Jenga `teacache_forward` on the CPU (tests/golden/make_golden.py gen_wan_1p3b, 45 s there).  The 1.4 G
+    parameters are regenerated from their names.  Output |y| <= 3.5; the bound covers bf16 GEMM summation-order noise
+    through 30 blocks."""
+    from jenga_amd import gilbert as G
+    from jenga_amd.wan_dit import WanDiT
+    c = inputs.WAN_1P3B
+    inp = inputs.wan_1p3b_inputs()
+    g = np.load(os.path.join(GOLD, "wan_1p3b_forward.npz"))
+    m = WanDiT(text_len=c["text_len"], in_dim=c["in_dim"], dim=c["dim"], ffn_dim=c["ffn_dim"], freq_dim=c["freq_dim"],
+               text_dim=c["text_dim"], out_dim=c["out_dim"], num_heads=c["num_heads"], num_layers=c["num_layers"],
+               cross_attn_norm=True, dtype=torch.bfloat16, device=dev)
+    with torch.no_grad():
+        for k_, p_ in m.state_dict().items():
+            if k_ == "patch_embedding.weight":
+                w = inputs.wan_param(k_, (c["dim"], c["in_dim"], 1, 2, 2), fan_in_gain=c["gain"]).reshape(c["dim"], -1)
+            else:
+                w = inputs.wan_param(k_, tuple(p_.shape), fan_in_gain=c["gain"])
+            p_.copy_(w.to(device=dev, dtype=p_.dtype))
+    F_, H_, W_ = c["latent"]
+    grid = (F_, H_ // 2, W_ // 2)
+    L = grid[0] * grid[1] * grid[2]
+    l2h, h2l = G.sliced_gilbert_mapping(*grid, as_tensor=True)
+    m.set_curve(l2h, h2l, G.sliced_gilbert_block_neighbor_mapping(*grid, as_tensor=True))
+    m.enable_teacache(num_steps=10, thresh=0.15, task="t2v-1.3B", use_ret_steps=False, enable=True)
+    y = m([inp["x"].to(dev)], torch.tensor([c["timestep"]], device=dev), [inp["context"].to(dev)], seq_len=L,
+          sa_drop_rate=0.0)[0]
+    ref = g["out"]
+    got = y.cpu().numpy()
+    assert got.shape == ref.shape == (16, 5, 32, 32) and np.isfinite(got).all()
+    err = np.abs(got - ref)
+    print("wan-1.3B full forward: max abs err %.4f, mean abs err %.5f at |ref| max %.2f mean %.3f" % (err.max(), err.mean(), np.abs(ref).max(), np.abs(ref).mean()))
+    assert err.max() <= 3e-2 and err.mean() <= 4e-3, (err.max(), err.mean(), np.abs(ref).max(), np.abs(ref).mean())
