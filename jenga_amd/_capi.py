@@ -382,6 +382,10 @@ def bsattn_fwd(q, k, vt, seqlens, idx, cnt, nq_img, sm_scale, text_amp, text_blo
         out = torch.empty((B, S, H, 128), dtype=q.dtype, device=q.device)
     if seqlens is not None and (seqlens.dtype != torch.int32 or seqlens.device != q.device):
         seqlens = seqlens.to(device=q.device, dtype=torch.int32)
+    if seqlens is not None and seqlens.numel() < B:
+        # the reference passes cu_seqlens_q[1:2] whatever the batch (attention_block_triton_diffres.py:327-329) and its
+        # kernel then reads past it for B > 1; here that is an error instead of an out-of-bounds read
+        raise ValueError(f"bsattn_fwd: seqlens has {seqlens.numel()} entries for batch {B}")
     if idx is not None and idx.shape[-1] != n_blocks:
         raise ValueError("idx row length must equal the number of kv blocks")
     prof = ATTN_PROFILE

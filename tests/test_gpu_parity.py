@@ -573,6 +573,12 @@ def test_c_abi_rejects_bad_arguments_on_device(dev):
     bad = list(args())
     bad[6] = None
     assert L.jenga_bsattn_fwd(*bad) != 0 and b"idx" in L.jenga_last_error()
+    # host wrapper: one kv length per sample is required (the reference would read past cu_seqlens_q[1:2] for B = 2)
+    q2 = torch.zeros(2, 256, 1, 128, device=dev, dtype=torch.bfloat16)
+    vt2 = torch.zeros(2, 1, 4, 128, 64, device=dev, dtype=torch.bfloat16)
+    with pytest.raises(ValueError):
+        _capi.bsattn_fwd(q2, q2, vt2, sl, idx.expand(2, -1, -1, -1).contiguous(), cnt.expand(2, -1, -1).contiguous(),
+                         2, 0.088, 0.0, 2)
 
 
 def test_two_streams_and_graph_capture(dev):
