@@ -388,6 +388,14 @@ def bsattn_fwd(q, k, vt, seqlens, idx, cnt, nq_img, sm_scale, text_amp, text_blo
         raise ValueError(f"bsattn_fwd: seqlens has {seqlens.numel()} entries for batch {B}")
     if idx is not None and idx.shape[-1] != n_blocks:
         raise ValueError("idx row length must equal the number of kv blocks")
+    if k.shape != q.shape or out.shape != q.shape:
+        raise ValueError("bsattn_fwd: q, k and out must have the same [B,S,H,128] shape")
+    if tuple(vt.shape) != (B, H, 2 * n_blocks, 128, 64) or not vt.is_contiguous() or vt.dtype != q.dtype:
+        raise ValueError(f"bsattn_fwd: vt must be the contiguous pack_v workspace {(B, H, 2 * n_blocks, 128, 64)}")
+    if nq_img > 0 and (idx is None or cnt is None or tuple(idx.shape[:3]) != (B, H, nq_img)
+                       or tuple(cnt.shape) != (B, H, nq_img) or idx.dtype != torch.int32 or cnt.dtype != torch.int32
+                       or not idx.is_contiguous() or not cnt.is_contiguous()):
+        raise ValueError("bsattn_fwd: idx / cnt must be contiguous int32 [B,H,nq_img,n_blocks] / [B,H,nq_img]")
     prof = ATTN_PROFILE
     with torch.cuda.device(q.device):
         if prof is not None:
