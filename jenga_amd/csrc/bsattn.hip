@@ -105,36 +105,13 @@ __device__ __forceinline__ void stage_tile(const void* kbase, const void* vbase,
 
 // Lazy running max: m~ is an integer-valued upper reference of each row's max, raised (by an integer step, so every
 // rescale factor is an exact power of two) only when a row's new max exceeds it by more than LAZY_THR in log2 units.
-// P = exp2(S - m~) costs one packed add per two scores; O and l are rescaled only in the (rare) raise path (keeping
-// -m~ in the MFMA C operand instead was tried: hipcc then copies the 32 C registers every tile, which costs more).  P <= 2^LAZY_THR keeps the storage dtype's relative
-// precision (power-of-two scaling commutes with rounding), so results match the eager max up to fp32 rounding.
-// Two measured-and-rejected variants of the softmax hot path, kept as switches (tools/micro/*.hip):
-// on a gfx950 SIMD the FP add/mul/convert ops of one wave are NOT hidden under the partner wave's MFMAs while v_mov,
-// integer ops, v_max, v_ldexp and (75 %) v_exp are -- but trading 32 FP subtracts for 32 register copies (CNEG: 997
-// TFLOP/s) or 16 v_cvt_pk for 80 integer ops (INTPACK: 967) lengthens the wave's own serial stream by more than it
-// frees on the shared pipe (baseline 1049); starting the chains with an inline-asm MFMA whose C is untied (CNEG=2: no
-// copies, no subtracts) is correct too but `asm volatile` pins the schedule and spills: 647.
-#ifndef JENGA_SM_CNEG
-#define JENGA_SM_CNEG 0      // 1: -m~ rides in the MFMA C operand; 0: subtracted with FP adds after the MFMAs
-#endif
-#ifndef JENGA_SM_INTPACK
-#define JENGA_SM_INTPACK 0   // 1: bf16 rounding/packing of P with integer ops; 0: v_cvt_pk_bf16_f32
-#endif
+// P = exp2(S - m~) costs one packed add per two scores; O and l are rescaled only in the (rare) raise path.
+// P <= 2^LAZY_THR keeps the storage dtype's relative precision (power-of-two scaling commutes with rounding), so
+// results match the eager max up to fp32 rounding.  Variants of this hot path that were measured and dropped (-m~ in
+// the MFMA C operand, integer bf16 packing, integer exponent subtract, untied-C inline-asm MFMA) are in DESIGN.md §3.
 constexpr float LAZY_THR = 8.0f;
-#if JENGA_SM_INTPACK
-#define PACKP pack2_int
-#else
-#define PACKP pack2
-#endif
 constexpr float RAISE_SUM = 256.0f;   // 2^LAZY_THR
-#ifndef JENGA_SETPRIO
-#define JENGA_SETPRIO 1
-#endif
-#if JENGA_SETPRIO
 #define MFMA_PRIO(x) __builtin_amdgcn_s_setprio(x)
-#else
-#define MFMA_PRIO(x)
-#endif
 
 template <typename T, bool TEXT>
 __device__ __forceinline__ void attn_block(const AttnParams& P, unsigned char* smem, int b, int h, int m) {
@@ -180,9 +157,6 @@ __device__ __forceinline__ void attn_block(const AttnParams& P, unsigned char* s
         for (int r = 0; r < 16; ++r) oacc[i][r] = 0.f;
     float l_i = 0.f;
     float neg_m = 0.f;      // -m~ (integer valued)
-    f32x16 cneg;            // MFMA C operand of the first K.Q^T step: -m~ splat (register copies are v_mov = free)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) cneg[r] = 0.f;
     f32x16 zero16;
 #pragma unroll
     for (int r = 0; r < 16; ++r) zero16[r] = 0.f;
@@ -234,33 +208,19 @@ __device__ __forceinline__ void attn_block(const AttnParams& P, unsigned char* s
                         ka[ds] = *reinterpret_cast<const uint4*>(cur + k_addr[ds]);                              \
                         kb[ds] = *reinterpret_cast<const uint4*>(cur + k_addr[ds] + 8192);                       \
                     }                                                                                            \
-                    if (!TEXT && JENGA_SM_CNEG == 2) { /* untied C: scores arrive as S - m~, no copies */       \
-                        s0 = mfma32_untied<T>(ka[0], qf[0], cneg);                                               \
-                        s1 = mfma32_untied<T>(kb[0], qf[0], cneg);                                               \
-                    } else {                                                                                     \
-                        s0 = mfma32<T>(ka[0], qf[0], (TEXT || !JENGA_SM_CNEG) ? zero16 : cneg);                 \
-                        s1 = mfma32<T>(kb[0], qf[0], (TEXT || !JENGA_SM_CNEG) ? zero16 : cneg);                 \
-                    }                                                                                            \
+                    s0 = mfma32<T>(ka[0], qf[0], zero16);                                                        \
+                    s1 = mfma32<T>(kb[0], qf[0], zero16);                                                        \
                     _Pragma("unroll") for (int ds = 1; ds < 8; ++ds) {                                           \
                         s0 = mfma32<T>(ka[ds], qf[ds], s0);                                                      \
                         s1 = mfma32<T>(kb[ds], qf[ds], s1);                                                      \
                     }                                                                                            \
                     /* issue order: LDS reads run 3 k-steps (6 reads) ahead of the MFMAs that consume them */    \
-                    if (!TEXT && JENGA_SM_CNEG == 2) { /* the two asm MFMAs are invisible to the group masks */  \
-                        __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);                                       \
-                        _Pragma("unroll") for (int g_ = 0; g_ < 4; ++g_) {                                       \
-                            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                                   \
-                            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);                                   \
-                        }                                                                                        \
-                        __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);                                       \
-                    } else {                                                                                     \
-                        __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);                                       \
-                        _Pragma("unroll") for (int g_ = 0; g_ < 5; ++g_) {                                       \
-                            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                                   \
-                            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);                                   \
-                        }                                                                                        \
-                        __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);                                       \
+                    __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);                                           \
+                    _Pragma("unroll") for (int g_ = 0; g_ < 5; ++g_) {                                           \
+                        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                                       \
+                        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);                                       \
                     }                                                                                            \
+                    __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);                                           \
                     MFMA_PRIO(0);                                                                                \
                 }                                                                                                \
                 if (TEXT) {                                                                                      \
@@ -283,7 +243,7 @@ __device__ __forceinline__ void attn_block(const AttnParams& P, unsigned char* s
                         }                                                                                        \
                     }                                                                                            \
                 }                                                                                                \
-                if (!TEXT && !JENGA_SM_CNEG) {                                                                   \
+                if (!TEXT) {                                                                                     \
                     _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                             \
                         s0[r] += neg_m;                                                                          \
                         s1[r] += neg_m;                                                                          \
@@ -301,7 +261,6 @@ __device__ __forceinline__ void attn_block(const AttnParams& P, unsigned char* s
                     _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                             \
                         s0[r] -= delta;                                                                          \
                         s1[r] -= delta;                                                                          \
-                        cneg[r] = neg_m;                                                                         \
                     }                                                                                            \
                     _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                \
                         _Pragma("unroll") for (int r = 0; r < 16; ++r) oacc[i][r] *= f2;                         \
@@ -327,7 +286,6 @@ __device__ __forceinline__ void attn_block(const AttnParams& P, unsigned char* s
                     const float f2 = __builtin_amdgcn_exp2f(-delta);                                             \
                     neg_m -= delta;                                                                              \
                     l_i *= f2;                                                                                   \
-                    _Pragma("unroll") for (int r = 0; r < 16; ++r) cneg[r] = neg_m;                              \
                     _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                \
                         _Pragma("unroll") for (int r = 0; r < 16; ++r) oacc[i][r] *= f2;                         \
                     psum = 0.f;                                                                                  \
@@ -343,14 +301,14 @@ __device__ __forceinline__ void attn_block(const AttnParams& P, unsigned char* s
             l_i += psum;                                                                                         \
             /* P -> 16-bit operands: k-step ks = 2g + s uses C registers 8s..8s+7 of group g */                  \
             uint4 pf[4];                                                                                         \
-            pf[0] = make_uint4(PACKP<T>(s0[0], s0[1]), PACKP<T>(s0[2], s0[3]), PACKP<T>(s0[4], s0[5]),           \
-                               PACKP<T>(s0[6], s0[7]));                                                          \
-            pf[1] = make_uint4(PACKP<T>(s0[8], s0[9]), PACKP<T>(s0[10], s0[11]), PACKP<T>(s0[12], s0[13]),       \
-                               PACKP<T>(s0[14], s0[15]));                                                        \
-            pf[2] = make_uint4(PACKP<T>(s1[0], s1[1]), PACKP<T>(s1[2], s1[3]), PACKP<T>(s1[4], s1[5]),           \
-                               PACKP<T>(s1[6], s1[7]));                                                          \
-            pf[3] = make_uint4(PACKP<T>(s1[8], s1[9]), PACKP<T>(s1[10], s1[11]), PACKP<T>(s1[12], s1[13]),       \
-                               PACKP<T>(s1[14], s1[15]));                                                        \
+            pf[0] = make_uint4(pack2<T>(s0[0], s0[1]), pack2<T>(s0[2], s0[3]), pack2<T>(s0[4], s0[5]),           \
+                               pack2<T>(s0[6], s0[7]));                                                          \
+            pf[1] = make_uint4(pack2<T>(s0[8], s0[9]), pack2<T>(s0[10], s0[11]), pack2<T>(s0[12], s0[13]),       \
+                               pack2<T>(s0[14], s0[15]));                                                        \
+            pf[2] = make_uint4(pack2<T>(s1[0], s1[1]), pack2<T>(s1[2], s1[3]), pack2<T>(s1[4], s1[5]),           \
+                               pack2<T>(s1[6], s1[7]));                                                          \
+            pf[3] = make_uint4(pack2<T>(s1[8], s1[9]), pack2<T>(s1[10], s1[11]), pack2<T>(s1[12], s1[13]),       \
+                               pack2<T>(s1[14], s1[15]));                                                        \
             /* O^T += V^T P^T: four independent accumulator chains per k-step */                                 \
             {                                                                                                    \
                 uint4 va[4][4];                                                                                  \

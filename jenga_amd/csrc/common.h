@@ -41,19 +41,6 @@ template <> __device__ __forceinline__ uint32_t pack2<FP16>(float lo, float hi) 
     const f32x2 v = {lo, hi};
     return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, f16x2));
 }
-// Same packing with INTEGER instructions only (round-to-nearest-even add, then a byte permute).  On gfx950 the FP
-// add/mul/convert datapath is shared with the MFMA pipe of the SIMD (a v_cvt_pk_bf16_f32 of one wave is not hidden
-// under the partner wave's MFMAs), integer ALU ops are -- see tools/micro/valu_cost.hip.  Inputs must be finite
-// and non-negative-or-any-sign normal values (no NaN handling): used for softmax probabilities only.
-template <typename T> __device__ __forceinline__ uint32_t pack2_int(float lo, float hi);
-template <> __device__ __forceinline__ uint32_t pack2_int<BF16>(float lo, float hi) {
-    const uint32_t ul = __float_as_uint(lo), uh = __float_as_uint(hi);
-    const uint32_t rl = ul + 0x7FFFu + ((ul >> 16) & 1u);
-    const uint32_t rh = uh + 0x7FFFu + ((uh >> 16) & 1u);
-    return __builtin_amdgcn_perm(rh, rl, 0x07060302u);   // bytes {rl[2], rl[3], rh[2], rh[3]}
-}
-template <> __device__ __forceinline__ uint32_t pack2_int<FP16>(float lo, float hi) { return pack2<FP16>(lo, hi); }
-
 template <typename T> __device__ __forceinline__ float round_to(float f) { return to_f32<T>(from_f32<T>(f)); }
 
 template <typename T> __device__ __forceinline__ void unpack8(const uint4& v, float (&f)[8]) {
@@ -83,25 +70,6 @@ template <> __device__ __forceinline__ f32x16 mfma32<BF16>(const uint4& a, const
 template <> __device__ __forceinline__ f32x16 mfma32<FP16>(const uint4& a, const uint4& b, const f32x16& c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0,
                                                   0);
-}
-
-// MFMA whose accumulator input C is a DIFFERENT register block than its result D (hipcc always ties D to C for the
-// builtin and would copy a loop-invariant C into D with 16 v_mov first).  Used to start the K.Q^T chains from the
-// -m~ splat at no VALU cost.  "=&v": D must not partially overlap C.  The result is only read by the next MFMA of the
-// chain as its (tied) C operand, which needs no wait states (accumulate forwarding).
-template <typename T> __device__ __forceinline__ f32x16 mfma32_untied(const uint4& a, const uint4& b, const f32x16& c);
-typedef int i32x4 __attribute__((ext_vector_type(4)));
-template <> __device__ __forceinline__ f32x16 mfma32_untied<BF16>(const uint4& a, const uint4& b, const f32x16& c) {
-    f32x16 d;
-    const i32x4 av = __builtin_bit_cast(i32x4, a), bv = __builtin_bit_cast(i32x4, b);
-    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %3" : "=&v"(d) : "v"(av), "v"(bv), "v"(c));
-    return d;
-}
-template <> __device__ __forceinline__ f32x16 mfma32_untied<FP16>(const uint4& a, const uint4& b, const f32x16& c) {
-    f32x16 d;
-    const i32x4 av = __builtin_bit_cast(i32x4, a), bv = __builtin_bit_cast(i32x4, b);
-    asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %3" : "=&v"(d) : "v"(av), "v"(bv), "v"(c));
-    return d;
 }
 
 // Key order inside a 32-key group as the P.V product consumes it: position p = hi*16 + s*8 + j  <->  key
