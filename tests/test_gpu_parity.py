@@ -170,7 +170,7 @@ def test_select_vs_oracle_larger(dev):
 
 
 # ----------------------------------------------------------------------------------------------- sparse kernel
-def _run_kernel(q_bhsd, k_bhsd, v_bhsd, mask, seqlen, amp, nb_img, dev):
+def _run_kernel(q_bhsd, k_bhsd, v_bhsd, mask, seqlen, amp, nb_img, dev, flags=None):
     """inputs in the reference kernel's [B,H,S,D] layout -> o [B,H,Sq_img,D] (image rows only)."""
     from jenga_amd import _capi
     B, H, Sq, D = q_bhsd.shape
@@ -184,7 +184,7 @@ def _run_kernel(q_bhsd, k_bhsd, v_bhsd, mask, seqlen, amp, nb_img, dev):
     idx, cnt = lists_from_mask(mask, dev)
     vt = _capi.pack_v(v, nb)
     seqlens = torch.tensor([seqlen] * B, dtype=torch.int32, device=dev)
-    o = _capi.bsattn_fwd(q, k, vt, seqlens, idx, cnt, nb_img, D ** -0.5, amp, nb_img)
+    o = _capi.bsattn_fwd(q, k, vt, seqlens, idx, cnt, nb_img, D ** -0.5, amp, nb_img, flags=flags)
     torch.cuda.synchronize()
     return o.transpose(1, 2)[:, :, :Sq].float().cpu().numpy()
 
@@ -202,8 +202,10 @@ def test_sparse_kernel_vs_triton_interpreter_golden(golden_dir, dev, index):
     assert (err > 2e-3).mean() < 2e-3
 
 
-@pytest.mark.parametrize("dt", ["bfloat16", "float16"])
-def test_sparse_kernel_vs_oracle(dev, dt):
+@pytest.mark.parametrize("dt,flags", [("bfloat16", None), ("float16", None), ("bfloat16", 3), ("float16", 2)])
+def test_sparse_kernel_vs_oracle(dev, dt, flags):
+    """flags None = the default 4-wave kernel; 2 / 3 = the experimental 8-wave ping-pong kernel (JENGA_ATTN_PINGPONG,
+    without / with the XCD remap), kept in-tree as a measured alternative and held to the same tolerance."""
     from oracle import attention as oa
     gen = torch.Generator().manual_seed(11)
     H, nb_img, tb = 3, 9, 2
@@ -216,7 +218,7 @@ def test_sparse_kernel_vs_oracle(dev, dt):
     mask[..., nb_img:] = True
     mask[..., 0] = True
     seqlen = nb_img * 128 + 37          # first text block partially valid, second fully masked
-    o = _run_kernel(q, k, v, mask, seqlen, 0.431, nb_img, dev)
+    o = _run_kernel(q, k, v, mask, seqlen, 0.431, nb_img, dev, flags=flags)
     ref = oa.sparse_rows(to_np(q), to_np(k), to_np(v), [seqlen], mask.numpy(), 128 ** -0.5, dt, 0.431, nb_img)
     tol = 2e-2 if dt == "bfloat16" else 4e-3     # 2-3 ulp of the storage dtype at |o| <= ~2
     assert np.abs(o - ref).max() <= tol, np.abs(o - ref).max()
