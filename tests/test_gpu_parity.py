@@ -202,9 +202,9 @@ def test_sparse_kernel_vs_triton_interpreter_golden(golden_dir, dev, index):
     assert (err > 2e-3).mean() < 2e-3
 
 
-@pytest.mark.parametrize("dt,flags", [("bfloat16", None), ("float16", None), ("bfloat16", 3), ("float16", 2)])
+@pytest.mark.parametrize("dt,flags", [("bfloat16", None), ("float16", None), ("bfloat16", 0), ("bfloat16", 3), ("float16", 2)])
 def test_sparse_kernel_vs_oracle(dev, dt, flags):
-    """flags None = the default 4-wave kernel; 2 / 3 = the experimental 8-wave ping-pong kernel (JENGA_ATTN_PINGPONG,
+    """flags None = the default 4-wave kernel (XCD remap on), 0 = plain workgroup order; 2 / 3 = the experimental 8-wave ping-pong kernel (JENGA_ATTN_PINGPONG,
     without / with the XCD remap), kept in-tree as a measured alternative and held to the same tolerance."""
     from oracle import attention as oa
     gen = torch.Generator().manual_seed(11)
