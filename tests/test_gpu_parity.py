@@ -662,3 +662,48 @@ def test_op_randomized_shapes_vs_oracle(dev, seed):
     bad = np.abs(got - ref) > tol
     # a selection tie resolved differently moves whole 128-row blocks; everything else must agree elementwise
     assert bad.mean() <= 0.0, (H, nimg, tb, valid, top_k, p, amp, dt, np.abs(got - ref).max(), bad.mean())
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_padded_flavours_randomized_vs_oracle(dev, seed):
+    """I2V (text_blocks = 4, ragged S padded to 128) and Wan (text_blocks = 0, first-frame blocks, bf16 forced, ragged S)
+    flavours over random lengths / top_k / thresholds."""
+    from jenga_amd.modules import attention_block_sparse as op
+    from oracle import attention as oa
+    rng = np.random.RandomState(500 + seed)
+    wan = bool(seed % 2)
+    H = int(rng.randint(1, 3))
+    nimg = int(rng.randint(2, 9))
+    gen = torch.Generator().manual_seed(50 + seed)
+    top_k = int(rng.randint(1, nimg + 1))
+    p = float(rng.choice([0.3, 0.5, 0.8, 0.9]))
+    nbm = (torch.rand(nimg + 1, nimg + 1, generator=gen) < 0.25) | torch.eye(nimg + 1, dtype=torch.bool)
+    if wan:
+        S = nimg * 128 + int(rng.randint(1, 128))                     # ragged tail -> one more (padded) block
+        ffb = int(rng.randint(0, 3))
+        q = (torch.randn(1, S, H, 128, generator=gen) * 1.2).to(torch.bfloat16)
+        k = (torch.randn(1, S, H, 128, generator=gen) * 1.2).to(torch.bfloat16)
+        v = torch.randn(1, S, H, 128, generator=gen).to(torch.bfloat16)
+        o = op.block_sparse_attention_wan(q.to(dev), k.to(dev), v.to(dev), top_k, block_neighbor_list=nbm,
+                                          p_remain_rates=p, first_frame_blocks=ffb)
+        ref = oa.block_sparse_attention(to_np(q), to_np(k), to_np(v), top_k, "bfloat16", text_blocks=0,
+                                        block_neighbor_list=nbm.numpy(), p_remain_rates=p, flavour="wan",
+                                        first_frame_blocks=ffb)
+    else:
+        S_img = nimg * 128
+        S = S_img + 4 * 128 - int(rng.randint(1, 128))                 # ragged text tail, padded up to 4 text blocks
+        valid = int(rng.randint(1, S - S_img))
+        q = (torch.randn(1, S, H, 128, generator=gen) * 1.2).to(torch.bfloat16)
+        k = (torch.randn(1, S, H, 128, generator=gen) * 1.2).to(torch.bfloat16)
+        v = torch.randn(1, S, H, 128, generator=gen).to(torch.bfloat16)
+        cu = torch.tensor([0, S_img + valid, S], dtype=torch.int32)
+        o = op.block_sparse_attention_i2v(q.to(dev), k.to(dev), v.to(dev), top_k, cu_seqlens_q=cu.to(dev),
+                                          cu_seqlens_kv=cu.to(dev), text_amp=0.2, block_neighbor_list=nbm[:nimg, :nimg],
+                                          p_remain_rates=p)
+        ref = oa.block_sparse_attention(to_np(q), to_np(k), to_np(v), top_k, "bfloat16", cu_seqlens_q=cu.numpy(),
+                                        text_blocks=4, text_amp=0.2, block_neighbor_list=nbm[:nimg, :nimg].numpy(),
+                                        p_remain_rates=p, flavour="i2v")
+    got = o.float().cpu().numpy()
+    assert got.shape == ref.shape and np.isfinite(got).all()
+    err = np.abs(got - ref)
+    assert (err.max(axis=-1) > 3e-2).mean() <= 0.0, (wan, H, nimg, S, top_k, p, err.max())
