@@ -171,6 +171,24 @@ int jenga_bsattn_fwd(void* stream, const void* q, const void* k, const void* vt,
 #define JENGA_ATTN_XCD_REMAP 1 /* contiguous q-block ranges per XCD (L2 locality); 0 = plain head-major order */
 #define JENGA_ATTN_PINGPONG 2  /* 8-wave workgroups, MFMA / softmax phases of the two waves per SIMD in anti-phase */
 
+/* Step 2, second generation (the default path of the Python modules): two Hilbert-adjacent query blocks per
+ * workgroup, kv blocks kept by BOTH staged once for 256 query rows, one wave per SIMD with the softmax of one
+ * (32-row, 64-key) item interleaved into the MFMA stream of its neighbours (csrc/bsattn2.hip).
+ *   jenga_pair_merge: idx/cnt of jenga_block_select ->
+ *       pidx int32 [B,H,ceil(nq_img/2),n_blocks]: per query-block pair (2j, 2j+1) the kv blocks both rows keep, then
+ *            those only row 2j keeps, then those only row 2j+1 keeps -- each part ascending;
+ *       pcnt int32 [B,H,ceil(nq_img/2),4]: the three part lengths, 0.   (odd nq_img: the last pair has one row)
+ *   jenga_bsattn_pair_fwd: same arguments and semantics as jenga_bsattn_fwd with (pidx, pcnt) in place of (idx, cnt).
+ *       The kv blocks of a row are visited in the order (only-this-row, shared) instead of ascending; online softmax
+ *       is order independent up to fp32 rounding and every rescale stays an exact power of two. */
+int jenga_pair_merge(void* stream, const int32_t* idx, const int32_t* cnt, int64_t B, int64_t H, int64_t nq_img,
+                     int64_t n_blocks, int32_t* pidx, int32_t* pcnt);
+int jenga_bsattn_pair_fwd(void* stream, const void* q, const void* k, const void* vt, void* o,
+                          const int32_t* seqlens, const int32_t* pidx, const int32_t* pcnt, int64_t B, int64_t H,
+                          int64_t n_blocks, int64_t nq_img, int64_t q_sb, int64_t q_ss, int64_t q_sh, int64_t k_sb,
+                          int64_t k_ss, int64_t k_sh, int64_t o_sb, int64_t o_ss, int64_t o_sh, float sm_scale,
+                          float text_amp, int64_t text_block_start, int dtype, int flags);
+
 /* ---------------------------------------------------------------------------------------------------
  * Ulysses head pack/unpack: the local halves of xFuserLongContextAttention.forward's SeqAllToAll4D calls
  * (hyvideo/modules/xdit_ring_atten.py:118-131 scatter heads / gather sequence, :212-217 the reverse).

@@ -12,6 +12,7 @@ LIB_PATH = os.environ.get("JENGA_LIB", os.path.join(_HERE, "libjenga_amd.so"))
 JENGA_BF16, JENGA_FP16 = 0, 1
 ATTN_XCD_REMAP = 1
 ATTN_PINGPONG = 2
+ATTN_LEGACY = 4      # (Python-side switch) the round-1 kernel: one 128-row query block per 4-wave workgroup
 ATTN_DEFAULT_FLAGS = int(os.environ.get("JENGA_ATTN_FLAGS", str(ATTN_XCD_REMAP)))
 
 _vp, _i64, _i32, _f32 = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_float
@@ -36,6 +37,8 @@ SIGNATURES = {
     "jenga_pack_v_bytes": (ctypes.c_size_t, [_i64, _i64, _i64]),
     "jenga_pack_v": (_i32, [_vp, _vp, _vp] + [_i64] * 8 + [_i32]),
     "jenga_bsattn_fwd": (_i32, [_vp] * 8 + [_i64] * 13 + [_f32, _f32, _i64, _i32, _i32]),
+    "jenga_pair_merge": (_i32, [_vp, _vp, _vp] + [_i64] * 4 + [_vp, _vp]),
+    "jenga_bsattn_pair_fwd": (_i32, [_vp] * 8 + [_i64] * 13 + [_f32, _f32, _i64, _i32, _i32]),
     "jenga_ulysses_pack_heads": (_i32, [_vp, _vp, _vp] + [_i64] * 7),
     "jenga_ulysses_unpack_heads": (_i32, [_vp, _vp, _vp] + [_i64] * 7),
 }
@@ -396,17 +399,26 @@ def bsattn_fwd(q, k, vt, seqlens, idx, cnt, nq_img, sm_scale, text_amp, text_blo
                        or tuple(cnt.shape) != (B, H, nq_img) or idx.dtype != torch.int32 or cnt.dtype != torch.int32
                        or not idx.is_contiguous() or not cnt.is_contiguous()):
         raise ValueError("bsattn_fwd: idx / cnt must be contiguous int32 [B,H,nq_img,n_blocks] / [B,H,nq_img]")
+    fl = ATTN_DEFAULT_FLAGS if flags is None else flags
+    if not xcd_remap:
+        fl &= ~ATTN_XCD_REMAP
+    legacy = bool(fl & (ATTN_LEGACY | ATTN_PINGPONG))
     prof = ATTN_PROFILE
     with torch.cuda.device(q.device):
+        pidx = pcnt = None
+        if not legacy and nq_img > 0:
+            pidx, pcnt = pair_merge(idx, cnt, n_blocks)
         if prof is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-        _check(lib().jenga_bsattn_fwd(_stream(q.device), _p(q), _p(k), _p(vt), _p(out), _p(seqlens), _p(idx), _p(cnt),
-                                      B, H, n_blocks, nq_img, *_bshd_strides(q), *_bshd_strides(k),
-                                      *_bshd_strides(out), float(sm_scale), float(text_amp), int(text_block_start),
-                                      dtype_code(q.dtype),
-                                      (ATTN_DEFAULT_FLAGS if flags is None else flags) & ~(0 if xcd_remap else ATTN_XCD_REMAP)),
-               "jenga_bsattn_fwd")
+        common = (B, H, n_blocks, nq_img, *_bshd_strides(q), *_bshd_strides(k), *_bshd_strides(out), float(sm_scale),
+                  float(text_amp), int(text_block_start), dtype_code(q.dtype))
+        if legacy:
+            _check(lib().jenga_bsattn_fwd(_stream(q.device), _p(q), _p(k), _p(vt), _p(out), _p(seqlens), _p(idx),
+                                          _p(cnt), *common, fl & ~ATTN_LEGACY), "jenga_bsattn_fwd")
+        else:
+            _check(lib().jenga_bsattn_pair_fwd(_stream(q.device), _p(q), _p(k), _p(vt), _p(out), _p(seqlens),
+                                               _p(pidx), _p(pcnt), *common, fl), "jenga_bsattn_pair_fwd")
         if prof is not None:
             e1.record()
             prof.events.append((e0, e1))
@@ -415,6 +427,22 @@ def bsattn_fwd(q, k, vt, seqlens, idx, cnt, nq_img, sm_scale, text_amp, text_blo
             tot = (cnt.sum(dtype=torch.int64) if cnt is not None else 0) + pairs
             prof.pairs = tot if prof.pairs is None else prof.pairs + tot
     return out
+
+
+def pair_merge(idx, cnt, n_blocks):
+    """idx int32 [B,H,nq,n_blocks], cnt int32 [B,H,nq] (jenga_block_select) -> (pidx [B,H,ceil(nq/2),n_blocks],
+    pcnt [B,H,ceil(nq/2),4]): per query-block pair the kv blocks both keep | only the even row | only the odd row."""
+    _need_gpu(idx, "pair_merge")
+    B, H, nq, nb = idx.shape
+    if nb != n_blocks or tuple(cnt.shape) != (B, H, nq) or idx.dtype != torch.int32 or cnt.dtype != torch.int32:
+        raise ValueError("pair_merge: idx / cnt must be int32 [B,H,nq,n_blocks] / [B,H,nq]")
+    npair = (nq + 1) // 2
+    pidx = torch.empty((B, H, npair, nb), dtype=torch.int32, device=idx.device)
+    pcnt = torch.empty((B, H, npair, 4), dtype=torch.int32, device=idx.device)
+    with torch.cuda.device(idx.device):
+        _check(lib().jenga_pair_merge(_stream(idx.device), _p(idx.contiguous()), _p(cnt.contiguous()), B, H, nq, nb,
+                                      _p(pidx), _p(pcnt)), "jenga_pair_merge")
+    return pidx, pcnt
 
 
 def ulysses_pack_heads(x, n_ranks, out=None):

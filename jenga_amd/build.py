@@ -17,6 +17,9 @@ SOURCES = [
     # no NaNs are produced on the attention path (masked logits are -inf, never inf-inf); without this flag every
     # fmaxf on an MFMA result is preceded by a canonicalising v_max.  Infinities stay honoured.
     ("bsattn.hip", ["-fno-honor-nans"]),
+    # no SLP vectorisation: v_pk_add_f32 beside MFMAs costs more than the two scalar adds it replaces (guide, per-
+    # instruction table); the softmax of the pair kernel is placed instruction by instruction into the MFMA gaps
+    ("bsattn2.hip", ["-fno-honor-nans", "-fno-slp-vectorize"]),
 ]
 
 

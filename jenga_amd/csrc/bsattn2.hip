@@ -1,0 +1,794 @@
+// Block-sparse attention forward, second generation ("pair kernel"), gfx950, head_dim 128, 128-token blocks.
+//
+// What changed against bsattn.hip (kept as the legacy path, JENGA_ATTN_LEGACY):
+//   * a workgroup = 4 waves = TWO Hilbert-adjacent query blocks A, B of one head (256 query rows).  Wave w owns rows
+//     [32w, 32w+32) of A and the same rows of B, so all four SIMDs carry the same load whatever the lists look like.
+//   * the two kept lists are merged beforehand (jenga_pair_merge) into three ascending lists: kv blocks both query
+//     blocks keep, blocks only A keeps, blocks only B keeps.  A "both" block is staged into LDS ONCE for 256 query
+//     rows -- half the fabric / LDS-DMA bytes per FLOP of the 128-row kernel; an A-only / B-only block costs what it
+//     cost before.  The kv order inside a row changes (A-only, then B-only, then shared) -- online softmax does not
+//     care, and every rescale factor stays an exact power of two.
+//   * ONE wave per SIMD with the whole 512-entry register file.  The unit of work is an ITEM = (32-row sub-block,
+//     64-key tile): QK^T (16 MFMAs) -> softmax (~110 VALU) -> P.V (16 MFMAs).  Items are software-pipelined inside
+//     the wave: basic block i issues  P.V of item i-2  +  QK^T of item i  (32 MFMAs)  with the softmax of item i-1
+//     interleaved into the MFMA gaps (sched_group_barrier) -- MFMA and VALU of DIFFERENT waves do not overlap on a
+//     gfx950 SIMD, MFMA and VALU of the same wave do.
+//       A-only / B-only block : items (X,h0) (X,h1)                 -> one step, one barrier, 2 K + 2 V tiles staged
+//       shared block          : items (A,h0) (B,h0) | (A,h1) (B,h1) -> two steps, each 1 K + 1 V tile staged
+//   * lazy integer running max without a "first tile" special case: m~ starts at 0; a wave-wide ballot on
+//     (row sum > 2^8  ||  running l < 2^-60) sends the wave through the exact max-first path, which moves m~ up OR
+//     down by an integer step.
+//
+// MFMA formulation, LDS tile images, V pre-tiling, numerics: identical to bsattn.hip (see its header); reference
+// semantics attention_block_triton_diffres.py:38-136 (image rows) and :371-380 (text rows, TEXT=true).
+#include "common.h"
+
+#ifndef JENGA_PIN_Q
+#define JENGA_PIN_Q 3   // bit 0 / 1: keep the Q fragments of sub-block A / B in the accumulator registers
+#endif
+#ifndef JENGA_RD_AHEAD
+#define JENGA_RD_AHEAD 8
+#endif
+
+namespace jenga {
+namespace {
+
+struct PairParams {
+    const uint16_t* q;
+    const uint16_t* k;
+    const uint16_t* vt;
+    uint16_t* o;
+    const int32_t* seqlens;
+    const int32_t* pidx;   // [B,H,npair_img,n_blocks]: shared blocks, then A-only, then B-only (each ascending)
+    const int32_t* pcnt;   // [B,H,npair_img,4]: n_shared, n_a, n_b, 0
+    long long q_sb, q_ss, q_sh, k_sb, k_ss, k_sh, o_sb, o_ss, o_sh;
+    int B, H, n_blocks, nq_img;
+    int npair_img, npair_txt;
+    int text_block_start;
+    float qk_scale;   // sm_scale * log2(e)
+    float text_amp;
+    int n_text_wg_pad;
+    int img_per_head;
+    int xcd_chunk;
+};
+
+constexpr int TILE_BYTES = 16384;          // one 64-key K tile [64][128] or V^T tile [128][64]
+constexpr int BLK_BYTES = 2 * TILE_BYTES;  // a 128-key block: tile h0, tile h1
+constexpr int K_RING = 0;                  // two block slots
+constexpr int V_RING = 2 * BLK_BYTES;      // two block slots
+constexpr int P2_LDS_BYTES = 4 * BLK_BYTES;   // 128 KiB
+
+constexpr float RAISE_SUM = 256.0f;        // 2^8: P = exp2(S - m~) stays <= 2^8
+constexpr float TINY_SUM = 8.673617379884035e-19f;   // 2^-60: everything seen so far is negligible -> lower m~
+
+// Four 1-KiB LDS-DMA pieces of one wave (global_load_lds_dwordx4): uniform base in SGPRs + per-lane byte offsets,
+// destination M0 advanced by 1 KiB per piece.  Inline asm on purpose (bsattn.hip: the builtin makes hipcc drain
+// vmcnt(0) before the next ds_read); the kernel counts and waits itself.
+__device__ __forceinline__ void stage4(const void* base, unsigned lds, unsigned o0, unsigned o1, unsigned o2,
+                                       unsigned o3) {
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %1\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %3, %2\n\t"
+        "s_add_u32 m0, m0, 0x400\n\t"
+        "global_load_lds_dwordx4 %4, %2\n\t"
+        "s_add_u32 m0, m0, 0x400\n\t"
+        "global_load_lds_dwordx4 %5, %2\n\t"
+        "s_add_u32 m0, m0, 0x400\n\t"
+        "global_load_lds_dwordx4 %6, %2\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "s"(lds), "s"(base), "v"(o0), "v"(o1), "v"(o2), "v"(o3)
+        : "memory", "scc");
+}
+#define DMA_WAIT_ALL() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+
+// One 32-row sub-block (A or B) of the wave: Q fragments, O accumulators, running sum, -m~.
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint4 as_u4(const u32x4& v) { return __builtin_bit_cast(uint4, v); }
+
+struct Sub {
+    u32x4 qf[8];    // lives in the accumulator half of the register file (see load_sub)
+    f32x16 o[4];
+    float l;
+    float neg_m;
+};
+
+template <typename T> __device__ __forceinline__ void pack_p(const float (&e0)[16], const float (&e1)[16], uint4 (&pf)[4]) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        pf[j] = make_uint4(pack2<T>(e0[8 * j + 0], e0[8 * j + 1]), pack2<T>(e0[8 * j + 2], e0[8 * j + 3]),
+                           pack2<T>(e0[8 * j + 4], e0[8 * j + 5]), pack2<T>(e0[8 * j + 6], e0[8 * j + 7]));
+        pf[2 + j] = make_uint4(pack2<T>(e1[8 * j + 0], e1[8 * j + 1]), pack2<T>(e1[8 * j + 2], e1[8 * j + 3]),
+                               pack2<T>(e1[8 * j + 4], e1[8 * j + 5]), pack2<T>(e1[8 * j + 6], e1[8 * j + 7]));
+    }
+}
+
+// Exact (max-first) softmax step of one item: moves m~ by an integer, rescales O and l by the exact power of two,
+// recomputes P from the intact raw scores `s0/s1`.
+template <typename T, bool TEXT>
+__device__ __forceinline__ void exact_softmax(Sub& sb, const f32x16& s0, const f32x16& s1, uint4 (&pf)[4], float& psum,
+                                              float qk_scale) {
+    float v0[16], v1[16];
+    float tmax = -INFINITY;
+    // the scores may come straight out of an MFMA (slow_item): an asm read is invisible to the hazard recogniser
+    asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        float r0, r1;   // scores are read out of the accumulator registers explicitly (see item_bb)
+        asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(r0) : "a"(s0[r]));
+        asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(r1) : "a"(s1[r]));
+        v0[r] = TEXT ? r0 * qk_scale + sb.neg_m : r0 + sb.neg_m;
+        v1[r] = TEXT ? r1 * qk_scale + sb.neg_m : r1 + sb.neg_m;
+        tmax = fmaxf(tmax, fmaxf(v0[r], v1[r]));
+    }
+    tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+    float lsum = sb.l + psum;
+    lsum += __shfl_xor(lsum, 32);
+    const bool move = (tmax > 0.f) || (lsum < TINY_SUM);
+    const float delta = (move && tmax > -1e30f) ? fmaxf(ceilf(tmax), -120.f) : 0.f;
+    const float f2 = __builtin_amdgcn_exp2f(-delta);
+    sb.neg_m -= delta;
+    sb.l *= f2;
+    // O lives in the accumulator registers and is rescaled IN PLACE there: written as plain `o *= f2`, hipcc keeps
+    // the rescaled copy in VGPRs and pays for it on the hot path (64-128 v_accvgpr moves per basic block to bring both
+    // versions to one place at the join).  s_nop 15: the last P.V MFMA of this accumulator may still be in flight and
+    // nothing inside an asm statement is covered by the compiler's hazard recogniser; s_nop 1 after the last write
+    // covers v_accvgpr_write -> MFMA srcC.
+    asm volatile("s_nop 15" ::: "memory");
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float t_;
+            asm volatile("v_accvgpr_read_b32 %1, %0\n\tv_mul_f32 %1, %1, %2\n\ts_nop 0\n\tv_accvgpr_write_b32 %0, %1"
+                         : "+a"(sb.o[i][r]), "=&v"(t_)
+                         : "v"(f2));
+        }
+    asm volatile("s_nop 1" ::: "memory");
+    float e0[16], e1[16];
+    psum = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        e0[r] = __builtin_amdgcn_exp2f(v0[r] - delta);
+        e1[r] = __builtin_amdgcn_exp2f(v1[r] - delta);
+        psum += e0[r] + e1[r];
+    }
+    pack_p<T>(e0, e1, pf);
+}
+
+// Basic block i of the item pipeline:
+//   DO_QK: sn = K(kt) . Q(sqk)                      item i     MFMA  0..15
+//   DO_PV: O(spv) += V^T(vt) . P(pf_old)            item i-2   MFMA 16..31
+//   DO_SM: pf_new = bf16(exp2(sp - m~)), l += sum   item i-1   one score per MFMA gap
+// then the wave-uniform check for the exact path of item i-1 (P.V of item i-2 is complete, P.V of item i-1 has not
+// started: cdna guide T13's safe order).
+// Hand-placed stream, one sched_barrier(0)-fenced slot per MFMA:  MFMA m | ds_read of the fragment of MFMA m+8 |
+// softmax of score m in three skewed stages (t = s - m~ in slot m, exp2 in slot m+1, row-sum add and bf16 pack in slot
+// m+2), i.e. 4-5 single-issue fillers per 32-cycle MFMA gap (the guide's budget for one wave per SIMD).  Left to
+// itself on an unfenced 32-MFMA region hipcc read the P.V fragments just in time (an LDS round trip in front of every
+// MFMA), issued the MFMAs in clumps of three with the VALU work behind them, and moved O between the register halves.
+template <typename T, bool TEXT, bool DO_PV, bool DO_QK, bool DO_SM>
+__device__ __forceinline__ void item_bb(const unsigned char* vt, Sub& spv, const uint4 (&pf_old)[4],
+                                        const unsigned char* kt, Sub& sqk, f32x16& sn0, f32x16& sn1, Sub& ssm,
+                                        const f32x16& sp0, const f32x16& sp1, uint4 (&pf_new)[4],
+                                        const int (&k_addr)[8], const int (&v_addr)[4], float qk_scale) {
+    f32x16 zero16;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) zero16[r] = 0.f;
+    uint4 fr[32];
+    float tt[32], xx[32];
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    uint32_t ww[16];
+#define BB_READ(M_)                                                                                                   \
+    do {                                                                                                              \
+        if ((M_) < 16) {                                                                                              \
+            if (DO_QK) fr[M_] = *reinterpret_cast<const uint4*>(kt + k_addr[(M_) >> 1] + ((M_) & 1) * 8192);          \
+        } else if ((M_) < 32) {                                                                                       \
+            if (DO_PV) fr[M_] = *reinterpret_cast<const uint4*>(vt + v_addr[((M_) - 16) >> 2] + (((M_) - 16) & 3) * 4096); \
+        }                                                                                                             \
+    } while (0)
+#define BB_SCORE(E_) ((E_) < 16 ? sp0[(E_) & 15] : sp1[(E_) & 15])
+#define BB_SM(M_)                                                                                                     \
+    do {                                                                                                              \
+        if (DO_SM) {                                                                                                  \
+            if ((M_) < 32) {                                                                                          \
+                float sv_;   /* the scores stay in the accumulator registers; read each one in ITS slot */           \
+                asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(sv_) : "a"(BB_SCORE(M_)));                            \
+                tt[(M_) & 31] = TEXT ? sv_ * qk_scale + ssm.neg_m : sv_ + ssm.neg_m;                                  \
+            }                                                                                                         \
+            if ((M_) >= 1 && (M_) < 33) xx[((M_) - 1) & 31] = __builtin_amdgcn_exp2f(tt[((M_) - 1) & 31]);            \
+            if ((M_) >= 2 && (M_) < 34) {                                                                             \
+                acc[((M_) - 2) & 3] += xx[((M_) - 2) & 31];                                                           \
+                if (((M_) - 2) & 1) ww[(((M_) - 2) & 31) >> 1] = pack2<T>(xx[((M_) - 3) & 31], xx[((M_) - 2) & 31]);  \
+            }                                                                                                         \
+        }                                                                                                             \
+    } while (0)
+#define BB_SLOT(M_)                                                                                                   \
+    do {                                                                                                              \
+        if ((M_) < 16) {                                                                                              \
+            if (DO_QK) {                                                                                              \
+                if ((M_) & 1) sn1 = mfma32<T>(fr[M_], as_u4(sqk.qf[(M_) >> 1]), (M_) < 2 ? zero16 : sn1);             \
+                else sn0 = mfma32<T>(fr[M_], as_u4(sqk.qf[(M_) >> 1]), (M_) < 2 ? zero16 : sn0);                      \
+            }                                                                                                         \
+        } else if (DO_PV) {                                                                                           \
+            spv.o[((M_) - 16) & 3] = mfma32<T>(fr[M_], pf_old[((M_) - 16) >> 2], spv.o[((M_) - 16) & 3]);             \
+        }                                                                                                             \
+        BB_READ((M_) + 8);                                                                                            \
+        BB_SM(M_);                                                                                                    \
+        __builtin_amdgcn_sched_barrier(0);                                                                            \
+    } while (0)
+    BB_READ(0); BB_READ(1); BB_READ(2); BB_READ(3); BB_READ(4); BB_READ(5); BB_READ(6); BB_READ(7);
+    if (!DO_QK) {   // (fill / drain forms) the P.V fragments have no slots 0..15 to be read from
+        BB_READ(16); BB_READ(17); BB_READ(18); BB_READ(19); BB_READ(20); BB_READ(21); BB_READ(22); BB_READ(23);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    BB_SLOT(0); BB_SLOT(1); BB_SLOT(2); BB_SLOT(3); BB_SLOT(4); BB_SLOT(5); BB_SLOT(6); BB_SLOT(7);
+    BB_SLOT(8); BB_SLOT(9); BB_SLOT(10); BB_SLOT(11); BB_SLOT(12); BB_SLOT(13); BB_SLOT(14); BB_SLOT(15);
+    BB_SLOT(16); BB_SLOT(17); BB_SLOT(18); BB_SLOT(19); BB_SLOT(20); BB_SLOT(21); BB_SLOT(22); BB_SLOT(23);
+    BB_SLOT(24); BB_SLOT(25); BB_SLOT(26); BB_SLOT(27); BB_SLOT(28); BB_SLOT(29); BB_SLOT(30); BB_SLOT(31);
+    BB_SM(32);
+    BB_SM(33);
+#undef BB_READ
+#undef BB_SCORE
+#undef BB_SM
+#undef BB_SLOT
+    // The NEXT block reads these scores with inline-asm v_accvgpr_read (invisible to the hazard recogniser).  In the
+    // steady state 16 P.V MFMAs separate the last QK^T MFMA from that read; the pipeline-fill forms have no P.V tail.
+    if (DO_QK && !DO_PV) asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");
+    if (DO_SM) {
+        float psum = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+        pf_new[0] = make_uint4(ww[0], ww[1], ww[2], ww[3]);
+        pf_new[1] = make_uint4(ww[4], ww[5], ww[6], ww[7]);
+        pf_new[2] = make_uint4(ww[8], ww[9], ww[10], ww[11]);
+        pf_new[3] = make_uint4(ww[12], ww[13], ww[14], ww[15]);
+        if (__any(!(psum <= RAISE_SUM) || (ssm.l + psum < TINY_SUM)))
+            exact_softmax<T, TEXT>(ssm, sp0, sp1, pf_new, psum, qk_scale);
+        ssm.l += psum;
+    }
+}
+
+// Unpipelined item with the text_amp add and the kv-length mask: the few blocks at the tail of the ascending lists
+// (text blocks, a padded last image block).  A tile entirely past seqlen is skipped (it contributes exp2(-inf) = 0).
+template <typename T>
+__device__ __forceinline__ void slow_item(Sub& sb, const unsigned char* kt, const unsigned char* vt, int blk, int half,
+                                          int seqlen, int text_block_start, float text_amp, int hi,
+                                          const int (&k_addr)[8], const int (&v_addr)[4]) {
+    const int key0 = blk * 128 + half * 64;
+    if (key0 >= seqlen) return;
+    f32x16 s0, s1;
+    {
+        uint4 ka[8], kb[8];
+#pragma unroll
+        for (int ds = 0; ds < 8; ++ds) {
+            ka[ds] = *reinterpret_cast<const uint4*>(kt + k_addr[ds]);
+            kb[ds] = *reinterpret_cast<const uint4*>(kt + k_addr[ds] + 8192);
+        }
+        f32x16 zero16;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) zero16[r] = 0.f;
+        s0 = mfma32<T>(ka[0], as_u4(sb.qf[0]), zero16);
+        s1 = mfma32<T>(kb[0], as_u4(sb.qf[0]), zero16);
+#pragma unroll
+        for (int ds = 1; ds < 8; ++ds) {
+            s0 = mfma32<T>(ka[ds], as_u4(sb.qf[ds]), s0);
+            s1 = mfma32<T>(kb[ds], as_u4(sb.qf[ds]), s1);
+        }
+    }
+    if (blk >= text_block_start) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            s0[r] += text_amp;
+            s1[r] += text_amp;
+        }
+    }
+    if (key0 + 64 > seqlen) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int kk = key0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+            if (kk >= seqlen) s0[r] = -INFINITY;
+            if (kk + 32 >= seqlen) s1[r] = -INFINITY;
+        }
+    }
+    uint4 pf[4];
+    float psum = 0.f;
+    exact_softmax<T, false>(sb, s0, s1, pf, psum, 0.f);
+    sb.l += psum;
+    {
+        uint4 va[4][4];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int db = 0; db < 4; ++db) va[ks][db] = *reinterpret_cast<const uint4*>(vt + v_addr[ks] + db * 4096);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int db = 0; db < 4; ++db) sb.o[db] = mfma32<T>(va[ks][db], pf[ks], sb.o[db]);
+    }
+}
+
+template <typename T, bool TEXT, bool PIN>
+__device__ __forceinline__ void load_sub(Sub& sb, const PairParams& P, int b, int h, long long qrow, int hi, bool on) {
+    const uint16_t* qp = P.q + b * P.q_sb + qrow * P.q_ss + h * P.q_sh + hi * 8;
+#pragma unroll
+    for (int ds = 0; ds < 8; ++ds) {
+        uint4 raw = make_uint4(0u, 0u, 0u, 0u);
+        if (on) {
+            raw = *reinterpret_cast<const uint4*>(qp + ds * 16);
+            if (!TEXT) {   // q~ = dtype(q * sm_scale * log2 e)   (reference :87-88)
+                float f[8];
+                unpack8<T>(raw, f);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) f[e] = f[e] * P.qk_scale;
+                raw = pack8<T>(f);
+            }
+        }
+        // keep Q in the accumulator half of the register file (MFMA reads A/B operands from there directly on gfx950):
+        // O (128) + S (64) + Q (64) fill the 256 AGPRs, the 256 VGPRs stay free for fragments, P and the softmax.
+        u32x4 rv = __builtin_bit_cast(u32x4, raw);
+        if (PIN) asm volatile("" : "+a"(rv));
+        sb.qf[ds] = rv;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sb.o[i][r] = 0.f;
+    sb.l = 0.f;
+    sb.neg_m = 0.f;
+}
+
+template <typename T>
+__device__ __forceinline__ void store_sub(const Sub& sb, uint16_t* op, bool row_ok) {
+    const float l_tot = sb.l + __shfl_xor(sb.l, 32);
+#pragma unroll
+    for (int db = 0; db < 4; ++db) {
+#pragma unroll
+        for (int rq = 0; rq < 4; ++rq) {
+            uint2 w = make_uint2(0u, 0u);
+            if (row_ok) {
+                w.x = pack2<T>(__fdiv_rn(sb.o[db][rq * 4 + 0], l_tot), __fdiv_rn(sb.o[db][rq * 4 + 1], l_tot));
+                w.y = pack2<T>(__fdiv_rn(sb.o[db][rq * 4 + 2], l_tot), __fdiv_rn(sb.o[db][rq * 4 + 3], l_tot));
+            }
+            *reinterpret_cast<uint2*>(op + db * 32 + rq * 8) = w;
+        }
+    }
+}
+
+// One workgroup: query blocks mA (and mB = mA + 1 if has_b) of head (b, h).
+template <typename T, bool TEXT>
+__device__ __forceinline__ void attn_pair(const PairParams& P, unsigned char* smem, int b, int h, int mA, bool has_b,
+                                          const int32_t* list, int n_sh, int n_a, int n_b) {
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lq = lane & 31, hi = lane >> 5;
+    const int seqlen = P.seqlens ? __builtin_amdgcn_readfirstlane(P.seqlens[b]) : P.n_blocks * 128;
+    const int n_ab = n_a + n_b, n_tot = n_ab + n_sh;
+
+    Sub A, B;
+    const long long qrowA = (long long)mA * 128 + wave_u * 32 + lq;
+    const long long qrowB = qrowA + 128;
+    load_sub<T, TEXT, (JENGA_PIN_Q & 1) != 0>(A, P, b, h, qrowA, hi, true);
+    load_sub<T, TEXT, (JENGA_PIN_Q & 2) != 0>(B, P, b, h, qrowB, hi, has_b);
+    uint16_t* const opA = P.o + b * P.o_sb + qrowA * P.o_ss + h * P.o_sh + hi * 4;
+    uint16_t* const opB = opA + 128 * P.o_ss;
+
+    const uint16_t* kbh = P.k + b * P.k_sb + h * P.k_sh;
+    const uint16_t* vbh = P.vt + ((long long)b * P.H + h) * (long long)P.n_blocks * (2 * 128 * 64);
+
+    // per-lane LDS read addresses: K tile rows = keys, 16-B chunk index XOR (row & 15); V^T rows = d, XOR ((d>>1)&7)
+    int k_addr[8], v_addr[4];
+#pragma unroll
+    for (int ds = 0; ds < 8; ++ds) k_addr[ds] = K_RING + lq * 256 + (((ds * 2 + hi) ^ (lq & 15)) << 4);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+        v_addr[ks] = V_RING + lq * 128 + ((((ks >> 1) * 4 + hi * 2 + (ks & 1)) ^ ((lq >> 1) & 7)) << 4);
+    // per-lane LDS-DMA source offsets (bytes) of this wave's four K and four V^T pieces of a tile (bsattn.hip)
+    const unsigned smem_base =
+        __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem);
+    const int kr_ = 16 * wave_u + (lane >> 4), kc_ = lane & 15, ksw_ = lane >> 4;
+    const unsigned kss_b = (unsigned)P.k_ss * 2u;
+    const unsigned k_src0 = (unsigned)(kr_ + 0) * kss_b + ((kc_ ^ (0 + ksw_)) << 4);
+    const unsigned k_src1 = (unsigned)(kr_ + 4) * kss_b + ((kc_ ^ (4 + ksw_)) << 4);
+    const unsigned k_src2 = (unsigned)(kr_ + 8) * kss_b + ((kc_ ^ (8 + ksw_)) << 4);
+    const unsigned k_src3 = (unsigned)(kr_ + 12) * kss_b + ((kc_ ^ (12 + ksw_)) << 4);
+    const int vr_ = 32 * wave_u + (lane >> 3), vc_ = lane & 7, vsw_ = lane >> 4;
+    const unsigned v_src0 = (unsigned)(vr_ + 0) * 128 + ((vc_ ^ ((0 + vsw_) & 7)) << 4);
+    const unsigned v_src1 = (unsigned)(vr_ + 8) * 128 + ((vc_ ^ ((4 + vsw_) & 7)) << 4);
+    const unsigned v_src2 = (unsigned)(vr_ + 16) * 128 + ((vc_ ^ ((8 + vsw_) & 7)) << 4);
+    const unsigned v_src3 = (unsigned)(vr_ + 24) * 128 + ((vc_ ^ ((12 + vsw_) & 7)) << 4);
+
+    // ---- block stream: position p = 0..n_tot-1 in processing order (A-only, B-only, shared) -> kv block id ----
+    // The merged list is read 64 entries at a time into one VGPR and entries are pulled out with v_readlane
+    // (a per-block `list[i]` is a vector load whose vmcnt(0) would drain the LDS-DMA prefetch every block).
+    int lchunk = 0, lbase = -64;
+    auto blk_at = [&](int p) -> int {
+        if (TEXT) return p;
+        const int li = (p < n_ab) ? n_sh + p : p - n_ab;
+        if (li < lbase || li >= lbase + 64) {
+            lbase = li & ~63;
+            lchunk = (lbase + lane < n_tot) ? list[lbase + lane] : 0;
+        }
+        return __builtin_amdgcn_readlane(lchunk, li - lbase);
+    };
+    // LDS-DMA of block p (stream position): K -> K slot p&1, V^T -> V slot p&1; 8 pieces per wave each.
+    auto issue_k = [&](int p, int half) {   // one K tile (64 keys)
+        const int blk = blk_at(p);
+        stage4(kbh + ((long long)blk * 128 + half * 64) * P.k_ss,
+               smem_base + K_RING + (p & 1) * BLK_BYTES + half * TILE_BYTES + wave_u * 4096, k_src0, k_src1, k_src2,
+               k_src3);
+    };
+    auto issue_v = [&](int p, int half) {   // one V^T tile
+        const int blk = blk_at(p);
+        stage4(vbh + ((long long)blk * 2 + half) * (128 * 64),
+               smem_base + V_RING + (p & 1) * BLK_BYTES + half * TILE_BYTES + wave_u * 4096, v_src0, v_src1, v_src2,
+               v_src3);
+    };
+    auto kslot = [&](int p, int half) { return smem + (p & 1) * BLK_BYTES + half * TILE_BYTES; };   // + k_addr (K_RING inside)
+    auto vslot = [&](int p, int half) { return smem + (p & 1) * BLK_BYTES + half * TILE_BYTES; };   // + v_addr (V_RING inside)
+    auto end_step = [&]() {
+        DMA_WAIT_ALL();
+        __syncthreads();
+    };
+
+    // how many blocks at the tail of a (ascending) segment need the text_amp / kv-length path
+    auto n_slow_tail = [&](int p0, int p1) -> int {
+        if (TEXT) return 0;
+        int n = 0;
+        while (p1 - n > p0) {
+            const int bl = blk_at(p1 - n - 1);
+            if (bl >= P.text_block_start || (bl + 1) * 128 > seqlen) ++n; else break;
+        }
+        return n;
+    };
+
+    f32x16 sX0, sX1, sY0, sY1;
+    uint4 pfX[4], pfY[4];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sX0[r] = sX1[r] = sY0[r] = sY1[r] = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) pfX[i] = pfY[i] = make_uint4(0u, 0u, 0u, 0u);
+
+    // prologue: K of the first block
+    if (n_tot > 0) {
+        issue_k(0, 0);
+        issue_k(0, 1);
+    }
+    end_step();
+
+    // ---- a segment of single-list blocks [p0, p1): items (X,h0), (X,h1) per block, one step per block ----
+#define SEG_SINGLE(X, P0, P1)                                                                                         \
+    do {                                                                                                              \
+        const int p0_ = (P0), p1_ = (P1);                                                                             \
+        const int pf_end = p1_ - n_slow_tail(p0_, p1_);                                                               \
+        if (pf_end > p0_) {                                                                                           \
+            /* fill: no P.V yet */                                                                                    \
+            issue_v(p0_, 0);                                                                                          \
+            issue_v(p0_, 1);                                                                                          \
+            item_bb<T, TEXT, false, true, false>(nullptr, X, pfX, kslot(p0_, 0), X, sX0, sX1, X, sY0, sY1, pfY, \
+                                                       k_addr, v_addr, P.qk_scale);                                   \
+            if (p0_ + 1 < n_tot) {                                                                                    \
+                issue_k(p0_ + 1, 0);                                                                                  \
+                issue_k(p0_ + 1, 1);                                                                                  \
+            }                                                                                                         \
+            item_bb<T, TEXT, false, true, true>(nullptr, X, pfY, kslot(p0_, 1), X, sY0, sY1, X, sX0, sX1, pfX,  \
+                                                      k_addr, v_addr, P.qk_scale);                                    \
+            end_step();                                                                                               \
+            for (int p = p0_ + 1; p < pf_end; ++p) {                                                                  \
+                issue_v(p, 0);                                                                                        \
+                issue_v(p, 1);                                                                                        \
+                item_bb<T, TEXT, true, true, true>(vslot(p - 1, 0), X, pfX, kslot(p, 0), X, sX0, sX1, X, sY0,   \
+                                                         sY1, pfY, k_addr, v_addr, P.qk_scale);                       \
+                if (p + 1 < n_tot) {                                                                                  \
+                    issue_k(p + 1, 0);                                                                                \
+                    issue_k(p + 1, 1);                                                                                \
+                }                                                                                                     \
+                item_bb<T, TEXT, true, true, true>(vslot(p - 1, 1), X, pfY, kslot(p, 1), X, sY0, sY1, X, sX0,   \
+                                                         sX1, pfX, k_addr, v_addr, P.qk_scale);                       \
+                end_step();                                                                                           \
+            }                                                                                                         \
+            /* drain: P.V of the last block's two items */                                                            \
+            item_bb<T, TEXT, true, false, true>(vslot(pf_end - 1, 0), X, pfX, nullptr, X, sX0, sX1, X, sY0,     \
+                                                      sY1, pfY, k_addr, v_addr, P.qk_scale);                          \
+            item_bb<T, TEXT, true, false, false>(vslot(pf_end - 1, 1), X, pfY, nullptr, X, sY0, sY1, X, sX0,    \
+                                                       sX1, pfX, k_addr, v_addr, P.qk_scale);                         \
+        }                                                                                                             \
+        if (!TEXT) {                                                                                                  \
+            for (int p = pf_end; p < p1_; ++p) {   /* text_amp / kv-length blocks, unpipelined */                     \
+                issue_v(p, 0);                                                                                        \
+                issue_v(p, 1);                                                                                        \
+                if (p + 1 < n_tot) {                                                                                  \
+                    issue_k(p + 1, 0);                                                                                \
+                    issue_k(p + 1, 1);                                                                                \
+                }                                                                                                     \
+                end_step();                                                                                           \
+                const int bl = blk_at(p);                                                                             \
+                slow_item<T>(X, kslot(p, 0), vslot(p, 0), bl, 0, seqlen, P.text_block_start, P.text_amp, hi, k_addr,  \
+                             v_addr);                                                                                 \
+                slow_item<T>(X, kslot(p, 1), vslot(p, 1), bl, 1, seqlen, P.text_block_start, P.text_amp, hi, k_addr,  \
+                             v_addr);                                                                                 \
+                __syncthreads();                                                                                      \
+            }                                                                                                         \
+        }                                                                                                             \
+    } while (0)
+
+    SEG_SINGLE(A, 0, n_a);
+    SEG_SINGLE(B, n_a, n_ab);
+
+    // ---- the shared blocks [n_ab, n_tot): items (A,h) (B,h) per step, two steps per block ----
+    {
+        const int p0_ = n_ab, p1_ = n_tot;
+        const int pf_end = p1_ - n_slow_tail(p0_, p1_);
+        if (pf_end > p0_) {
+            // fill
+            issue_v(p0_, 0);
+            item_bb<T, TEXT, false, true, false>(nullptr, A, pfX, kslot(p0_, 0), A, sX0, sX1, B, sY0, sY1, pfY,
+                                                        k_addr, v_addr, P.qk_scale);
+            item_bb<T, TEXT, false, true, true>(nullptr, B, pfY, kslot(p0_, 0), B, sY0, sY1, A, sX0, sX1, pfX,
+                                                       k_addr, v_addr, P.qk_scale);
+            end_step();
+            issue_v(p0_, 1);
+            if (p0_ + 1 < n_tot) {
+                issue_k(p0_ + 1, 0);
+                issue_k(p0_ + 1, 1);
+            }
+            item_bb<T, TEXT, true, true, true>(vslot(p0_, 0), A, pfX, kslot(p0_, 1), A, sX0, sX1, B, sY0, sY1,
+                                                      pfY, k_addr, v_addr, P.qk_scale);
+            item_bb<T, TEXT, true, true, true>(vslot(p0_, 0), B, pfY, kslot(p0_, 1), B, sY0, sY1, A, sX0, sX1,
+                                                      pfX, k_addr, v_addr, P.qk_scale);
+            end_step();
+            for (int p = p0_ + 1; p < pf_end; ++p) {
+                issue_v(p, 0);
+                item_bb<T, TEXT, true, true, true>(vslot(p - 1, 1), A, pfX, kslot(p, 0), A, sX0, sX1, B, sY0,
+                                                          sY1, pfY, k_addr, v_addr, P.qk_scale);
+                item_bb<T, TEXT, true, true, true>(vslot(p - 1, 1), B, pfY, kslot(p, 0), B, sY0, sY1, A, sX0,
+                                                          sX1, pfX, k_addr, v_addr, P.qk_scale);
+                end_step();
+                issue_v(p, 1);
+                if (p + 1 < n_tot) {
+                    issue_k(p + 1, 0);
+                    issue_k(p + 1, 1);
+                }
+                item_bb<T, TEXT, true, true, true>(vslot(p, 0), A, pfX, kslot(p, 1), A, sX0, sX1, B, sY0, sY1,
+                                                          pfY, k_addr, v_addr, P.qk_scale);
+                item_bb<T, TEXT, true, true, true>(vslot(p, 0), B, pfY, kslot(p, 1), B, sY0, sY1, A, sX0, sX1,
+                                                          pfX, k_addr, v_addr, P.qk_scale);
+                end_step();
+            }
+            // drain
+            item_bb<T, TEXT, true, false, true>(vslot(pf_end - 1, 1), A, pfX, nullptr, A, sX0, sX1, B, sY0, sY1,
+                                                       pfY, k_addr, v_addr, P.qk_scale);
+            item_bb<T, TEXT, true, false, false>(vslot(pf_end - 1, 1), B, pfY, nullptr, B, sY0, sY1, A, sX0, sX1,
+                                                        pfX, k_addr, v_addr, P.qk_scale);
+        }
+        if (!TEXT) {
+            for (int p = pf_end; p < p1_; ++p) {
+                issue_v(p, 0);
+                issue_v(p, 1);
+                if (p + 1 < n_tot) {
+                    issue_k(p + 1, 0);
+                    issue_k(p + 1, 1);
+                }
+                end_step();
+                const int bl = blk_at(p);
+                slow_item<T>(A, kslot(p, 0), vslot(p, 0), bl, 0, seqlen, P.text_block_start, P.text_amp, hi, k_addr,
+                             v_addr);
+                slow_item<T>(B, kslot(p, 0), vslot(p, 0), bl, 0, seqlen, P.text_block_start, P.text_amp, hi, k_addr,
+                             v_addr);
+                slow_item<T>(A, kslot(p, 1), vslot(p, 1), bl, 1, seqlen, P.text_block_start, P.text_amp, hi, k_addr,
+                             v_addr);
+                slow_item<T>(B, kslot(p, 1), vslot(p, 1), bl, 1, seqlen, P.text_block_start, P.text_amp, hi, k_addr,
+                             v_addr);
+                __syncthreads();
+            }
+        }
+    }
+#undef SEG_SINGLE
+    DMA_WAIT_ALL();
+
+    store_sub<T>(A, opA, TEXT || (qrowA < seqlen));
+    if (has_b) store_sub<T>(B, opB, TEXT || (qrowB < seqlen));
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256, 1) bsattn_pair_kernel(PairParams P) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int n_text = P.n_blocks - P.nq_img;
+    const int id = blockIdx.x;
+    if (id < P.n_text_wg_pad) {   // text query blocks first: the longest work items start earliest
+        if (id >= P.B * P.H * P.npair_txt) return;
+        const int pr = id % P.npair_txt;
+        const int bh = id / P.npair_txt;
+        const bool has_b = 2 * pr + 1 < n_text;
+        attn_pair<T, true>(P, smem, bh / P.H, bh % P.H, P.nq_img + 2 * pr, has_b, nullptr, has_b ? P.n_blocks : 0,
+                           has_b ? 0 : P.n_blocks, 0);
+        return;
+    }
+    const int li = id - P.n_text_wg_pad;
+    const int bh = li / P.img_per_head;
+    const int r = li % P.img_per_head;
+    int pr;
+    if (P.xcd_chunk) {   // workgroup id -> XCD is id % 8: give each XCD a contiguous range of query-block pairs
+        pr = (r & 7) * P.xcd_chunk + (r >> 3);
+        if ((r >> 3) >= P.xcd_chunk || pr >= P.npair_img) return;
+    } else {
+        pr = r;
+    }
+    const long long row = (long long)bh * P.npair_img + pr;
+    const int32_t* list = P.pidx + row * P.n_blocks;
+    const int n_sh = __builtin_amdgcn_readfirstlane(P.pcnt[row * 4 + 0]);
+    const int n_a = __builtin_amdgcn_readfirstlane(P.pcnt[row * 4 + 1]);
+    const int n_b = __builtin_amdgcn_readfirstlane(P.pcnt[row * 4 + 2]);
+    attn_pair<T, false>(P, smem, bh / P.H, bh % P.H, 2 * pr, 2 * pr + 1 < P.nq_img, list, n_sh, n_a, n_b);
+}
+
+// ------------------------------------------------------------------------------------------------ list merge
+// One wave per query-block pair: the two ascending kept lists -> [shared | A-only | B-only], each ascending.
+constexpr int MERGE_WORDS = 128;   // up to 4096 kv blocks
+__global__ void __launch_bounds__(64) pair_merge_kernel(const int32_t* __restrict__ idx, const int32_t* __restrict__ cnt,
+                                                        int32_t* __restrict__ pidx, int32_t* __restrict__ pcnt,
+                                                        int nq, int npair, int n_blocks) {
+    __shared__ uint32_t bmA[MERGE_WORDS], bmB[MERGE_WORDS];
+    const int lane = threadIdx.x;
+    const long long prow = blockIdx.x;               // bh * npair + pr
+    const long long bh = prow / npair;
+    const int pr = (int)(prow % npair);
+    const long long rowA = bh * nq + 2 * pr;
+    const bool has_b = 2 * pr + 1 < nq;
+    for (int w = lane; w < MERGE_WORDS; w += 64) bmA[w] = bmB[w] = 0u;
+    __syncthreads();
+    const int cA = cnt[rowA], cB = has_b ? cnt[rowA + 1] : 0;
+    for (int i = lane; i < cA; i += 64) {
+        const int j = idx[rowA * n_blocks + i];
+        atomicOr(&bmA[j >> 5], 1u << (j & 31));
+    }
+    for (int i = lane; i < cB; i += 64) {
+        const int j = idx[(rowA + 1) * n_blocks + i];
+        atomicOr(&bmB[j >> 5], 1u << (j & 31));
+    }
+    __syncthreads();
+    const int nwords = (n_blocks + 31) >> 5;
+    int32_t* out = pidx + prow * n_blocks;
+    int base = 0;
+    for (int cat = 0; cat < 3; ++cat) {
+        int run = 0;   // entries of this category written so far (wave-uniform)
+        for (int w0 = 0; w0 < nwords; w0 += 64) {
+            const int w = w0 + lane;
+            uint32_t m = 0u;
+            if (w < nwords) {
+                const uint32_t a = bmA[w], bb = bmB[w];
+                m = cat == 0 ? (a & bb) : cat == 1 ? (a & ~bb) : (bb & ~a);
+            }
+            const int c = __popc(m);
+            int inc = c;   // inclusive wave scan
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const int t = __shfl_up(inc, o);
+                if (lane >= o) inc += t;
+            }
+            int pos = base + run + inc - c;
+            while (m) {
+                const int bit = __ffs(m) - 1;
+                m &= m - 1;
+                out[pos++] = w * 32 + bit;
+            }
+            run += __shfl(inc, 63);
+        }
+        if (lane == 0) pcnt[prow * 4 + cat] = run;
+        base += run;
+    }
+    if (lane == 0) pcnt[prow * 4 + 3] = 0;
+}
+
+}  // namespace
+}  // namespace jenga
+
+using namespace jenga;
+
+extern "C" int jenga_pair_merge(void* stream, const int32_t* idx, const int32_t* cnt, int64_t B, int64_t H,
+                                int64_t nq_img, int64_t n_blocks, int32_t* pidx, int32_t* pcnt) {
+    if (B <= 0 || H <= 0 || nq_img < 0 || n_blocks <= 0 || (nq_img > 0 && (!idx || !cnt || !pidx || !pcnt))) {
+        set_error("jenga_pair_merge: bad arguments");
+        return JENGA_EINVAL;
+    }
+    if (n_blocks > MERGE_WORDS * 32) {
+        set_error("jenga_pair_merge: at most %d kv blocks supported (got %lld)", MERGE_WORDS * 32, (long long)n_blocks);
+        return JENGA_EUNSUPPORTED;
+    }
+    const long long npair = (nq_img + 1) / 2;
+    const long long rows = B * H * npair;
+    if (rows == 0) return JENGA_OK;
+    hipLaunchKernelGGL(pair_merge_kernel, dim3((unsigned)rows), dim3(64), 0, (hipStream_t)stream, idx, cnt, pidx, pcnt,
+                       (int)nq_img, (int)npair, (int)n_blocks);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        set_error("jenga_pair_merge: %s", hipGetErrorString(e));
+        return JENGA_ELAUNCH;
+    }
+    return JENGA_OK;
+}
+
+extern "C" int jenga_bsattn_pair_fwd(void* stream, const void* q, const void* k, const void* vt, void* o,
+                                     const int32_t* seqlens, const int32_t* pidx, const int32_t* pcnt, int64_t B,
+                                     int64_t H, int64_t n_blocks, int64_t nq_img, int64_t q_sb, int64_t q_ss,
+                                     int64_t q_sh, int64_t k_sb, int64_t k_ss, int64_t k_sh, int64_t o_sb, int64_t o_ss,
+                                     int64_t o_sh, float sm_scale, float text_amp, int64_t text_block_start, int dtype,
+                                     int flags) {
+    if (!q || !k || !vt || !o || B <= 0 || H <= 0 || n_blocks <= 0 || nq_img < 0 || nq_img > n_blocks) {
+        set_error("jenga_bsattn_pair_fwd: bad arguments");
+        return JENGA_EINVAL;
+    }
+    if (nq_img > 0 && (!pidx || !pcnt)) {
+        set_error("jenga_bsattn_pair_fwd: pidx/pcnt are required when nq_img > 0");
+        return JENGA_EINVAL;
+    }
+    const int64_t strides[9] = {q_sb, q_ss, q_sh, k_sb, k_ss, k_sh, o_sb, o_ss, o_sh};
+    for (int i = 0; i < 9; ++i)
+        if (strides[i] & 7) {
+            set_error("jenga_bsattn_pair_fwd: strides must be multiples of 8 elements (16-byte rows)");
+            return JENGA_EINVAL;
+        }
+    if (((uintptr_t)q & 15) || ((uintptr_t)k & 15) || ((uintptr_t)vt & 15) || ((uintptr_t)o & 15)) {
+        set_error("jenga_bsattn_pair_fwd: pointers must be 16-byte aligned");
+        return JENGA_EINVAL;
+    }
+    if (dtype != JENGA_BF16 && dtype != JENGA_FP16) {
+        set_error("jenga_bsattn_pair_fwd: dtype must be bf16 or fp16");
+        return JENGA_EUNSUPPORTED;
+    }
+    if (k_ss <= 0 || k_ss > (1 << 23)) {
+        set_error("jenga_bsattn_pair_fwd: key sequence stride %lld out of range", (long long)k_ss);
+        return JENGA_EINVAL;
+    }
+    PairParams P;
+    P.q = (const uint16_t*)q;
+    P.k = (const uint16_t*)k;
+    P.vt = (const uint16_t*)vt;
+    P.o = (uint16_t*)o;
+    P.seqlens = seqlens;
+    P.pidx = pidx;
+    P.pcnt = pcnt;
+    P.q_sb = q_sb; P.q_ss = q_ss; P.q_sh = q_sh;
+    P.k_sb = k_sb; P.k_ss = k_ss; P.k_sh = k_sh;
+    P.o_sb = o_sb; P.o_ss = o_ss; P.o_sh = o_sh;
+    P.B = (int)B; P.H = (int)H; P.n_blocks = (int)n_blocks; P.nq_img = (int)nq_img;
+    P.npair_img = (int)((nq_img + 1) / 2);
+    const long long n_text = n_blocks - nq_img;
+    P.npair_txt = (int)((n_text + 1) / 2);
+    P.text_block_start = (int)text_block_start;
+    P.qk_scale = (float)((double)sm_scale * 1.44269504);
+    P.text_amp = text_amp;
+    const long long n_text_wg = B * H * (long long)P.npair_txt;
+    P.n_text_wg_pad = (int)((n_text_wg + 7) / 8 * 8);
+    if ((flags & JENGA_ATTN_XCD_REMAP) && P.npair_img >= 64) {
+        P.xcd_chunk = (P.npair_img + 7) / 8;
+        P.img_per_head = P.xcd_chunk * 8;
+    } else {
+        P.xcd_chunk = 0;
+        P.img_per_head = P.npair_img;
+    }
+    const long long grid = (long long)P.n_text_wg_pad + B * H * (long long)P.img_per_head;
+    if (grid <= 0 || grid > 0x7fffffffLL) {
+        set_error("jenga_bsattn_pair_fwd: grid size %lld out of range", grid);
+        return JENGA_EINVAL;
+    }
+    const size_t smem = P2_LDS_BYTES;
+    // (cheap; set on every call so that it holds on whichever device / context is current)
+    if (dtype == JENGA_BF16) {
+        (void)hipFuncSetAttribute((const void*)bsattn_pair_kernel<BF16>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)smem);
+        hipLaunchKernelGGL(bsattn_pair_kernel<BF16>, dim3((unsigned)grid), dim3(256), smem, (hipStream_t)stream, P);
+    } else {
+        (void)hipFuncSetAttribute((const void*)bsattn_pair_kernel<FP16>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)smem);
+        hipLaunchKernelGGL(bsattn_pair_kernel<FP16>, dim3((unsigned)grid), dim3(256), smem, (hipStream_t)stream, P);
+    }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        set_error("jenga_bsattn_pair_fwd: %s", hipGetErrorString(e));
+        return JENGA_ELAUNCH;
+    }
+    return JENGA_OK;
+}

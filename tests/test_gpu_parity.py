@@ -202,10 +202,12 @@ def test_sparse_kernel_vs_triton_interpreter_golden(golden_dir, dev, index):
     assert (err > 2e-3).mean() < 2e-3
 
 
-@pytest.mark.parametrize("dt,flags", [("bfloat16", None), ("float16", None), ("bfloat16", 0), ("bfloat16", 3), ("float16", 2)])
+@pytest.mark.parametrize("dt,flags", [("bfloat16", None), ("float16", None), ("bfloat16", 0), ("bfloat16", 5), ("float16", 4),
+                                      ("bfloat16", 3), ("float16", 2)])
 def test_sparse_kernel_vs_oracle(dev, dt, flags):
-    """flags None = the default 4-wave kernel (XCD remap on), 0 = plain workgroup order; 2 / 3 = the experimental 8-wave ping-pong kernel (JENGA_ATTN_PINGPONG,
-    without / with the XCD remap), kept in-tree as a measured alternative and held to the same tolerance."""
+    """flags None = the default pair kernel (two query blocks per workgroup, XCD remap on), 0 = plain workgroup order;
+    4 / 5 = the round-1 kernel (JENGA_ATTN_LEGACY: one query block per 4-wave workgroup); 2 / 3 = the experimental 8-wave
+    ping-pong kernel (JENGA_ATTN_PINGPONG) -- both kept in-tree as measured alternatives and held to the same tolerance."""
     from oracle import attention as oa
     gen = torch.Generator().manual_seed(11)
     H, nb_img, tb = 3, 9, 2

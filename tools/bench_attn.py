@@ -43,7 +43,11 @@ def main():
     ap.add_argument("--window", type=int, default=0,
                     help="experiment: every query block keeps a random 31.6 %% of the kv blocks [0, WINDOW) only")
     ap.add_argument("--k-head-major", action="store_true", help="K (and Q) stored [B,H,S,D]: contiguous 16 KiB K tiles")
-    ap.add_argument("--flags", type=int, default=None, help="jenga_bsattn_fwd flags (1 = XCD remap, 2 = ping-pong)")
+    ap.add_argument("--flags", type=int, default=None,
+                    help="jenga_bsattn_fwd flags (1 = XCD remap, 2 = ping-pong, 4 = round-1 kernel; default: pair kernel + remap)")
+    ap.add_argument("--pair-overlap", type=float, default=-1.0,
+                    help=">= 0: synthetic lists -- every odd query block shares this fraction of its list with the even "
+                         "block in front of it (what Hilbert-adjacent blocks of a trained model look like); same counts")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     t, h, w = a.grid
@@ -91,6 +95,22 @@ def main():
         idx = torch.zeros(1, H, nimg, nb, dtype=torch.int32, device=dev)
         idx[..., :n] = sel
         cnt = torch.full_like(cnt, n)
+    if a.pair_overlap >= 0:
+        n = int(cnt.float().mean().item())
+        g = torch.Generator(device=dev).manual_seed(3)
+        r = torch.rand(1, H, nimg, nimg, device=dev, generator=g)
+        # odd rows reuse the even row's random keys for a fraction of the columns -> correlated top-n sets
+        take = torch.rand(1, H, nimg, nimg, device=dev, generator=g) < a.pair_overlap
+        r[:, :, 1::2] = torch.where(take[:, :, 1::2], r[:, :, 0:nimg - 1:2][:, :, : r[:, :, 1::2].shape[2]], r[:, :, 1::2])
+        sel = r.topk(n - tb, dim=-1).indices.sort(dim=-1).values.to(torch.int32)
+        idx = torch.zeros(1, H, nimg, nb, dtype=torch.int32, device=dev)
+        idx[..., : n - tb] = sel
+        idx[..., n - tb:n] = torch.arange(nimg, nb, device=dev, dtype=torch.int32)
+        cnt = torch.full_like(cnt, n)
+        ev, od = idx[:, :, 0:nimg - 1:2, : n - tb], idx[:, :, 1::2, : n - tb]
+        ev = ev[:, :, : od.shape[2]]
+        m_ev = torch.zeros(1, H, od.shape[2], nb, dtype=torch.bool, device=dev).scatter_(-1, ev.long(), True)
+        res["pair_shared_frac"] = float(m_ev.gather(-1, od.long()).float().mean().item())
     if a.k_head_major:
         k = k.permute(0, 2, 1, 3).contiguous().permute(0, 2, 1, 3)
         q = q.permute(0, 2, 1, 3).contiguous().permute(0, 2, 1, 3)
