@@ -170,6 +170,7 @@ int jenga_bsattn_fwd(void* stream, const void* q, const void* k, const void* vt,
 /* flags */
 #define JENGA_ATTN_XCD_REMAP 1 /* contiguous q-block ranges per XCD (L2 locality); 0 = plain head-major order */
 #define JENGA_ATTN_PINGPONG 2  /* 8-wave workgroups, MFMA / softmax phases of the two waves per SIMD in anti-phase */
+#define JENGA_ATTN_LP 8        /* same decomposition, in-wave software pipeline (softmax inside the MFMA stream) */
 
 /* Step 2, second generation (the default path of the Python modules): two Hilbert-adjacent query blocks per
  * workgroup, kv blocks kept by BOTH staged once for 256 query rows, one wave per SIMD with the softmax of one

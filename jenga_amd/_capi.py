@@ -13,7 +13,8 @@ JENGA_BF16, JENGA_FP16 = 0, 1
 ATTN_XCD_REMAP = 1
 ATTN_PINGPONG = 2
 ATTN_LEGACY = 4      # (Python-side switch) the round-1 kernel: one 128-row query block per 4-wave workgroup
-ATTN_DEFAULT_FLAGS = int(os.environ.get("JENGA_ATTN_FLAGS", str(ATTN_XCD_REMAP)))
+ATTN_LP = 8          # round-1 decomposition + in-wave software pipeline (csrc/bsattn3.hip)
+ATTN_DEFAULT_FLAGS = int(os.environ.get("JENGA_ATTN_FLAGS", str(ATTN_XCD_REMAP | 8)))   # LP kernel (csrc/bsattn3.hip)
 
 _vp, _i64, _i32, _f32 = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_float
 
@@ -402,7 +403,7 @@ def bsattn_fwd(q, k, vt, seqlens, idx, cnt, nq_img, sm_scale, text_amp, text_blo
     fl = ATTN_DEFAULT_FLAGS if flags is None else flags
     if not xcd_remap:
         fl &= ~ATTN_XCD_REMAP
-    legacy = bool(fl & (ATTN_LEGACY | ATTN_PINGPONG))
+    legacy = bool(fl & (ATTN_LEGACY | ATTN_PINGPONG | ATTN_LP))
     prof = ATTN_PROFILE
     with torch.cuda.device(q.device):
         pidx = pcnt = None

@@ -20,6 +20,7 @@ SOURCES = [
     # no SLP vectorisation: v_pk_add_f32 beside MFMAs costs more than the two scalar adds it replaces (guide, per-
     # instruction table); the softmax of the pair kernel is placed instruction by instruction into the MFMA gaps
     ("bsattn2.hip", ["-fno-honor-nans", "-fno-slp-vectorize"]),
+    ("bsattn3.hip", ["-fno-honor-nans", "-fno-slp-vectorize"]),
 ]
 
 

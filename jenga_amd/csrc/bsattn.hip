@@ -112,6 +112,10 @@ __device__ __forceinline__ void stage_tile(const void* kbase, const void* vbase,
 constexpr float LAZY_THR = 8.0f;
 constexpr float RAISE_SUM = 256.0f;   // 2^LAZY_THR
 #define MFMA_PRIO(x) __builtin_amdgcn_s_setprio(x)
+// s_waitcnt vmcnt(0) as a BUILTIN right behind the (rare) reload of the kept-list chunk: hipcc otherwise puts the wait
+// for that load at the join in front of v_readlane, where it runs every block and drains the whole LDS-DMA prefetch
+// (the hardware counter includes the asm loads the compiler knows nothing about).  Found in round 2 from the ISA.
+#define LIST_LOAD_WAIT() __builtin_amdgcn_s_waitcnt(0x0F70)
 
 template <typename T, bool TEXT>
 __device__ __forceinline__ void attn_block(const AttnParams& P, unsigned char* smem, int b, int h, int m) {
@@ -350,7 +354,10 @@ __device__ __forceinline__ void attn_block(const AttnParams& P, unsigned char* s
         if (TEXT) {                                                                                              \
             DST = (J);                                                                                           \
         } else {                                                                                                 \
-            if (((J) & 63) == 0) lchunk = ((J) + lane < nkept) ? list[(J) + lane] : 0;                           \
+            if (((J) & 63) == 0) {                                                                               \
+                lchunk = ((J) + lane < nkept) ? list[(J) + lane] : 0;                                            \
+                LIST_LOAD_WAIT();   /* HERE, not at the join in front of v_readlane (every block: drains the DMA) */ \
+            }                                                                                                    \
             DST = __builtin_amdgcn_readlane(lchunk, (J) & 63);                                                   \
         }                                                                                                        \
     } while (0)
@@ -581,7 +588,10 @@ __device__ __forceinline__ void attn_block_pp(const AttnParams& P, unsigned char
         if (TEXT) {                                                                                              \
             DST = (J);                                                                                           \
         } else {                                                                                                 \
-            if (((J) & 63) == 0) lchunk = ((J) + lane < nkept) ? list[(J) + lane] : 0;                           \
+            if (((J) & 63) == 0) {                                                                               \
+                lchunk = ((J) + lane < nkept) ? list[(J) + lane] : 0;                                            \
+                LIST_LOAD_WAIT();   /* HERE, not at the join in front of v_readlane (every block: drains the DMA) */ \
+            }                                                                                                    \
             DST = __builtin_amdgcn_readlane(lchunk, (J) & 63);                                                   \
         }                                                                                                        \
     } while (0)
@@ -656,6 +666,7 @@ __device__ __forceinline__ void attn_block_pp(const AttnParams& P, unsigned char
             if (((J) >> 6) != chunk_id) {                                                                        \
                 chunk_id = (J) >> 6;                                                                             \
                 lchunk = (chunk_id * 64 + lane < nkept) ? list[chunk_id * 64 + lane] : 0;                        \
+                LIST_LOAD_WAIT();                                                                                \
             }                                                                                                    \
             DST = __builtin_amdgcn_readlane(lchunk, (J) & 63);                                                   \
         }                                                                                                        \
@@ -847,6 +858,10 @@ extern "C" int jenga_bsattn_fwd(void* stream, const void* q, const void* k, cons
         set_error("jenga_bsattn_fwd: key sequence stride %lld out of range", (long long)k_ss);
         return JENGA_EINVAL;
     }
+    if (flags & JENGA_ATTN_LP)
+        return jenga_bsattn_lp_launch(stream, q, k, vt, o, seqlens, idx, cnt, B, H, n_blocks, nq_img, q_sb, q_ss, q_sh,
+                                      k_sb, k_ss, k_sh, o_sb, o_ss, o_sh, sm_scale, text_amp, text_block_start, dtype,
+                                      flags);
     AttnParams P;
     P.q = (const uint16_t*)q;
     P.k = (const uint16_t*)k;

@@ -26,6 +26,16 @@
 #ifndef JENGA_PIN_Q
 #define JENGA_PIN_Q 3   // bit 0 / 1: keep the Q fragments of sub-block A / B in the accumulator registers
 #endif
+// Elimination experiments (tools/build_alt2.sh; results are WRONG with any of these set, only the clock is read):
+//   JENGA_X_NODMA   no LDS-DMA at all (compute on stale LDS)      JENGA_X_NOWAIT  no vmcnt wait at the end of a step
+//   JENGA_X_NOBAR   no s_barrier at the end of a step             JENGA_X_NOSM    no softmax arithmetic (P = const)
+//   JENGA_X_NOCHECK no exact-path ballot / branch
+#ifndef JENGA_DMA_STAGGER
+#define JENGA_DMA_STAGGER 0
+#endif
+#ifndef JENGA_DMA_PLACE
+#define JENGA_DMA_PLACE 1
+#endif
 #ifndef JENGA_RD_AHEAD
 #define JENGA_RD_AHEAD 8
 #endif
@@ -54,36 +64,78 @@ struct PairParams {
 
 constexpr int TILE_BYTES = 16384;          // one 64-key K tile [64][128] or V^T tile [128][64]
 constexpr int BLK_BYTES = 2 * TILE_BYTES;  // a 128-key block: tile h0, tile h1
-constexpr int K_RING = 0;                  // two block slots
-constexpr int V_RING = 2 * BLK_BYTES;      // two block slots
-constexpr int P2_LDS_BYTES = 4 * BLK_BYTES;   // 128 KiB
+// LDS ring, in 128-key blocks.  During step p (QK^T on block p, P.V on block p-1) the LDS-DMA of K(p+1) and then of
+// V(p+1) goes out, piece by piece inside the MFMA stream; `s_waitcnt vmcnt(8)` at the end of the step retires K(p+1)
+// (needed next step) and leaves this wave's 8 V(p+1) pieces (needed the step after next) in flight across the barrier.
+//   K: block p in use, p+1 landing             -> 2 slots (p & 1)
+//   V: p-1 in use, p landed, p+1 landing       -> 3 slots (p % 3)          = 160 KiB, the whole LDS of a CU
+constexpr int K_RING = 0;
+constexpr int V_RING = 2 * BLK_BYTES;
+constexpr int P2_LDS_BYTES = 5 * BLK_BYTES;
 
 constexpr float RAISE_SUM = 256.0f;        // 2^8: P = exp2(S - m~) stays <= 2^8
-constexpr float TINY_SUM = 8.673617379884035e-19f;   // 2^-60: everything seen so far is negligible -> lower m~
+// lower bound of the running row sum before m~ is pulled DOWN: P is rounded to the storage dtype before P.V, so the
+// row's largest P must stay inside that dtype's normal range.  bf16 shares fp32's exponent range; fp16's normals end
+// at 2^-14.
+template <typename T> __device__ __forceinline__ constexpr float tiny_sum();
+template <> __device__ __forceinline__ constexpr float tiny_sum<BF16>() { return 8.673617379884035e-19f; }   // 2^-60
+template <> __device__ __forceinline__ constexpr float tiny_sum<FP16>() { return 0.0625f; }                   // 2^-4
 
-// Four 1-KiB LDS-DMA pieces of one wave (global_load_lds_dwordx4): uniform base in SGPRs + per-lane byte offsets,
-// destination M0 advanced by 1 KiB per piece.  Inline asm on purpose (bsattn.hip: the builtin makes hipcc drain
-// vmcnt(0) before the next ds_read); the kernel counts and waits itself.
+// LDS-DMA (global_load_lds_dwordx4, 1 KiB per wave-instruction): uniform base in SGPRs + per-lane byte offsets; the LDS
+// destination is M0 + the instruction's immediate offset + lane * 16, and the immediate is added to the GLOBAL address
+// as well -- the per-lane offsets of piece i are pre-biased by -1024 i (see k_src / v_src), so one M0 value serves the
+// four pieces of a tile.  Inline asm on purpose (bsattn.hip: the builtin makes hipcc drain vmcnt(0) before the next
+// ds_read); the kernel counts and waits itself.  M0 is NOT restored: a write to M0 behind the load has to wait until
+// the vector-memory unit has consumed it, which parks the wave for the whole issue of the piece (JENGA_DMA_RESTORE_M0
+// re-creates that for A/B runs); nothing else in this kernel uses M0.
+#ifdef JENGA_DMA_RESTORE_M0
+#define DMA_M0_SAVE "s_mov_b32 %0, m0\n\t"
+#define DMA_M0_RESTORE "\n\ts_mov_b32 m0, %0"
+#else
+#define DMA_M0_SAVE
+#define DMA_M0_RESTORE
+#endif
 __device__ __forceinline__ void stage4(const void* base, unsigned lds, unsigned o0, unsigned o1, unsigned o2,
                                        unsigned o3) {
+#ifdef JENGA_X_NODMA
+    return;
+#endif
     unsigned keep;
-    asm volatile(
-        "s_mov_b32 %0, m0\n\t"
-        "s_mov_b32 m0, %1\n\t"
-        "s_nop 0\n\t"
-        "global_load_lds_dwordx4 %3, %2\n\t"
-        "s_add_u32 m0, m0, 0x400\n\t"
-        "global_load_lds_dwordx4 %4, %2\n\t"
-        "s_add_u32 m0, m0, 0x400\n\t"
-        "global_load_lds_dwordx4 %5, %2\n\t"
-        "s_add_u32 m0, m0, 0x400\n\t"
-        "global_load_lds_dwordx4 %6, %2\n\t"
-        "s_mov_b32 m0, %0"
-        : "=&s"(keep)
-        : "s"(lds), "s"(base), "v"(o0), "v"(o1), "v"(o2), "v"(o3)
-        : "memory", "scc");
+    asm volatile(DMA_M0_SAVE
+                 "s_mov_b32 m0, %1\n\t"
+                 "s_nop 0\n\t"
+                 "global_load_lds_dwordx4 %3, %2\n\t"
+                 "global_load_lds_dwordx4 %4, %2 offset:1024\n\t"
+                 "global_load_lds_dwordx4 %5, %2 offset:2048\n\t"
+                 "global_load_lds_dwordx4 %6, %2 offset:3072" DMA_M0_RESTORE
+                 : "=&s"(keep)
+                 : "s"(lds), "s"(base), "v"(o0), "v"(o1), "v"(o2), "v"(o3)
+                 : "memory");
+}
+// piece I (0..3) of a tile, placed into an MFMA gap by item_bb
+template <int I>
+__device__ __forceinline__ void stage1(const void* base, unsigned lds, unsigned off) {
+#ifdef JENGA_X_NODMA
+    return;
+#endif
+    unsigned keep;
+    asm volatile(DMA_M0_SAVE
+                 "s_mov_b32 m0, %1\n\t"
+                 "s_nop 0\n\t"
+                 "global_load_lds_dwordx4 %3, %2 offset:%4" DMA_M0_RESTORE
+                 : "=&s"(keep)
+                 : "s"(lds), "s"(base), "v"(off), "i"(I * 1024)
+                 : "memory");
 }
 #define DMA_WAIT_ALL() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#define DMA_WAIT_KEEP8() asm volatile("s_waitcnt vmcnt(8)" ::: "memory")
+
+// What a basic block stages while it computes: NG groups of four 1-KiB pieces (one 16-KiB tile = 4 pieces per wave).
+struct Dma {
+    const void* base[2];   // uniform global address of the tile (group 0 / 1)
+    unsigned lds[2];       // this wave's LDS destination of piece 0 of the tile
+    unsigned off[2][4];    // per-lane source byte offsets of the four pieces
+};
 
 // One 32-row sub-block (A or B) of the wave: Q fragments, O accumulators, running sum, -m~.
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -125,9 +177,7 @@ __device__ __forceinline__ void exact_softmax(Sub& sb, const f32x16& s0, const f
         tmax = fmaxf(tmax, fmaxf(v0[r], v1[r]));
     }
     tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
-    float lsum = sb.l + psum;
-    lsum += __shfl_xor(lsum, 32);
-    const bool move = (tmax > 0.f) || (lsum < TINY_SUM);
+    const bool move = (tmax > 0.f) || (sb.l + psum < tiny_sum<T>());   // l, psum: whole-row values in both half-lanes
     const float delta = (move && tmax > -1e30f) ? fmaxf(ceilf(tmax), -120.f) : 0.f;
     const float f2 = __builtin_amdgcn_exp2f(-delta);
     sb.neg_m -= delta;
@@ -156,6 +206,7 @@ __device__ __forceinline__ void exact_softmax(Sub& sb, const f32x16& s0, const f
         e1[r] = __builtin_amdgcn_exp2f(v1[r] - delta);
         psum += e0[r] + e1[r];
     }
+    psum += __shfl_xor(psum, 32);
     pack_p<T>(e0, e1, pf);
 }
 
@@ -163,6 +214,7 @@ __device__ __forceinline__ void exact_softmax(Sub& sb, const f32x16& s0, const f
 //   DO_QK: sn = K(kt) . Q(sqk)                      item i     MFMA  0..15
 //   DO_PV: O(spv) += V^T(vt) . P(pf_old)            item i-2   MFMA 16..31
 //   DO_SM: pf_new = bf16(exp2(sp - m~)), l += sum   item i-1   one score per MFMA gap
+//   NG   : 4*NG LDS-DMA pieces of later tiles, one every fourth (NG = 2) / eighth (NG = 1) gap
 // then the wave-uniform check for the exact path of item i-1 (P.V of item i-2 is complete, P.V of item i-1 has not
 // started: cdna guide T13's safe order).
 // Hand-placed stream, one sched_barrier(0)-fenced slot per MFMA:  MFMA m | ds_read of the fragment of MFMA m+8 |
@@ -170,11 +222,14 @@ __device__ __forceinline__ void exact_softmax(Sub& sb, const f32x16& s0, const f
 // m+2), i.e. 4-5 single-issue fillers per 32-cycle MFMA gap (the guide's budget for one wave per SIMD).  Left to
 // itself on an unfenced 32-MFMA region hipcc read the P.V fragments just in time (an LDS round trip in front of every
 // MFMA), issued the MFMAs in clumps of three with the VALU work behind them, and moved O between the register halves.
-template <typename T, bool TEXT, bool DO_PV, bool DO_QK, bool DO_SM>
+// The LDS-DMA pieces sit INSIDE the stream for the same reason: with one wave per SIMD nothing else covers their
+// ~60-cycle issue (the first measured version issued 8-16 of them in a row at the start of a step: 884 TFLOP/s).
+template <typename T, bool TEXT, bool DO_PV, bool DO_QK, bool DO_SM, int NG>
 __device__ __forceinline__ void item_bb(const unsigned char* vt, Sub& spv, const uint4 (&pf_old)[4],
                                         const unsigned char* kt, Sub& sqk, f32x16& sn0, f32x16& sn1, Sub& ssm,
                                         const f32x16& sp0, const f32x16& sp1, uint4 (&pf_new)[4],
-                                        const int (&k_addr)[8], const int (&v_addr)[4], float qk_scale) {
+                                        const int (&k_addr)[8], const int (&v_addr)[4], float qk_scale,
+                                        const Dma& dma, int wave_u) {
     f32x16 zero16;
 #pragma unroll
     for (int r = 0; r < 16; ++r) zero16[r] = 0.f;
@@ -191,9 +246,14 @@ __device__ __forceinline__ void item_bb(const unsigned char* vt, Sub& spv, const
         }                                                                                                             \
     } while (0)
 #define BB_SCORE(E_) ((E_) < 16 ? sp0[(E_) & 15] : sp1[(E_) & 15])
+#ifdef JENGA_X_NOSM
+#define BB_SM_ON false
+#else
+#define BB_SM_ON true
+#endif
 #define BB_SM(M_)                                                                                                     \
     do {                                                                                                              \
-        if (DO_SM) {                                                                                                  \
+        if (DO_SM && BB_SM_ON) {                                                                                                  \
             if ((M_) < 32) {                                                                                          \
                 float sv_;   /* the scores stay in the accumulator registers; read each one in ITS slot */           \
                 asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(sv_) : "a"(BB_SCORE(M_)));                            \
@@ -206,6 +266,38 @@ __device__ __forceinline__ void item_bb(const unsigned char* vt, Sub& spv, const
             }                                                                                                         \
         }                                                                                                             \
     } while (0)
+    /* piece J_ (0 .. 4*NG-1) = piece J_&3 of group J_>>2 */
+#define BB_PIECE(J_)                                                                                                  \
+    do {                                                                                                              \
+        if ((J_) < 4 * NG) stage1<(J_) & 3>(dma.base[((J_) >> 2) & 1], dma.lds[((J_) >> 2) & 1],                      \
+                                            dma.off[((J_) >> 2) & 1][(J_) & 3]);                                      \
+    } while (0)
+    /* JENGA_DMA_STAGGER (default): the four waves of the workgroup run this stream in lockstep, and four LDS-DMA issues
+       at the same moment queue up in the CU's one vector-memory path (~120 cycles each, measured); wave w therefore
+       takes the slots == w (mod 4): piece j at slot 4 j + w (NG = 2) / 8 j + 2 w (NG = 1).  Otherwise: piece 0 before
+       slot 0, the rest at a fixed stride, all waves together. */
+#if JENGA_DMA_STAGGER
+#define BB_DMA(M_)                                                                                                    \
+    do {                                                                                                              \
+        if (NG == 2 && wave_u == ((M_) & 3)) BB_PIECE((M_) >> 2);                                                     \
+        if (NG == 1 && !((M_) & 1) && wave_u == (((M_) >> 1) & 3)) BB_PIECE((M_) >> 3);                               \
+    } while (0)
+#define BB_DMA_PRE()
+#elif JENGA_DMA_PLACE == 0   /* piece 0 before slot 0, the rest every 4th / 8th slot (next to a ds_read each) */
+#define BB_DMA(M_)                                                                                                    \
+    do {                                                                                                              \
+        if (NG == 2 && ((M_) & 3) == 3 && (M_) < 28) BB_PIECE(((M_) >> 2) + 1);                                       \
+        if (NG == 1 && ((M_) & 7) == 7 && (M_) < 24) BB_PIECE(((M_) >> 3) + 1);                                       \
+    } while (0)
+#define BB_DMA_PRE() BB_PIECE(0)
+#else                        /* the last eight slots carry no fragment read (reads run 8 MFMAs ahead): pieces go there */
+#define BB_DMA(M_)                                                                                                    \
+    do {                                                                                                              \
+        if (NG == 2 && (M_) >= 24) BB_PIECE((M_) - 24);                                                               \
+        if (NG == 1 && (M_) >= 24 && !((M_) & 1)) BB_PIECE(((M_) - 24) >> 1);                                         \
+    } while (0)
+#define BB_DMA_PRE()
+#endif
 #define BB_SLOT(M_)                                                                                                   \
     do {                                                                                                              \
         if ((M_) < 16) {                                                                                              \
@@ -217,6 +309,7 @@ __device__ __forceinline__ void item_bb(const unsigned char* vt, Sub& spv, const
             spv.o[((M_) - 16) & 3] = mfma32<T>(fr[M_], pf_old[((M_) - 16) >> 2], spv.o[((M_) - 16) & 3]);             \
         }                                                                                                             \
         BB_READ((M_) + 8);                                                                                            \
+        BB_DMA(M_);                                                                                                   \
         BB_SM(M_);                                                                                                    \
         __builtin_amdgcn_sched_barrier(0);                                                                            \
     } while (0)
@@ -224,6 +317,7 @@ __device__ __forceinline__ void item_bb(const unsigned char* vt, Sub& spv, const
     if (!DO_QK) {   // (fill / drain forms) the P.V fragments have no slots 0..15 to be read from
         BB_READ(16); BB_READ(17); BB_READ(18); BB_READ(19); BB_READ(20); BB_READ(21); BB_READ(22); BB_READ(23);
     }
+    BB_DMA_PRE();
     __builtin_amdgcn_sched_barrier(0);
     BB_SLOT(0); BB_SLOT(1); BB_SLOT(2); BB_SLOT(3); BB_SLOT(4); BB_SLOT(5); BB_SLOT(6); BB_SLOT(7);
     BB_SLOT(8); BB_SLOT(9); BB_SLOT(10); BB_SLOT(11); BB_SLOT(12); BB_SLOT(13); BB_SLOT(14); BB_SLOT(15);
@@ -234,18 +328,34 @@ __device__ __forceinline__ void item_bb(const unsigned char* vt, Sub& spv, const
 #undef BB_READ
 #undef BB_SCORE
 #undef BB_SM
+#undef BB_PIECE
+#undef BB_DMA
+#undef BB_DMA_PRE
 #undef BB_SLOT
     // The NEXT block reads these scores with inline-asm v_accvgpr_read (invisible to the hazard recogniser).  In the
     // steady state 16 P.V MFMAs separate the last QK^T MFMA from that read; the pipeline-fill forms have no P.V tail.
     if (DO_QK && !DO_PV) asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");
     if (DO_SM) {
-        float psum = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+        // row sum of this tile over BOTH half-lanes (v_permlane32_swap: lane i <-> lane i+32, no LDS round trip):
+        // l and the checks below are whole-row quantities, identical in the two lanes that share a row
+        const float half_ = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+        const auto sw_ = __builtin_amdgcn_permlane32_swap(__float_as_uint(half_), __float_as_uint(half_), false, false);
+        float psum = __uint_as_float(sw_[0]) + __uint_as_float(sw_[1]);
         pf_new[0] = make_uint4(ww[0], ww[1], ww[2], ww[3]);
         pf_new[1] = make_uint4(ww[4], ww[5], ww[6], ww[7]);
         pf_new[2] = make_uint4(ww[8], ww[9], ww[10], ww[11]);
         pf_new[3] = make_uint4(ww[12], ww[13], ww[14], ww[15]);
-        if (__any(!(psum <= RAISE_SUM) || (ssm.l + psum < TINY_SUM)))
+#ifdef JENGA_X_NOSM
+        asm volatile("" ::"a"(sp0[0]), "a"(sp1[0]));   // keep the QK^T MFMAs of this item
+        psum = 1.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) ww[i] = 0x3c003c00u;
+        pf_new[0] = pf_new[1] = pf_new[2] = pf_new[3] = make_uint4(ww[0], ww[1], ww[2], ww[3]);
+#endif
+#if !defined(JENGA_X_NOCHECK) && !defined(JENGA_X_NOSM)
+        if (__any(!(psum <= RAISE_SUM) || (ssm.l + psum < tiny_sum<T>())))
             exact_softmax<T, TEXT>(ssm, sp0, sp1, pf_new, psum, qk_scale);
+#endif
         ssm.l += psum;
     }
 }
@@ -341,7 +451,7 @@ __device__ __forceinline__ void load_sub(Sub& sb, const PairParams& P, int b, in
 
 template <typename T>
 __device__ __forceinline__ void store_sub(const Sub& sb, uint16_t* op, bool row_ok) {
-    const float l_tot = sb.l + __shfl_xor(sb.l, 32);
+    const float l_tot = sb.l;   // whole-row sum (item_bb / exact_softmax add both half-lanes' parts)
 #pragma unroll
     for (int db = 0; db < 4; ++db) {
 #pragma unroll
@@ -385,50 +495,72 @@ __device__ __forceinline__ void attn_pair(const PairParams& P, unsigned char* sm
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks)
         v_addr[ks] = V_RING + lq * 128 + ((((ks >> 1) * 4 + hi * 2 + (ks & 1)) ^ ((lq >> 1) & 7)) << 4);
-    // per-lane LDS-DMA source offsets (bytes) of this wave's four K and four V^T pieces of a tile (bsattn.hip)
+    // per-lane LDS-DMA source offsets (bytes) of this wave's four K and four V^T pieces of a tile (bsattn.hip),
+    // piece i biased by -1024 i: the instruction's immediate offset (+1024 i) moves the LDS AND the global address
     const unsigned smem_base =
         __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem);
     const int kr_ = 16 * wave_u + (lane >> 4), kc_ = lane & 15, ksw_ = lane >> 4;
     const unsigned kss_b = (unsigned)P.k_ss * 2u;
     const unsigned k_src0 = (unsigned)(kr_ + 0) * kss_b + ((kc_ ^ (0 + ksw_)) << 4);
-    const unsigned k_src1 = (unsigned)(kr_ + 4) * kss_b + ((kc_ ^ (4 + ksw_)) << 4);
-    const unsigned k_src2 = (unsigned)(kr_ + 8) * kss_b + ((kc_ ^ (8 + ksw_)) << 4);
-    const unsigned k_src3 = (unsigned)(kr_ + 12) * kss_b + ((kc_ ^ (12 + ksw_)) << 4);
+    const unsigned k_src1 = (unsigned)(kr_ + 4) * kss_b + ((kc_ ^ (4 + ksw_)) << 4) - 1024u;
+    const unsigned k_src2 = (unsigned)(kr_ + 8) * kss_b + ((kc_ ^ (8 + ksw_)) << 4) - 2048u;
+    const unsigned k_src3 = (unsigned)(kr_ + 12) * kss_b + ((kc_ ^ (12 + ksw_)) << 4) - 3072u;
     const int vr_ = 32 * wave_u + (lane >> 3), vc_ = lane & 7, vsw_ = lane >> 4;
     const unsigned v_src0 = (unsigned)(vr_ + 0) * 128 + ((vc_ ^ ((0 + vsw_) & 7)) << 4);
-    const unsigned v_src1 = (unsigned)(vr_ + 8) * 128 + ((vc_ ^ ((4 + vsw_) & 7)) << 4);
-    const unsigned v_src2 = (unsigned)(vr_ + 16) * 128 + ((vc_ ^ ((8 + vsw_) & 7)) << 4);
-    const unsigned v_src3 = (unsigned)(vr_ + 24) * 128 + ((vc_ ^ ((12 + vsw_) & 7)) << 4);
+    const unsigned v_src1 = (unsigned)(vr_ + 8) * 128 + ((vc_ ^ ((4 + vsw_) & 7)) << 4) - 1024u;
+    const unsigned v_src2 = (unsigned)(vr_ + 16) * 128 + ((vc_ ^ ((8 + vsw_) & 7)) << 4) - 2048u;
+    const unsigned v_src3 = (unsigned)(vr_ + 24) * 128 + ((vc_ ^ ((12 + vsw_) & 7)) << 4) - 3072u;
 
     // ---- block stream: position p = 0..n_tot-1 in processing order (A-only, B-only, shared) -> kv block id ----
     // The merged list is read 64 entries at a time into one VGPR and entries are pulled out with v_readlane
     // (a per-block `list[i]` is a vector load whose vmcnt(0) would drain the LDS-DMA prefetch every block).
     int lchunk = 0, lbase = -64;
     auto blk_at = [&](int p) -> int {
+        if (p >= n_tot) p = n_tot - 1;   // the stream's last steps stage one (unused) block more: same piece count per step
         if (TEXT) return p;
         const int li = (p < n_ab) ? n_sh + p : p - n_ab;
         if (li < lbase || li >= lbase + 64) {
             lbase = li & ~63;
             lchunk = (lbase + lane < n_tot) ? list[lbase + lane] : 0;
+            // wait HERE for the (rare) reload: at the join in front of v_readlane hipcc's vmcnt(0) runs every step and
+            // drains the whole LDS-DMA prefetch (the hardware counter includes the asm loads)
+            __builtin_amdgcn_s_waitcnt(0x0F70);
         }
         return __builtin_amdgcn_readlane(lchunk, li - lbase);
     };
-    // LDS-DMA of block p (stream position): K -> K slot p&1, V^T -> V slot p&1; 8 pieces per wave each.
-    auto issue_k = [&](int p, int half) {   // one K tile (64 keys)
+    // LDS-DMA descriptors of one tile of block p (stream position): K -> K slot p & 1, V^T -> V slot p % 3
+    auto dma_k = [&](Dma& d, int g, int p, int half) {
         const int blk = blk_at(p);
-        stage4(kbh + ((long long)blk * 128 + half * 64) * P.k_ss,
-               smem_base + K_RING + (p & 1) * BLK_BYTES + half * TILE_BYTES + wave_u * 4096, k_src0, k_src1, k_src2,
-               k_src3);
+        d.base[g] = kbh + ((long long)blk * 128 + half * 64) * P.k_ss;
+        d.lds[g] = smem_base + K_RING + (p & 1) * BLK_BYTES + half * TILE_BYTES + wave_u * 4096;
+        d.off[g][0] = k_src0; d.off[g][1] = k_src1; d.off[g][2] = k_src2; d.off[g][3] = k_src3;
     };
-    auto issue_v = [&](int p, int half) {   // one V^T tile
+    auto dma_v = [&](Dma& d, int g, int p, int half) {
         const int blk = blk_at(p);
-        stage4(vbh + ((long long)blk * 2 + half) * (128 * 64),
-               smem_base + V_RING + (p & 1) * BLK_BYTES + half * TILE_BYTES + wave_u * 4096, v_src0, v_src1, v_src2,
-               v_src3);
+        d.base[g] = vbh + ((long long)blk * 2 + half) * (128 * 64);
+        d.lds[g] = smem_base + V_RING + (p % 3) * BLK_BYTES + half * TILE_BYTES + wave_u * 4096;
+        d.off[g][0] = v_src0; d.off[g][1] = v_src1; d.off[g][2] = v_src2; d.off[g][3] = v_src3;
     };
+    auto issue_now = [&](const Dma& d, int g) { stage4(d.base[g], d.lds[g], d.off[g][0], d.off[g][1], d.off[g][2], d.off[g][3]); };
     auto kslot = [&](int p, int half) { return smem + (p & 1) * BLK_BYTES + half * TILE_BYTES; };   // + k_addr (K_RING inside)
-    auto vslot = [&](int p, int half) { return smem + (p & 1) * BLK_BYTES + half * TILE_BYTES; };   // + v_addr (V_RING inside)
+    auto vslot = [&](int p, int half) { return smem + (p % 3) * BLK_BYTES + half * TILE_BYTES; };   // + v_addr (V_RING inside)
+    // end of a pipelined step: everything but this wave's newest 8 pieces (V of block p+1) has landed; publish
     auto end_step = [&]() {
+#ifndef JENGA_X_NOWAIT
+        DMA_WAIT_KEEP8();
+#endif
+#ifndef JENGA_X_NOBAR
+        __syncthreads();
+#endif
+    };
+    // a text_amp / kv-length block (unpipelined): stage K(p+1), V(p+1) like any step, but wait for everything -- this
+    // step reads V(p), which the step before left in flight
+    auto slow_begin = [&](int p) {
+        Dma d;
+        dma_k(d, 0, p + 1, 0); dma_k(d, 1, p + 1, 1);
+        issue_now(d, 0); issue_now(d, 1);
+        dma_v(d, 0, p + 1, 0); dma_v(d, 1, p + 1, 1);
+        issue_now(d, 0); issue_now(d, 1);
         DMA_WAIT_ALL();
         __syncthreads();
     };
@@ -451,59 +583,47 @@ __device__ __forceinline__ void attn_pair(const PairParams& P, unsigned char* sm
 #pragma unroll
     for (int i = 0; i < 4; ++i) pfX[i] = pfY[i] = make_uint4(0u, 0u, 0u, 0u);
 
-    // prologue: K of the first block
+    // prologue: K and V of the first block
     if (n_tot > 0) {
-        issue_k(0, 0);
-        issue_k(0, 1);
+        Dma d;
+        dma_k(d, 0, 0, 0); dma_k(d, 1, 0, 1);
+        issue_now(d, 0); issue_now(d, 1);
+        dma_v(d, 0, 0, 0); dma_v(d, 1, 0, 1);
+        issue_now(d, 0); issue_now(d, 1);
     }
-    end_step();
+    DMA_WAIT_ALL();
+    __syncthreads();
+    const Dma no_dma = {};
 
-    // ---- a segment of single-list blocks [p0, p1): items (X,h0), (X,h1) per block, one step per block ----
+    // ---- a segment of single-list blocks [p0, p1): items (X,h0), (X,h1) per block, one step per block.
+    //      Step p: block 0 stages K(p+1) (8 pieces), block 1 stages V(p+1) (8 pieces).
+#define SINGLE_STEP(X, P_, PV_)                                                                                       \
+    do {                                                                                                              \
+        Dma dk_, dv_;                                                                                                 \
+        dma_k(dk_, 0, (P_) + 1, 0); dma_k(dk_, 1, (P_) + 1, 1);                                                       \
+        dma_v(dv_, 0, (P_) + 1, 0); dma_v(dv_, 1, (P_) + 1, 1);                                                       \
+        item_bb<T, TEXT, PV_, true, PV_, 2>(vslot((P_) - 1, 0), X, pfX, kslot(P_, 0), X, sX0, sX1, X, sY0, sY1, pfY,  \
+                                            k_addr, v_addr, P.qk_scale, dk_, wave_u);                                         \
+        item_bb<T, TEXT, PV_, true, true, 2>(vslot((P_) - 1, 1), X, pfY, kslot(P_, 1), X, sY0, sY1, X, sX0, sX1, pfX, \
+                                             k_addr, v_addr, P.qk_scale, dv_, wave_u);                                        \
+        end_step();                                                                                                   \
+    } while (0)
 #define SEG_SINGLE(X, P0, P1)                                                                                         \
     do {                                                                                                              \
         const int p0_ = (P0), p1_ = (P1);                                                                             \
         const int pf_end = p1_ - n_slow_tail(p0_, p1_);                                                               \
         if (pf_end > p0_) {                                                                                           \
-            /* fill: no P.V yet */                                                                                    \
-            issue_v(p0_, 0);                                                                                          \
-            issue_v(p0_, 1);                                                                                          \
-            item_bb<T, TEXT, false, true, false>(nullptr, X, pfX, kslot(p0_, 0), X, sX0, sX1, X, sY0, sY1, pfY, \
-                                                       k_addr, v_addr, P.qk_scale);                                   \
-            if (p0_ + 1 < n_tot) {                                                                                    \
-                issue_k(p0_ + 1, 0);                                                                                  \
-                issue_k(p0_ + 1, 1);                                                                                  \
-            }                                                                                                         \
-            item_bb<T, TEXT, false, true, true>(nullptr, X, pfY, kslot(p0_, 1), X, sY0, sY1, X, sX0, sX1, pfX,  \
-                                                      k_addr, v_addr, P.qk_scale);                                    \
-            end_step();                                                                                               \
-            for (int p = p0_ + 1; p < pf_end; ++p) {                                                                  \
-                issue_v(p, 0);                                                                                        \
-                issue_v(p, 1);                                                                                        \
-                item_bb<T, TEXT, true, true, true>(vslot(p - 1, 0), X, pfX, kslot(p, 0), X, sX0, sX1, X, sY0,   \
-                                                         sY1, pfY, k_addr, v_addr, P.qk_scale);                       \
-                if (p + 1 < n_tot) {                                                                                  \
-                    issue_k(p + 1, 0);                                                                                \
-                    issue_k(p + 1, 1);                                                                                \
-                }                                                                                                     \
-                item_bb<T, TEXT, true, true, true>(vslot(p - 1, 1), X, pfY, kslot(p, 1), X, sY0, sY1, X, sX0,   \
-                                                         sX1, pfX, k_addr, v_addr, P.qk_scale);                       \
-                end_step();                                                                                           \
-            }                                                                                                         \
-            /* drain: P.V of the last block's two items */                                                            \
-            item_bb<T, TEXT, true, false, true>(vslot(pf_end - 1, 0), X, pfX, nullptr, X, sX0, sX1, X, sY0,     \
-                                                      sY1, pfY, k_addr, v_addr, P.qk_scale);                          \
-            item_bb<T, TEXT, true, false, false>(vslot(pf_end - 1, 1), X, pfY, nullptr, X, sY0, sY1, X, sX0,    \
-                                                       sX1, pfX, k_addr, v_addr, P.qk_scale);                         \
+            SINGLE_STEP(X, p0_, false);   /* fill: no P.V yet, no softmax in the first block */                       \
+            for (int p = p0_ + 1; p < pf_end; ++p) SINGLE_STEP(X, p, true);                                           \
+            /* drain: softmax of the last item, P.V of the last block's two items */                                  \
+            item_bb<T, TEXT, true, false, true, 0>(vslot(pf_end - 1, 0), X, pfX, nullptr, X, sX0, sX1, X, sY0, sY1,   \
+                                                   pfY, k_addr, v_addr, P.qk_scale, no_dma, wave_u);                          \
+            item_bb<T, TEXT, true, false, false, 0>(vslot(pf_end - 1, 1), X, pfY, nullptr, X, sY0, sY1, X, sX0, sX1,  \
+                                                    pfX, k_addr, v_addr, P.qk_scale, no_dma, wave_u);                         \
         }                                                                                                             \
         if (!TEXT) {                                                                                                  \
-            for (int p = pf_end; p < p1_; ++p) {   /* text_amp / kv-length blocks, unpipelined */                     \
-                issue_v(p, 0);                                                                                        \
-                issue_v(p, 1);                                                                                        \
-                if (p + 1 < n_tot) {                                                                                  \
-                    issue_k(p + 1, 0);                                                                                \
-                    issue_k(p + 1, 1);                                                                                \
-                }                                                                                                     \
-                end_step();                                                                                           \
+            for (int p = pf_end; p < p1_; ++p) {                                                                      \
+                slow_begin(p);                                                                                        \
                 const int bl = blk_at(p);                                                                             \
                 slow_item<T>(X, kslot(p, 0), vslot(p, 0), bl, 0, seqlen, P.text_block_start, P.text_amp, hi, k_addr,  \
                              v_addr);                                                                                 \
@@ -517,61 +637,38 @@ __device__ __forceinline__ void attn_pair(const PairParams& P, unsigned char* sm
     SEG_SINGLE(A, 0, n_a);
     SEG_SINGLE(B, n_a, n_ab);
 
-    // ---- the shared blocks [n_ab, n_tot): items (A,h) (B,h) per step, two steps per block ----
+    // ---- the shared blocks [n_ab, n_tot): items (A,h) (B,h) per step, two steps per block.
+    //      Step (p,h0) stages K(p+1) (4 + 4 pieces), step (p,h1) stages V(p+1).
+#define SHARED_HALF(P_, H_, VT_, PV_, SM0_)                                                                           \
+    do {                                                                                                              \
+        Dma d0_, d1_;                                                                                                 \
+        if ((H_) == 0) { dma_k(d0_, 0, (P_) + 1, 0); dma_k(d1_, 0, (P_) + 1, 1); }                                    \
+        else { dma_v(d0_, 0, (P_) + 1, 0); dma_v(d1_, 0, (P_) + 1, 1); }                                              \
+        item_bb<T, TEXT, PV_, true, SM0_, 1>(VT_, A, pfX, kslot(P_, H_), A, sX0, sX1, B, sY0, sY1, pfY, k_addr,       \
+                                             v_addr, P.qk_scale, d0_, wave_u);                                                \
+        item_bb<T, TEXT, PV_, true, true, 1>(VT_, B, pfY, kslot(P_, H_), B, sY0, sY1, A, sX0, sX1, pfX, k_addr,       \
+                                             v_addr, P.qk_scale, d1_, wave_u);                                                \
+        end_step();                                                                                                   \
+    } while (0)
     {
         const int p0_ = n_ab, p1_ = n_tot;
         const int pf_end = p1_ - n_slow_tail(p0_, p1_);
         if (pf_end > p0_) {
-            // fill
-            issue_v(p0_, 0);
-            item_bb<T, TEXT, false, true, false>(nullptr, A, pfX, kslot(p0_, 0), A, sX0, sX1, B, sY0, sY1, pfY,
-                                                        k_addr, v_addr, P.qk_scale);
-            item_bb<T, TEXT, false, true, true>(nullptr, B, pfY, kslot(p0_, 0), B, sY0, sY1, A, sX0, sX1, pfX,
-                                                       k_addr, v_addr, P.qk_scale);
-            end_step();
-            issue_v(p0_, 1);
-            if (p0_ + 1 < n_tot) {
-                issue_k(p0_ + 1, 0);
-                issue_k(p0_ + 1, 1);
-            }
-            item_bb<T, TEXT, true, true, true>(vslot(p0_, 0), A, pfX, kslot(p0_, 1), A, sX0, sX1, B, sY0, sY1,
-                                                      pfY, k_addr, v_addr, P.qk_scale);
-            item_bb<T, TEXT, true, true, true>(vslot(p0_, 0), B, pfY, kslot(p0_, 1), B, sY0, sY1, A, sX0, sX1,
-                                                      pfX, k_addr, v_addr, P.qk_scale);
-            end_step();
+            SHARED_HALF(p0_, 0, nullptr, false, false);          // fill
+            SHARED_HALF(p0_, 1, vslot(p0_, 0), true, true);
             for (int p = p0_ + 1; p < pf_end; ++p) {
-                issue_v(p, 0);
-                item_bb<T, TEXT, true, true, true>(vslot(p - 1, 1), A, pfX, kslot(p, 0), A, sX0, sX1, B, sY0,
-                                                          sY1, pfY, k_addr, v_addr, P.qk_scale);
-                item_bb<T, TEXT, true, true, true>(vslot(p - 1, 1), B, pfY, kslot(p, 0), B, sY0, sY1, A, sX0,
-                                                          sX1, pfX, k_addr, v_addr, P.qk_scale);
-                end_step();
-                issue_v(p, 1);
-                if (p + 1 < n_tot) {
-                    issue_k(p + 1, 0);
-                    issue_k(p + 1, 1);
-                }
-                item_bb<T, TEXT, true, true, true>(vslot(p, 0), A, pfX, kslot(p, 1), A, sX0, sX1, B, sY0, sY1,
-                                                          pfY, k_addr, v_addr, P.qk_scale);
-                item_bb<T, TEXT, true, true, true>(vslot(p, 0), B, pfY, kslot(p, 1), B, sY0, sY1, A, sX0, sX1,
-                                                          pfX, k_addr, v_addr, P.qk_scale);
-                end_step();
+                SHARED_HALF(p, 0, vslot(p - 1, 1), true, true);
+                SHARED_HALF(p, 1, vslot(p, 0), true, true);
             }
             // drain
-            item_bb<T, TEXT, true, false, true>(vslot(pf_end - 1, 1), A, pfX, nullptr, A, sX0, sX1, B, sY0, sY1,
-                                                       pfY, k_addr, v_addr, P.qk_scale);
-            item_bb<T, TEXT, true, false, false>(vslot(pf_end - 1, 1), B, pfY, nullptr, B, sY0, sY1, A, sX0, sX1,
-                                                        pfX, k_addr, v_addr, P.qk_scale);
+            item_bb<T, TEXT, true, false, true, 0>(vslot(pf_end - 1, 1), A, pfX, nullptr, A, sX0, sX1, B, sY0, sY1, pfY,
+                                                   k_addr, v_addr, P.qk_scale, no_dma, wave_u);
+            item_bb<T, TEXT, true, false, false, 0>(vslot(pf_end - 1, 1), B, pfY, nullptr, B, sY0, sY1, A, sX0, sX1,
+                                                    pfX, k_addr, v_addr, P.qk_scale, no_dma, wave_u);
         }
         if (!TEXT) {
             for (int p = pf_end; p < p1_; ++p) {
-                issue_v(p, 0);
-                issue_v(p, 1);
-                if (p + 1 < n_tot) {
-                    issue_k(p + 1, 0);
-                    issue_k(p + 1, 1);
-                }
-                end_step();
+                slow_begin(p);
                 const int bl = blk_at(p);
                 slow_item<T>(A, kslot(p, 0), vslot(p, 0), bl, 0, seqlen, P.text_block_start, P.text_amp, hi, k_addr,
                              v_addr);
@@ -585,7 +682,9 @@ __device__ __forceinline__ void attn_pair(const PairParams& P, unsigned char* sm
             }
         }
     }
+#undef SINGLE_STEP
 #undef SEG_SINGLE
+#undef SHARED_HALF
     DMA_WAIT_ALL();
 
     store_sub<T>(A, opA, TEXT || (qrowA < seqlen));

@@ -1,0 +1,591 @@
+// Block-sparse attention forward, third generation ("LP": the round-1 decomposition with an in-wave software
+// pipeline), gfx950, head_dim 128, 128-token blocks.  Same arguments, lists and numerics as jenga_bsattn_fwd.
+//
+// What two measured kernels taught:
+//   * bsattn.hip (round 1): 4 waves = one 128-row query block, two workgroups per CU = two waves per SIMD.  The
+//     softmax VALU work of one wave does not hide under the OTHER wave's MFMAs on a gfx950 SIMD, so MFMA time and
+//     VALU time add up: 1040 TFLOP/s.
+//   * bsattn2.hip (pair kernel): one wave per SIMD, softmax of item i-1 placed instruction by instruction into the
+//     MFMA gaps of items i and i-2 IN THE SAME WAVE -- that works: the compute-only build runs at 1410-1460 TFLOP/s.
+//     But every 1-KiB LDS-DMA piece parks its issuing wave for ~130 cycles (L2-hot or not, wherever it is placed,
+//     whether or not M0 is restored), and with one wave per SIMD nothing covers that: 935-1015 TFLOP/s.
+// This kernel takes both halves: round 1's workgroup shape and LDS ring (so that the partner wave of the SIMD -- a
+// wave of the CU's other workgroup -- runs while this one sits in its DMA issue), and the pair kernel's in-wave
+// pipeline, cut to 32-key half tiles so that it fits the 256 registers a wave has at two waves per SIMD:
+//   item     = (this wave's 32 query rows) x (32 keys): 8 QK^T MFMAs -> softmax of 16 scores/lane -> 8 P.V MFMAs
+//   block i  : MFMA 0-7  S(i)    = K . Q~^T                    \   16 fenced slots: MFMA | fragment read 8 ahead |
+//              MFMA 8-15 O      += V^T(i-2) . P(i-2)            >  one score of item i-1 in three skewed stages
+//              VALU      P(i-1) = bf16(exp2(S(i-1) - m~)), l   /   (t = s - m~ | exp2 | row-sum add + bf16 pack)
+//   then the wave-uniform ballot for the exact max-first path of item i-1 (its P.V has not started, the P.V of item
+//   i-2 is complete: guide T13's safe order).
+// Tile t (64 keys = items 2t, 2t+1): V^T(t) and K(t+2) are staged at the start of its step; P.V runs one tile behind
+// QK^T, so V^T(t) is first read in step t+1 and the round-1 ring (K 3 slots, V^T 2 slots, 80 KiB) gives K two steps and
+// V one step of lead; `s_waitcnt vmcnt(4)` + s_barrier end a step.
+// Lazy integer running max without a first-tile case (m~ starts at 0, moves up or down by integers in the exact
+// path), whole-row sums in both half-lanes, dtype-dependent lower threshold: as in bsattn2.hip.
+#include "common.h"
+
+namespace jenga {
+namespace {
+
+struct LpParams {
+    const uint16_t* q;
+    const uint16_t* k;
+    const uint16_t* vt;
+    uint16_t* o;
+    const int32_t* seqlens;
+    const int32_t* idx;
+    const int32_t* cnt;
+    long long q_sb, q_ss, q_sh, k_sb, k_ss, k_sh, o_sb, o_ss, o_sh;
+    int B, H, n_blocks, nq_img;
+    int text_block_start;
+    float qk_scale;
+    float text_amp;
+    int n_text_wg_pad;
+    int img_per_head;
+    int xcd_chunk;
+};
+
+constexpr int LP_TILE = 16384;
+constexpr int LP_K_RING = 0;               // 3 slots: tile t in slot t % 3
+constexpr int LP_V_RING = 3 * LP_TILE;     // 2 slots: tile t in slot t & 1
+constexpr int LP_LDS_BYTES = 5 * LP_TILE;  // 80 KiB: two workgroups per CU
+
+constexpr float LP_RAISE_SUM = 256.0f;
+template <typename T> __device__ __forceinline__ constexpr float lp_tiny();
+template <> __device__ __forceinline__ constexpr float lp_tiny<BF16>() { return 8.673617379884035e-19f; }   // 2^-60
+template <> __device__ __forceinline__ constexpr float lp_tiny<FP16>() { return 0.0625f; }                   // 2^-4
+
+// four 1-KiB LDS-DMA pieces of one tile (see bsattn2.hip: immediate offsets, piece i's lane offsets biased by -1024 i)
+__device__ __forceinline__ void lp_stage4(const void* base, unsigned lds, unsigned o0, unsigned o1, unsigned o2,
+                                          unsigned o3) {
+#ifdef JENGA_X_NODMA
+    return;
+#endif
+    asm volatile("s_mov_b32 m0, %0\n\t"
+                 "s_nop 0\n\t"
+                 "global_load_lds_dwordx4 %2, %1\n\t"
+                 "global_load_lds_dwordx4 %3, %1 offset:1024\n\t"
+                 "global_load_lds_dwordx4 %4, %1 offset:2048\n\t"
+                 "global_load_lds_dwordx4 %5, %1 offset:3072"
+                 :
+                 : "s"(lds), "s"(base), "v"(o0), "v"(o1), "v"(o2), "v"(o3)
+                 : "memory");
+}
+#define LP_WAIT_ALL() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#ifdef JENGA_X_NOWAIT
+#define LP_WAIT_KEEP4()
+#else
+#define LP_WAIT_KEEP4() asm volatile("s_waitcnt vmcnt(4)" ::: "memory")
+#endif
+
+struct LpState {
+    uint4 qf[8];
+    f32x16 o[4];
+    float l;       // whole-row running sum (identical in the two lanes that share a row)
+    float neg_m;   // -m~
+    f32x16 cinit;  // 16 copies of -m~: C operand of the first QK^T MFMA of an item (image rows), so that the scores
+                   // arrive as S - m~ and the softmax saves one VALU instruction per score
+};
+
+// exact (max-first) softmax of one 32-key item from its intact scores
+// `s`: raw scores (TEXT) or S - m~(old) (image rows).  `pend`: scores of the NEXT item, already produced against the
+// old m~ (or null).
+template <typename T, bool TEXT>
+__device__ __forceinline__ void lp_exact(LpState& st, const f32x16& s, uint4 (&pf)[2], float& psum, float qk_scale,
+                                         f32x16* pend) {
+    float v[16];
+    float tmax = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        v[r] = TEXT ? s[r] * qk_scale + st.neg_m : s[r];
+        tmax = fmaxf(tmax, v[r]);
+    }
+    tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+    const bool move = (tmax > 0.f) || (st.l + psum < lp_tiny<T>());
+    const float delta = (move && tmax > -1e30f) ? fmaxf(ceilf(tmax), -120.f) : 0.f;
+    const float f2 = __builtin_amdgcn_exp2f(-delta);
+    st.neg_m -= delta;
+    st.l *= f2;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) st.o[i][r] *= f2;
+    if (!TEXT) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) st.cinit[r] = st.neg_m;
+        if (pend) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) (*pend)[r] -= delta;
+        }
+    }
+    float e[16];
+    psum = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        e[r] = __builtin_amdgcn_exp2f(v[r] - delta);
+        psum += e[r];
+    }
+    psum += __shfl_xor(psum, 32);
+    pf[0] = make_uint4(pack2<T>(e[0], e[1]), pack2<T>(e[2], e[3]), pack2<T>(e[4], e[5]), pack2<T>(e[6], e[7]));
+    pf[1] = make_uint4(pack2<T>(e[8], e[9]), pack2<T>(e[10], e[11]), pack2<T>(e[12], e[13]), pack2<T>(e[14], e[15]));
+}
+
+// One basic block of the pipeline (see the header).  HALF: which 32-key half of the 64-key tiles kt (item i) and vt
+// (item i-2) this block works on.
+template <typename T, bool TEXT, int HALF, bool DO_PV, bool DO_QK, bool DO_SM>
+__device__ __forceinline__ void lp_bb(LpState& st, const unsigned char* kt, const unsigned char* vt, f32x16& sn,
+                                      const f32x16& sp, const uint4 (&pf_old)[2], uint4 (&pf_new)[2],
+                                      const int (&k_addr)[8], const int (&v_addr)[4], float qk_scale) {
+    f32x16 zero16;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) zero16[r] = 0.f;
+    uint4 fr[16];
+    float tt[16], xx[16];
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    uint32_t ww[8];
+#ifdef JENGA_X_NOREADS      /* EXPERIMENT (wrong results): no fragment reads at all */
+#define LP_RD_ON(F_) false
+#elif defined(JENGA_X_HALFREADS)   /* EXPERIMENT (wrong results): every second fragment read skipped */
+#define LP_RD_ON(F_) (((F_) & 1) == 0)
+#else
+#define LP_RD_ON(F_) true
+#endif
+#define LP_READ(F_)                                                                                                   \
+    do {                                                                                                              \
+        if (!LP_RD_ON(F_)) {                                                                                          \
+            if ((F_) < 16) fr[(F_) & 15] = fr[((F_) & 15) ^ 1];                                                       \
+        } else if ((F_) < 8) {                                                                                        \
+            if (DO_QK) fr[F_] = *reinterpret_cast<const uint4*>(kt + k_addr[F_] + HALF * 8192);                       \
+        } else if ((F_) < 16) {                                                                                       \
+            if (DO_PV) fr[F_] = *reinterpret_cast<const uint4*>(vt + v_addr[2 * HALF + (((F_) - 8) >> 2)] +           \
+                                                                (((F_) - 8) & 3) * 4096);                             \
+        }                                                                                                             \
+    } while (0)
+#ifdef JENGA_X_NOSM
+#define LP_SM_ON false
+#else
+#define LP_SM_ON true
+#endif
+    /* image rows: the scores are S - m~ already (C operand); TEXT rows: raw scores, scaled and shifted here */
+#define LP_SM(M_)                                                                                                     \
+    do {                                                                                                              \
+        if (DO_SM && LP_SM_ON) {                                                                                      \
+            if (TEXT) {                                                                                               \
+                if ((M_) < 16) tt[(M_) & 15] = sp[(M_) & 15] * qk_scale + st.neg_m;                                   \
+                if ((M_) >= 1 && (M_) < 17) xx[((M_) - 1) & 15] = __builtin_amdgcn_exp2f(tt[((M_) - 1) & 15]);        \
+            } else {                                                                                                  \
+                if ((M_) >= 1 && (M_) < 17) xx[((M_) - 1) & 15] = __builtin_amdgcn_exp2f(sp[((M_) - 1) & 15]);        \
+            }                                                                                                         \
+            if ((M_) >= 2 && (M_) < 18) {                                                                             \
+                acc[((M_) - 2) & 3] += xx[((M_) - 2) & 15];                                                           \
+                if (((M_) - 2) & 1) ww[(((M_) - 2) & 15) >> 1] = pack2<T>(xx[((M_) - 3) & 15], xx[((M_) - 2) & 15]);  \
+            }                                                                                                         \
+        }                                                                                                             \
+    } while (0)
+#ifdef JENGA_X_NOMFMA       /* EXPERIMENT (wrong results): MFMAs replaced by one cheap VALU op each */
+#define LP_MFMA(D_, A_, B_, C_) do { D_ = C_; D_[0] += __uint_as_float((A_).x ^ (B_).x); } while (0)
+#else
+#define LP_MFMA(D_, A_, B_, C_) D_ = mfma32<T>(A_, B_, C_)
+#endif
+    /* fragment reads go out two at a time, eight MFMAs ahead (slot m, m even, reads the fragments of MFMAs m+8 and
+       m+9), with ONE explicit counted s_waitcnt lgkmcnt per two MFMAs (the compiler would emit one per MFMA).
+       Before MFMA m (even) fragments m, m+1 must be there; the reads issued behind them are m+2 .. min(m+7, 15). */
+#define LP_LGKM(N_)                                                                                                   \
+    do {                                                                                                              \
+        if ((N_) == 0) __builtin_amdgcn_s_waitcnt(0xC07F);                                                            \
+        else if ((N_) == 2) __builtin_amdgcn_s_waitcnt(0xC27F);                                                       \
+        else if ((N_) == 4) __builtin_amdgcn_s_waitcnt(0xC47F);                                                       \
+        else if ((N_) == 6) __builtin_amdgcn_s_waitcnt(0xC67F);                                                       \
+        else if ((N_) == 8) __builtin_amdgcn_s_waitcnt(0xC87F);                                                       \
+        else __builtin_amdgcn_s_waitcnt(0xC07F);                                                                      \
+    } while (0)
+#define LP_SLOT(M_)                                                                                                   \
+    do {                                                                                                              \
+        if (!((M_) & 1) && (((M_) < 8 && DO_QK) || ((M_) >= 8 && DO_PV))) {                                           \
+            if (!DO_QK) LP_LGKM(14 - (M_) > 8 ? 0 : 14 - (M_));   /* drain forms: fragments 8..15 read up front */    \
+            else LP_LGKM((M_) <= 8 ? 6 : 14 - (M_));                                                                  \
+            __builtin_amdgcn_sched_barrier(0);   /* or hipcc moves the MFMA above the wait and adds its own */        \
+        }                                                                                                             \
+        if ((M_) < 8) {                                                                                               \
+            if (DO_QK) {                                                                                              \
+                if ((M_) == 0) { if (TEXT) LP_MFMA(sn, fr[M_], st.qf[M_], zero16); else LP_MFMA(sn, fr[M_], st.qf[M_], st.cinit); } \
+                else LP_MFMA(sn, fr[M_], st.qf[M_], sn);                                                              \
+            }                                                                                                         \
+        } else if (DO_PV) {                                                                                           \
+            LP_MFMA(st.o[((M_) - 8) & 3], fr[M_], pf_old[((M_) - 8) >> 2], st.o[((M_) - 8) & 3]);                     \
+        }                                                                                                             \
+        if (((M_) & 1) == 0) {                                                                                        \
+            LP_READ((M_) + 8); LP_READ((M_) + 9);                                                                     \
+        }                                                                                                             \
+        LP_SM(M_);                                                                                                    \
+        __builtin_amdgcn_sched_barrier(0);                                                                            \
+    } while (0)
+    LP_READ(0); LP_READ(1); LP_READ(2); LP_READ(3); LP_READ(4); LP_READ(5); LP_READ(6); LP_READ(7);
+    if (!DO_QK) {
+        LP_READ(8); LP_READ(9); LP_READ(10); LP_READ(11); LP_READ(12); LP_READ(13); LP_READ(14); LP_READ(15);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    LP_SLOT(0); LP_SLOT(1); LP_SLOT(2); LP_SLOT(3); LP_SLOT(4); LP_SLOT(5); LP_SLOT(6); LP_SLOT(7);
+    LP_SLOT(8); LP_SLOT(9); LP_SLOT(10); LP_SLOT(11); LP_SLOT(12); LP_SLOT(13); LP_SLOT(14); LP_SLOT(15);
+    LP_SM(16);
+    LP_SM(17);
+#undef LP_READ
+#undef LP_SM
+#undef LP_SLOT
+#undef LP_MFMA
+#undef LP_LGKM
+    if (DO_SM) {
+        const float half_ = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+        const auto sw_ = __builtin_amdgcn_permlane32_swap(__float_as_uint(half_), __float_as_uint(half_), false, false);
+        float psum = __uint_as_float(sw_[0]) + __uint_as_float(sw_[1]);   // both half-lanes: the row's 32 keys
+        pf_new[0] = make_uint4(ww[0], ww[1], ww[2], ww[3]);
+        pf_new[1] = make_uint4(ww[4], ww[5], ww[6], ww[7]);
+#ifdef JENGA_X_NOSM
+        psum = 1.f + sp[0] * 1e-30f;
+        pf_new[0] = pf_new[1] = make_uint4(0x3c003c00u, 0x3c003c00u, 0x3c003c00u, 0x3c003c00u);
+#else
+        if (__any(!(psum <= LP_RAISE_SUM) || (st.l + psum < lp_tiny<T>())))
+            lp_exact<T, TEXT>(st, sp, pf_new, psum, qk_scale, DO_QK ? &sn : nullptr);
+#endif
+        st.l += psum;
+    }
+}
+
+// a whole 64-key tile, unpipelined, with the text_amp add and the kv-length mask (tail of the ascending lists)
+template <typename T>
+__device__ __forceinline__ void lp_slow_tile(LpState& st, const unsigned char* kt, const unsigned char* vt, int key0,
+                                             bool amp_on, float text_amp, int seqlen, int hi,
+                                             const int (&k_addr)[8], const int (&v_addr)[4]) {
+    if (key0 >= seqlen) return;   // contributes exp2(-inf) = 0
+    f32x16 zero16;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) zero16[r] = 0.f;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        f32x16 s;
+        {
+            uint4 ka[8];
+#pragma unroll
+            for (int ds = 0; ds < 8; ++ds) ka[ds] = *reinterpret_cast<const uint4*>(kt + k_addr[ds] + half * 8192);
+            s = mfma32<T>(ka[0], st.qf[0], st.cinit);   // S - m~
+#pragma unroll
+            for (int ds = 1; ds < 8; ++ds) s = mfma32<T>(ka[ds], st.qf[ds], s);
+        }
+        if (amp_on) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[r] += text_amp;
+        }
+        if (key0 + 64 > seqlen) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int kk = key0 + half * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                if (kk >= seqlen) s[r] = -INFINITY;
+            }
+        }
+        uint4 pf[2];
+        float psum = 0.f;
+        lp_exact<T, false>(st, s, pf, psum, 0.f, nullptr);
+        st.l += psum;
+        uint4 va[2][4];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int db = 0; db < 4; ++db)
+                va[ks][db] = *reinterpret_cast<const uint4*>(vt + v_addr[2 * half + ks] + db * 4096);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int db = 0; db < 4; ++db) st.o[db] = mfma32<T>(va[ks][db], pf[ks], st.o[db]);
+    }
+}
+
+template <typename T, bool TEXT>
+__device__ __forceinline__ void attn_block_lp(const LpParams& P, unsigned char* smem, int b, int h, int m) {
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+#ifdef JENGA_LP_LOADERS
+    // EXPERIMENT (timing of the "idle waves stage the tiles" idea): 8 waves; waves 0-3 compute and never issue a DMA,
+    // waves 4-7 issue all of it (8 pieces of K + 8 of V^T per tile each ... i.e. both halves of this wave's share)
+    const int wave_all = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool is_loader = wave_all >= 4;
+    const int wave_u = wave_all & 3;
+#else
+    const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool is_loader = false;
+#endif
+    const int lq = lane & 31, hi = lane >> 5;
+    const int seqlen = P.seqlens ? __builtin_amdgcn_readfirstlane(P.seqlens[b]) : P.n_blocks * 128;
+
+    const int32_t* list = nullptr;
+    int nkept;
+    if (TEXT) {
+        nkept = P.n_blocks;
+    } else {
+        const long long row = ((long long)b * P.H + h) * P.nq_img + m;
+        list = P.idx + row * P.n_blocks;
+        nkept = __builtin_amdgcn_readfirstlane(P.cnt[row]);
+    }
+
+    LpState st;
+    const long long qrow = (long long)m * 128 + wave_u * 32 + lq;
+    {
+        const uint16_t* qp = P.q + b * P.q_sb + qrow * P.q_ss + h * P.q_sh + hi * 8;
+#pragma unroll
+        for (int ds = 0; ds < 8; ++ds) {
+            uint4 raw = *reinterpret_cast<const uint4*>(qp + ds * 16);
+            if (!TEXT) {   // q~ = dtype(q * sm_scale * log2 e)   (reference :87-88)
+                float f[8];
+                unpack8<T>(raw, f);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) f[e] = f[e] * P.qk_scale;
+                raw = pack8<T>(f);
+            }
+            st.qf[ds] = raw;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) st.o[i][r] = 0.f;
+    st.l = 0.f;
+    st.neg_m = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) st.cinit[r] = 0.f;
+    uint16_t* const op = P.o + b * P.o_sb + qrow * P.o_ss + h * P.o_sh + hi * 4;
+
+    const uint16_t* kbh = P.k + b * P.k_sb + h * P.k_sh;
+    const uint16_t* vbh = P.vt + ((long long)b * P.H + h) * (long long)P.n_blocks * (2 * 128 * 64);
+
+    int k_addr[8], v_addr[4];
+#pragma unroll
+    for (int ds = 0; ds < 8; ++ds) k_addr[ds] = LP_K_RING + lq * 256 + (((ds * 2 + hi) ^ (lq & 15)) << 4);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+        v_addr[ks] = LP_V_RING + lq * 128 + ((((ks >> 1) * 4 + hi * 2 + (ks & 1)) ^ ((lq >> 1) & 7)) << 4);
+    const unsigned smem_base =
+        __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem);
+    const int kr_ = 16 * wave_u + (lane >> 4), kc_ = lane & 15, ksw_ = lane >> 4;
+    const unsigned kss_b = (unsigned)P.k_ss * 2u;
+    const unsigned k_src0 = (unsigned)(kr_ + 0) * kss_b + ((kc_ ^ (0 + ksw_)) << 4);
+    const unsigned k_src1 = (unsigned)(kr_ + 4) * kss_b + ((kc_ ^ (4 + ksw_)) << 4) - 1024u;
+    const unsigned k_src2 = (unsigned)(kr_ + 8) * kss_b + ((kc_ ^ (8 + ksw_)) << 4) - 2048u;
+    const unsigned k_src3 = (unsigned)(kr_ + 12) * kss_b + ((kc_ ^ (12 + ksw_)) << 4) - 3072u;
+    const int vr_ = 32 * wave_u + (lane >> 3), vc_ = lane & 7, vsw_ = lane >> 4;
+    const unsigned v_src0 = (unsigned)(vr_ + 0) * 128 + ((vc_ ^ ((0 + vsw_) & 7)) << 4);
+    const unsigned v_src1 = (unsigned)(vr_ + 8) * 128 + ((vc_ ^ ((4 + vsw_) & 7)) << 4) - 1024u;
+    const unsigned v_src2 = (unsigned)(vr_ + 16) * 128 + ((vc_ ^ ((8 + vsw_) & 7)) << 4) - 2048u;
+    const unsigned v_src3 = (unsigned)(vr_ + 24) * 128 + ((vc_ ^ ((12 + vsw_) & 7)) << 4) - 3072u;
+
+    // kept list, 64 entries at a time in one VGPR (bsattn.hip)
+    int lchunk = 0, lbase = -64;
+    auto blk_at = [&](int i) -> int {
+        if (i >= nkept) i = nkept - 1;   // the last steps stage one (unused) tile more: same piece count every step
+        if (TEXT) return i;
+        if (i < lbase || i >= lbase + 64) {
+            lbase = i & ~63;
+            lchunk = (lbase + lane < nkept) ? list[lbase + lane] : 0;
+            // wait HERE for the (rare) reload: at the join in front of v_readlane hipcc's vmcnt(0) runs every step and
+            // drains the whole LDS-DMA prefetch (the hardware counter includes the asm loads)
+            __builtin_amdgcn_s_waitcnt(0x0F70);
+        }
+        return __builtin_amdgcn_readlane(lchunk, i - lbase);
+    };
+    // tile t = half (t & 1) of kept block t >> 1
+    auto issue_k = [&](int t) {
+#ifdef JENGA_LP_LOADERS
+        if (!is_loader) return;
+#endif
+        const int tc = t < 2 * nkept ? t : 2 * nkept - 1;
+        const int blk = blk_at(tc >> 1);
+        lp_stage4(kbh + ((long long)blk * 128 + (tc & 1) * 64) * P.k_ss,
+                  smem_base + LP_K_RING + (t % 3) * LP_TILE + wave_u * 4096, k_src0, k_src1, k_src2, k_src3);
+    };
+    auto issue_v = [&](int t) {
+#ifdef JENGA_LP_LOADERS
+        if (!is_loader) return;
+#endif
+        const int tc = t < 2 * nkept ? t : 2 * nkept - 1;
+        const int blk = blk_at(tc >> 1);
+        lp_stage4(vbh + ((long long)blk * 2 + (tc & 1)) * (128 * 64),
+                  smem_base + LP_V_RING + (t & 1) * LP_TILE + wave_u * 4096, v_src0, v_src1, v_src2, v_src3);
+    };
+    auto kslot = [&](int t) { return smem + (t % 3) * LP_TILE; };   // + k_addr (LP_K_RING inside)
+    auto vslot = [&](int t) { return smem + (t & 1) * LP_TILE; };   // + v_addr (LP_V_RING inside)
+
+    // blocks at the tail of the ascending list that need the text_amp / kv-length path
+    int n_fast = nkept;
+    if (!TEXT) {
+        while (n_fast > 0) {
+            const int bl = blk_at(n_fast - 1);
+            if (bl >= P.text_block_start || (bl + 1) * 128 > seqlen) --n_fast; else break;
+        }
+    }
+    const int t_fast = 2 * n_fast, t_all = 2 * nkept;
+
+    f32x16 sA, sB;
+    uint4 pfA[2], pfB[2];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sA[r] = sB[r] = 0.f;
+    pfA[0] = pfA[1] = pfB[0] = pfB[1] = make_uint4(0u, 0u, 0u, 0u);
+
+    // prologue: K(0), K(1)
+    if (nkept > 0) {
+        issue_k(0);
+        issue_k(1);
+    }
+    LP_WAIT_ALL();
+    __syncthreads();
+
+    // step t: stage V^T(t) and K(t+2); QK^T on K(t); P.V on V^T(t-1)
+#define LP_STEP(T_, PV_, SM0_)                                                                                        \
+    do {                                                                                                              \
+        issue_v(T_);                                                                                                  \
+        lp_bb<T, TEXT, 0, PV_, true, SM0_>(st, kslot(T_), vslot((T_) - 1), sA, sB, pfA, pfB, k_addr, v_addr,          \
+                                           P.qk_scale);                                                               \
+        issue_k((T_) + 2);                                                                                            \
+        lp_bb<T, TEXT, 1, PV_, true, true>(st, kslot(T_), vslot((T_) - 1), sB, sA, pfB, pfA, k_addr, v_addr,          \
+                                           P.qk_scale);                                                               \
+        LP_WAIT_KEEP4();                                                                                              \
+        __syncthreads();                                                                                              \
+    } while (0)
+#ifdef JENGA_LP_LOADERS
+    if (is_loader) {
+        for (int t = 0; t < t_all; ++t) {
+            issue_v(t);
+            issue_k(t + 2);
+            if (t < t_fast) { LP_WAIT_KEEP4(); __syncthreads(); }
+            else { LP_WAIT_ALL(); __syncthreads(); __syncthreads(); }
+        }
+        LP_WAIT_ALL();
+        return;
+    }
+#endif
+    if (t_fast > 0) {
+        LP_STEP(0, false, false);
+        for (int t = 1; t < t_fast; ++t) LP_STEP(t, true, true);
+        // drain: softmax of the last item, P.V of the last tile
+        lp_bb<T, TEXT, 0, true, false, true>(st, nullptr, vslot(t_fast - 1), sA, sB, pfA, pfB, k_addr, v_addr,
+                                             P.qk_scale);
+        lp_bb<T, TEXT, 1, true, false, false>(st, nullptr, vslot(t_fast - 1), sB, sA, pfB, pfA, k_addr, v_addr,
+                                              P.qk_scale);
+    }
+#undef LP_STEP
+    if (!TEXT) {
+        for (int t = t_fast; t < t_all; ++t) {
+            issue_v(t);
+            issue_k(t + 2);
+            LP_WAIT_ALL();   // this step reads V^T(t) itself
+            __syncthreads();
+            const int blk = blk_at(t >> 1);
+            lp_slow_tile<T>(st, kslot(t), vslot(t), blk * 128 + (t & 1) * 64, blk >= P.text_block_start, P.text_amp,
+                            seqlen, hi, k_addr, v_addr);
+            __syncthreads();
+        }
+    }
+    LP_WAIT_ALL();
+
+    // ---- epilogue: o = acc / l, rows >= seqlen written as zeros (image rows only) ----
+    const bool row_ok = TEXT || (qrow < seqlen);
+#pragma unroll
+    for (int db = 0; db < 4; ++db) {
+#pragma unroll
+        for (int rq = 0; rq < 4; ++rq) {
+            uint2 w = make_uint2(0u, 0u);
+            if (row_ok) {
+                w.x = pack2<T>(__fdiv_rn(st.o[db][rq * 4 + 0], st.l), __fdiv_rn(st.o[db][rq * 4 + 1], st.l));
+                w.y = pack2<T>(__fdiv_rn(st.o[db][rq * 4 + 2], st.l), __fdiv_rn(st.o[db][rq * 4 + 3], st.l));
+            }
+            *reinterpret_cast<uint2*>(op + db * 32 + rq * 8) = w;
+        }
+    }
+}
+
+#ifdef JENGA_LP_LOADERS
+#define LP_THREADS 512
+#else
+#define LP_THREADS 256
+#endif
+template <typename T>
+__global__ void __launch_bounds__(LP_THREADS, 2) bsattn_lp_kernel(LpParams P) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int n_text = P.n_blocks - P.nq_img;
+    const int id = blockIdx.x;
+    if (id < P.n_text_wg_pad) {   // text query blocks first: the longest work items start earliest
+        if (id >= P.B * P.H * n_text) return;
+        const int m = P.nq_img + id % n_text;
+        const int bh = id / n_text;
+        attn_block_lp<T, true>(P, smem, bh / P.H, bh % P.H, m);
+        return;
+    }
+    const int li = id - P.n_text_wg_pad;
+    const int bh = li / P.img_per_head;
+    const int r = li % P.img_per_head;
+    int m;
+    if (P.xcd_chunk) {
+        m = (r & 7) * P.xcd_chunk + (r >> 3);
+        if ((r >> 3) >= P.xcd_chunk || m >= P.nq_img) return;
+    } else {
+        m = r;
+    }
+    attn_block_lp<T, false>(P, smem, bh / P.H, bh % P.H, m);
+}
+
+}  // namespace
+}  // namespace jenga
+
+using namespace jenga;
+
+// same arguments as jenga_bsattn_fwd (bsattn.hip); reached through it with JENGA_ATTN_LP
+int jenga_bsattn_lp_launch(void* stream, const void* q, const void* k, const void* vt, void* o, const int32_t* seqlens,
+                           const int32_t* idx, const int32_t* cnt, int64_t B, int64_t H, int64_t n_blocks,
+                           int64_t nq_img, int64_t q_sb, int64_t q_ss, int64_t q_sh, int64_t k_sb, int64_t k_ss,
+                           int64_t k_sh, int64_t o_sb, int64_t o_ss, int64_t o_sh, float sm_scale, float text_amp,
+                           int64_t text_block_start, int dtype, int flags) {
+    LpParams P;
+    P.q = (const uint16_t*)q;
+    P.k = (const uint16_t*)k;
+    P.vt = (const uint16_t*)vt;
+    P.o = (uint16_t*)o;
+    P.seqlens = seqlens;
+    P.idx = idx;
+    P.cnt = cnt;
+    P.q_sb = q_sb; P.q_ss = q_ss; P.q_sh = q_sh;
+    P.k_sb = k_sb; P.k_ss = k_ss; P.k_sh = k_sh;
+    P.o_sb = o_sb; P.o_ss = o_ss; P.o_sh = o_sh;
+    P.B = (int)B; P.H = (int)H; P.n_blocks = (int)n_blocks; P.nq_img = (int)nq_img;
+    P.text_block_start = (int)text_block_start;
+    P.qk_scale = (float)((double)sm_scale * 1.44269504);
+    P.text_amp = text_amp;
+    const long long n_text = n_blocks - nq_img;
+    const long long n_text_wg = B * H * n_text;
+    P.n_text_wg_pad = (int)((n_text_wg + 7) / 8 * 8);
+    if ((flags & JENGA_ATTN_XCD_REMAP) && nq_img >= 64) {
+        P.xcd_chunk = (int)((nq_img + 7) / 8);
+        P.img_per_head = P.xcd_chunk * 8;
+    } else {
+        P.xcd_chunk = 0;
+        P.img_per_head = (int)nq_img;
+    }
+    const long long grid = (long long)P.n_text_wg_pad + B * H * (long long)P.img_per_head;
+    if (grid <= 0 || grid > 0x7fffffffLL) {
+        set_error("jenga_bsattn_fwd: grid size %lld out of range", grid);
+        return JENGA_EINVAL;
+    }
+    const size_t smem = LP_LDS_BYTES;
+    if (dtype == JENGA_BF16) {
+        (void)hipFuncSetAttribute((const void*)bsattn_lp_kernel<BF16>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)smem);
+        hipLaunchKernelGGL(bsattn_lp_kernel<BF16>, dim3((unsigned)grid), dim3(LP_THREADS), smem, (hipStream_t)stream, P);
+    } else {
+        (void)hipFuncSetAttribute((const void*)bsattn_lp_kernel<FP16>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)smem);
+        hipLaunchKernelGGL(bsattn_lp_kernel<FP16>, dim3((unsigned)grid), dim3(LP_THREADS), smem, (hipStream_t)stream, P);
+    }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        set_error("jenga_bsattn_fwd (lp): %s", hipGetErrorString(e));
+        return JENGA_ELAUNCH;
+    }
+    return JENGA_OK;
+}

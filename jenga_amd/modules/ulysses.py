@@ -3,17 +3,32 @@ for tests.  Counterpart of hyvideo/modules/xdit_ring_atten.py:22-222 (xFuserLong
 xfuser group accessors the driver uses (jenga_hyvideo_multigpu.py:168-177,193).
 
 What the reference does per layer: 4 all-to-alls in (Q, K, V, text-Q), local block_sparse_attention on H/N heads over
-the whole sequence, 2 all-to-alls out (image O, and text O repeated N times = an all-gather in disguise).
-What this does: three all_to_all_single calls for Q, K, V whose send buffers are packed peer-major by a HIP kernel and
-whose receive buffers ARE the prefix of the [S_img + S_txt] tensors the attention kernel reads (zero unpack copies), no
-exchange at all for text Q/K/V (text is replicated: every rank slices its own heads), one all_to_all_single for image
-O straight out of the attention output (already peer-major), one all_gather over heads for text O.  xGMI is a full
-point-to-point mesh, so the N-1 peer messages of an all-to-all (11 MB each at N=8) ride separate links concurrently.
+the whole sequence, 2 all-to-alls out (image O, and text O repeated N times = an all-gather in disguise), all on one
+stream, each followed by a permute+contiguous copy.
+
+What this does per layer ("1 fused QKV all-to-all + 1 O all-to-all + 1 small text all-gather"):
+  in : Q, K, V of the local sequence shard are packed peer-major by a HIP kernel and leave in ONE grouped exchange
+       (one RCCL group = one communication kernel: N-1 sends + N-1 receives per tensor, posted together).  Every
+       incoming message lands directly in the prefix of the [S_img + S_txt] tensor the attention kernel reads
+       (rank-major sequence == contiguous for B == 1): no unpack pass, no torch.cat.  The exchange runs on RCCL's own
+       stream; the compute stream meanwhile copies the replicated text rows (each rank slices its own heads, nothing
+       is exchanged for text), waits for Q and K only, pools and selects blocks, and waits for V just before the V
+       re-tiling -- the V transfer overlaps the selection.  (JENGA_ULYSSES_EXCHANGE=a2a: three all_to_all_single calls
+       instead, issued back to back and waited for the same way.)
+  out: one all_to_all_single for image O straight out of the attention output (already peer-major), one
+       all_gather_into_tensor over heads for text O, both in flight together, one HIP unpack kernel each.
+xGMI is a full point-to-point mesh: the N-1 peer messages of an exchange (11 MB each at N = 8) ride separate links.
 
 The arithmetic contract (the part parity tests pin): rank-major sequence concatenation, contiguous head slices
 [r*H/N, (r+1)*H/N), top_k passed through unchanged (the caller already multiplied it by N, models_mul...:249-251),
 cu_seqlens rebuilt as [0, n_valid_text + S_img, S] (:183-184).
+
+The forward is written as local stages (`stage_in`, `local_attention`, `stage_out`) around two exchanges so that
+tests can drive N simulated ranks in one process on one GPU with an exchange that really permutes the chunks
+(tests/test_gpu_ulysses.py), and the world_size-2 gloo test exercises the collectives themselves.
 """
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -33,9 +48,10 @@ class _SPGroup:
         n = dist.get_world_size(self.group)
         if n == 1:
             return x
-        parts = [torch.empty_like(x) for _ in range(n)]
-        dist.all_gather(parts, x.contiguous(), group=self.group)
-        return torch.cat(parts, dim=dim)
+        x = x.contiguous()
+        out = torch.empty((n,) + tuple(x.shape), dtype=x.dtype, device=x.device)
+        dist.all_gather_into_tensor(out, x, group=self.group)
+        return torch.cat(list(out.unbind(0)), dim=dim) if dim != 0 else out.reshape((-1,) + tuple(x.shape[1:]))
 
 
 def init_sequence_parallel(group=None):
@@ -68,32 +84,124 @@ def _unpack_heads(recv, N, out):
     return _capi.ulysses_unpack_heads(recv, N, out=out)
 
 
-def _hip_attention(q_all, k_all, v_all, top_k, seqlens, text_blocks, text_amp, p, neighbors):
-    """Default local attention: the HIP AttenCarve core on this rank's heads over the whole sequence."""
+def _hip_select(q_all, k_all, top_k, text_blocks, p, neighbors):
+    nb = q_all.shape[1] // 128
+    if nb - text_blocks <= 0:
+        return None, None
+    _, idx, cnt = _op.build_block_index(q_all, k_all, top_k, text_blocks, p, neighbors)
+    return idx, cnt
+
+
+def _hip_attend(q_all, k_all, v_all, idx, cnt, seqlens, text_blocks, text_amp):
     nb = q_all.shape[1] // 128
     vt = _capi.pack_v(v_all, nb)
-    return _op.attencarve_packed(q_all, k_all, vt, top_k, seqlens, text_blocks, text_amp, p, neighbors)
+    return _capi.bsattn_fwd(q_all, k_all, vt, seqlens, idx, cnt, nb - text_blocks, q_all.shape[-1] ** -0.5, text_amp,
+                            nb - text_blocks)
+
+
+class _Done:
+    def wait(self):
+        return True
+
+
+class DistExchange:
+    """The two exchange steps on a torch.distributed process group.  Every method returns an object with .wait():
+    on RCCL the transfer runs on the process group's own stream and .wait() only makes the CURRENT stream wait for it
+    (no host synchronisation); on gloo .wait() blocks the host."""
+
+    def __init__(self, group, mode=None):
+        self.group = group
+        self.mode = mode or os.environ.get("JENGA_ULYSSES_EXCHANGE", "p2p")
+        if self.mode not in ("p2p", "a2a"):
+            raise ValueError("JENGA_ULYSSES_EXCHANGE must be 'p2p' (one grouped exchange) or 'a2a'")
+
+    def size(self):
+        return dist.get_world_size(self.group)
+
+    def rank(self):
+        return dist.get_rank(self.group)
+
+    def all_to_all(self, recvs, sends):
+        """recvs[i], sends[i]: [N, ...] contiguous, chunk p of sends[i] goes to rank p and chunk p of recvs[i] comes
+        from rank p -- for ALL i in one grouped exchange ("p2p") or one all_to_all_single per tensor ("a2a")."""
+        N, r = self.size(), self.rank()
+        if N == 1:
+            for rc, sd in zip(recvs, sends):
+                rc.copy_(sd)
+            return [_Done()]
+        if self.mode == "a2a":
+            return [dist.all_to_all_single(rc, sd, group=self.group, async_op=True) for rc, sd in zip(recvs, sends)]
+        ops = []
+        for rc, sd in zip(recvs, sends):
+            rc[r].copy_(sd[r])                                   # my own chunk never touches the fabric
+            for step in range(1, N):                             # same peer order on every rank, sends and receives
+                to, frm = (r + step) % N, (r - step) % N         # of one step pair up: no rank waits on a busy peer
+                ops.append(dist.P2POp(dist.isend, sd[to], dist.get_global_rank(self.group, to), self.group))
+                ops.append(dist.P2POp(dist.irecv, rc[frm], dist.get_global_rank(self.group, frm), self.group))
+        return dist.batch_isend_irecv(ops)
+
+    def all_gather(self, out, x):
+        """out [N, ...] <- x from every rank."""
+        if self.size() == 1:
+            out[0].copy_(x)
+            return _Done()
+        return dist.all_gather_into_tensor(out, x.contiguous(), group=self.group, async_op=True)
+
+
+def _wait_all(works):
+    for w in works:
+        w.wait()
 
 
 class UlyssesAttenCarve(torch.nn.Module):
     """Callable with the signature of xFuserLongContextAttention.forward (xdit_ring_atten.py:61-85); assign an
     instance to `block.hybrid_seq_parallel_attn` exactly as jenga_hyvideo_multigpu.py:181-182 does.
 
-    The three local steps are injectable so that the world_size > 1 exchange logic can be exercised on CPU tensors over
-    gloo against the oracle (tests/test_ulysses_gloo.py supplies oracle stand-ins); the defaults are the HIP kernels and
+    The local steps are injectable so that the world_size > 1 exchange logic can be exercised on CPU tensors over gloo
+    against the oracle (tests/test_ulysses_gloo.py supplies oracle stand-ins); the defaults are the HIP kernels and
     raise on CPU tensors -- there is no CPU path in the product:
-      attn_fn(q_all, k_all, v_all, top_k, seqlens, text_blocks, text_amp, p, neighbors) -> [1,S,H/N,D]
+      select_fn(q_all, k_all, top_k, text_blocks, p, neighbors) -> (idx, cnt)
+      attend_fn(q_all, k_all, v_all, idx, cnt, seqlens, text_blocks, text_amp) -> [1,S,H/N,D]
       pack_fn(t [B,S_loc,H,D], N) -> [N,B,S_loc,H/N,D];  unpack_fn(recv [N,B,S_loc,H/N,D], N, out [B,S_loc,H,D])"""
 
-    def __init__(self, group=None, attn_fn=None, pack_fn=None, unpack_fn=None):
+    def __init__(self, group=None, select_fn=None, attend_fn=None, pack_fn=None, unpack_fn=None, exchange=None):
         super().__init__()
         self.group = group
-        self.attn_fn = attn_fn or _hip_attention
+        self.select_fn = select_fn or _hip_select
+        self.attend_fn = attend_fn or _hip_attend
         self.pack_fn = pack_fn or _pack_heads
         self.unpack_fn = unpack_fn or _unpack_heads
+        self._exchange = exchange
 
-    def _pg(self):
-        return self.group if self.group is not None else get_sp_group().group
+    def exchange(self):
+        if self._exchange is None:
+            self._exchange = DistExchange(self.group if self.group is not None else get_sp_group().group)
+        return self._exchange
+
+    # ---- local stages ------------------------------------------------------------------------------------------
+    def stage_in(self, query, key, value, jq, jk, jv, N, r):
+        """-> (sends [3 x [N,S_loc,Hn,D]], gathered [3 x [1,S,Hn,D]] with the text rows already in place, recv views)."""
+        B, S_loc, H, D = query.shape
+        Hn = H // N
+        S_txt = jq.shape[1]
+        S_img = S_loc * N
+        hs = slice(r * Hn, (r + 1) * Hn)
+        sends, fulls, recvs = [], [], []
+        for t, joint in ((query, jq), (key, jk), (value, jv)):
+            sends.append(self.pack_fn(t, N).view(N, S_loc, Hn, D))
+            full = torch.empty((B, S_img + S_txt, Hn, D), dtype=t.dtype, device=t.device)
+            full[:, S_img:] = joint[:, :, hs]      # text is replicated on every rank: slice my heads, no exchange
+            fulls.append(full)
+            recvs.append(full[0, :S_img].view(N, S_loc, Hn, D))
+        return sends, fulls, recvs
+
+    def stage_out(self, o_recv, txt_all, N, S_loc, S_txt, dtype, device):
+        """o_recv [N,S_loc,Hn,D] (chunk p = my tokens, rank p's heads), txt_all [N,1,S_txt,Hn,D] -> [1,S_loc+S_txt,H,D]."""
+        Hn, D = o_recv.shape[-2:]
+        result = torch.empty((1, S_loc + S_txt, N * Hn, D), dtype=dtype, device=device)
+        self.unpack_fn(o_recv.view(N, 1, S_loc, Hn, D), N, result[:, :S_loc])
+        self.unpack_fn(txt_all, N, result[:, S_loc:])
+        return result
 
     @torch.no_grad()
     def forward(self, attn, query, key, value, *, joint_tensor_query=None, joint_tensor_key=None,
@@ -103,8 +211,8 @@ class UlyssesAttenCarve(torch.nn.Module):
         if joint_strategy != "rear" or joint_tensor_query is None or joint_tensor_key is None \
                 or joint_tensor_value is None:
             raise ValueError("jenga_amd Ulysses: only joint_strategy='rear' with text q/k/v (the Jenga call) is supported")
-        pg = self._pg()
-        N, r = dist.get_world_size(pg), dist.get_rank(pg)
+        ex = self.exchange()
+        N, r = ex.size(), ex.rank()
         B, S_loc, H, D = query.shape
         if B != 1:
             raise ValueError("jenga_amd Ulysses: batch must be 1")
@@ -113,38 +221,32 @@ class UlyssesAttenCarve(torch.nn.Module):
         Hn = H // N
         S_txt = joint_tensor_query.shape[1]
         S_img = S_loc * N
-        S = S_img + S_txt
         if S_img % 128 or S_txt % 128:
             raise ValueError("gathered image length and text length must be multiples of 128")
         dev, dt = query.device, query.dtype
-        hs = slice(r * Hn, (r + 1) * Hn)
-        # ---- exchange in: scatter heads / gather sequence.  Each all-to-all lands in the PREFIX of the buffer the
-        #      attention kernel reads (rank-major sequence == contiguous for B == 1): no unpack, no torch.cat.
-        gathered = []
-        for t, joint in ((query, joint_tensor_query), (key, joint_tensor_key), (value, joint_tensor_value)):
-            full = torch.empty((B, S, Hn, D), dtype=dt, device=dev)
-            dist.all_to_all_single(full[0, :S_img].view(N, S_loc, Hn, D), self.pack_fn(t, N).view(N, S_loc, Hn, D),
-                                   group=pg)
-            full[:, S_img:] = joint[:, :, hs]      # text is replicated on every rank: slice my heads, no exchange
-            gathered.append(full)
-        q_all, k_all, v_all = gathered
+        # ---- exchange in: scatter heads / gather sequence; Q+K first, V behind them on the communication stream
+        sends, (q_all, k_all, v_all), recvs = self.stage_in(query, key, value, joint_tensor_query, joint_tensor_key,
+                                                            joint_tensor_value, N, r)
+        w_qk = ex.all_to_all(recvs[:2], sends[:2])
+        w_v = ex.all_to_all(recvs[2:], sends[2:])
         # cu_seqlens = [0, n_valid_text + S_img, S] (xdit_ring_atten.py:105,183-184) -- stays on the device
         seqlens = (cu_seqlens_q[1:2].to(torch.int64) - S_loc + S_img).to(device=dev, dtype=torch.int32)
-        out = self.attn_fn(q_all, k_all, v_all, top_k, seqlens, S_txt // 128, text_amp, p_remain_rates,
-                           block_neighbor_list)
+        _wait_all(w_qk)
+        idx, cnt = self.select_fn(q_all, k_all, top_k, S_txt // 128, p_remain_rates, block_neighbor_list)
+        _wait_all(w_v)                                         # the V transfer overlapped pooling + selection
+        out = self.attend_fn(q_all, k_all, v_all, idx, cnt, seqlens, S_txt // 128, text_amp)
         # ---- exchange out: image rows (already peer-major: chunk p = rank p's tokens) back to sequence shards;
         #      text rows gathered over heads (the reference repeats them N times and all-to-alls, :206-217)
         o_img = out[0, :S_img].reshape(N, S_loc, Hn, D)
         if not o_img.is_contiguous():
             o_img = o_img.contiguous()
         o_recv = torch.empty((N, S_loc, Hn, D), dtype=dt, device=dev)
-        dist.all_to_all_single(o_recv, o_img, group=pg)
-        result = torch.empty((B, S_loc + S_txt, H, D), dtype=dt, device=dev)
-        self.unpack_fn(o_recv.view(N, B, S_loc, Hn, D), N, result[:, :S_loc])
-        txt_parts = [torch.empty((B, S_txt, Hn, D), dtype=dt, device=dev) for _ in range(N)]
-        dist.all_gather(txt_parts, out[:, S_img:].contiguous(), group=pg)
-        result[:, S_loc:] = torch.cat(txt_parts, dim=2)
-        return result
+        txt_all = torch.empty((N, B, S_txt, Hn, D), dtype=dt, device=dev)
+        w_o = ex.all_to_all([o_recv], [o_img])
+        w_t = ex.all_gather(txt_all, out[:, S_img:])
+        _wait_all(w_o)
+        w_t.wait()
+        return self.stage_out(o_recv, txt_all, N, S_loc, S_txt, dt, dev)
 
 
 # name the reference uses (jenga_hyvideo_multigpu.py:181)

@@ -92,8 +92,12 @@ CASES = [
 ]
 
 
+NEW_KERNELS = {"pair": 1, "lp": 9}     # flags: XCD remap | (0 = pair kernel, 8 = JENGA_ATTN_LP)
+
+
+@pytest.mark.parametrize("kern", list(NEW_KERNELS))
 @pytest.mark.parametrize("case", CASES, ids=lambda c: f"seed{c[0]}")
-def test_pair_kernel_vs_oracle_and_legacy(dev, case):
+def test_pair_kernel_vs_oracle_and_legacy(dev, case, kern):
     """Every row of the output (image AND text rows) against the oracle, and the two kernels against each other: same
     arithmetic, different kv order per row, so they agree to fp32-summation noise, i.e. the odd last-place flip."""
     from jenga_amd import _capi
@@ -101,7 +105,7 @@ def test_pair_kernel_vs_oracle_and_legacy(dev, case):
     seed, H, nq_img, tb, dt, density, overlap, valid_text, amp = case
     q, k, v, mask = _rand_case(seed, H, nq_img, tb, dt, density, overlap)
     seqlen = nq_img * 128 + valid_text if tb else nq_img * 128 - 19     # no text: the last image block is padded
-    o_new = _run(q, k, v, mask, seqlen, amp, nq_img, dev, flags=_capi.ATTN_XCD_REMAP)
+    o_new = _run(q, k, v, mask, seqlen, amp, nq_img, dev, flags=NEW_KERNELS[kern])
     o_old = _run(q, k, v, mask, seqlen, amp, nq_img, dev, flags=_capi.ATTN_XCD_REMAP | _capi.ATTN_LEGACY)
     assert torch.isfinite(o_new.float()).all()
     tol = 2e-2 if dt == "bfloat16" else 4e-3
@@ -118,8 +122,9 @@ def test_pair_kernel_vs_oracle_and_legacy(dev, case):
         assert np.abs(gott - reft).max() <= tol, np.abs(gott - reft).max()
 
 
+@pytest.mark.parametrize("kern", list(NEW_KERNELS))
 @pytest.mark.parametrize("dt", ["bfloat16", "float16"])
-def test_pair_kernel_running_max_moves_both_ways(dev, dt):
+def test_pair_kernel_running_max_moves_both_ways(dev, dt, kern):
     """The lazy running max starts at 0 and has no first-tile special case: rows whose scores all sit far BELOW zero
     must pull m~ down (running sum < 2^-60 -> exact path), rows with a late spike must push it up, including spikes
     that sit in A-only, B-only and shared blocks and in either 64-key half."""
@@ -150,7 +155,7 @@ def test_pair_kernel_running_max_moves_both_ways(dev, dt):
     mask[:, :, 5, 7] = True; mask[:, :, 4, 7] = True       # rows 640/641 (block 5): shared block
     mask[:, :, 7, 1] = True
     seqlen = nq_img * 128 + 50
-    o = _run(q, kk, v, mask, seqlen, 0.0, nq_img, dev, flags=None)
+    o = _run(q, kk, v, mask, seqlen, 0.0, nq_img, dev, flags=NEW_KERNELS[kern])
     # the low rows: a second run in which ALL keys are anti-aligned with those rows' queries is too contrived; instead
     # shift the rows' scores down through the query itself: q_r -> q_r and k unchanged gives ordinary scores, so use a
     # dedicated tensor where keys of the kept blocks are -g * q_r for ONE head-row pair each
@@ -165,7 +170,7 @@ def test_pair_kernel_running_max_moves_both_ways(dev, dt):
     # all-negative rows: every key of the sequence = -g * (that row's query) + noise, one row at a time
     for r, g in zip(low_rows, (4.0, 6.0, 5.0)):
         k2 = (-g * q[0, r].float()[None].expand(S, H, 128) + 0.05 * torch.randn(S, H, 128, generator=gen))[None].to(tdt)
-        o2 = _run(q, k2, v, mask, seqlen, 0.0, nq_img, dev, flags=None)
+        o2 = _run(q, k2, v, mask, seqlen, 0.0, nq_img, dev, flags=NEW_KERNELS[kern])
         ref2 = oa.sparse_rows(qn[:, :, :S_img], to_np(k2.transpose(1, 2)), vn, [seqlen], mask.numpy(), 128 ** -0.5, dt,
                               0.0, nq_img)
         got2 = o2[:, :S_img].transpose(1, 2).float().cpu().numpy()
@@ -174,7 +179,8 @@ def test_pair_kernel_running_max_moves_both_ways(dev, dt):
         assert np.abs(got2 - ref2).max() <= tol, np.abs(got2 - ref2).max()
 
 
-def test_pair_kernel_full_size_heads_subset(dev):
+@pytest.mark.parametrize("kern", list(NEW_KERNELS))
+def test_pair_kernel_full_size_heads_subset(dev, kern):
     """HunyuanVideo 720p shape (900 + 2 blocks), 2 heads, random lists with the benchmark's density: finite output,
     softmax rows are convex combinations of V (|o| <= max |v|), and sampled rows against the oracle."""
     from jenga_amd import _capi
@@ -195,7 +201,7 @@ def test_pair_kernel_full_size_heads_subset(dev):
     vt = _capi.pack_v(v, nb)
     seqlen = nq_img * 128 + 64
     seqlens = torch.tensor([seqlen], dtype=torch.int32, device=dev)
-    o = _capi.bsattn_fwd(q, k, vt, seqlens, idx, cnt, nq_img, 128 ** -0.5, 0.0, nq_img)
+    o = _capi.bsattn_fwd(q, k, vt, seqlens, idx, cnt, nq_img, 128 ** -0.5, 0.0, nq_img, flags=NEW_KERNELS[kern])
     o_old = _capi.bsattn_fwd(q, k, vt, seqlens, idx, cnt, nq_img, 128 ** -0.5, 0.0, nq_img,
                              flags=_capi.ATTN_XCD_REMAP | _capi.ATTN_LEGACY)
     torch.cuda.synchronize()

@@ -203,7 +203,7 @@ def test_sparse_kernel_vs_triton_interpreter_golden(golden_dir, dev, index):
 
 
 @pytest.mark.parametrize("dt,flags", [("bfloat16", None), ("float16", None), ("bfloat16", 0), ("bfloat16", 5), ("float16", 4),
-                                      ("bfloat16", 3), ("float16", 2)])
+                                      ("bfloat16", 3), ("float16", 2), ("bfloat16", 9), ("float16", 8), ("bfloat16", 1)])
 def test_sparse_kernel_vs_oracle(dev, dt, flags):
     """flags None = the default pair kernel (two query blocks per workgroup, XCD remap on), 0 = plain workgroup order;
     4 / 5 = the round-1 kernel (JENGA_ATTN_LEGACY: one query block per 4-wave workgroup); 2 / 3 = the experimental 8-wave

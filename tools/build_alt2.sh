@@ -1,0 +1,12 @@
+#!/bin/bash
+# Alternative libjenga_amd.so with a variant of the PAIR kernel for same-box A/B runs (select with JENGA_LIB=...):
+#   tools/build_alt2.sh NAME [extra hipcc flags for bsattn2.hip, e.g. -DJENGA_X_NODMA ...]
+# Output: alt_libs/NAME.so (git-ignored, travels with gpurun).  Needs jenga_amd/build/*.o from a normal build.
+set -e
+cd "$(dirname "$0")/.."
+NAME=$1; shift
+mkdir -p alt_libs
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -x hip -Ijenga_amd/csrc -c jenga_amd/csrc/bsattn2.hip -o alt_libs/$NAME.o -fno-honor-nans -fno-slp-vectorize "$@" 2>&1 | grep -E "error" || true
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o alt_libs/$NAME.so alt_libs/$NAME.o jenga_amd/build/capi.o jenga_amd/build/gilbert.o jenga_amd/build/rowops.o jenga_amd/build/select.o jenga_amd/build/bsattn.o
+rm alt_libs/$NAME.o
+echo alt_libs/$NAME.so
