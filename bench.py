@@ -124,12 +124,35 @@ def main():
     if sim > 1:
         from torch.testing._internal.distributed.fake_pg import FakeStore
         dist.init_process_group(backend="fake", rank=0, world_size=sim, store=FakeStore())
-        dist.all_to_all_single = lambda out, inp, group=None, **kw: out.copy_(inp)      # same shapes by construction
 
-        def _gather(parts, x, group=None, **kw):
-            for p_ in parts:
-                p_.copy_(x)
-        dist.all_gather = _gather
+        def _gather_into(out, x, group=None, **kw):          # rank 0's view: every peer holds what I hold
+            out.view((sim,) + tuple(x.shape)).copy_(x.unsqueeze(0).expand((sim,) + tuple(x.shape)))
+        dist.all_gather_into_tensor = _gather_into
+
+    class _LocalExchange:
+        """--simulate-ranks: the exchanges of rank 0 replaced by local copies of the same shapes."""
+
+        def __init__(self, n):
+            self.n = n
+
+        def size(self):
+            return self.n
+
+        def rank(self):
+            return 0
+
+        def all_to_all(self, recvs, sends):
+            for rc, sd in zip(recvs, sends):
+                rc.copy_(sd)
+            return []
+
+        def all_gather(self, out, x):
+            out.copy_(x.unsqueeze(0).expand_as(out))
+
+            class _W:
+                def wait(self):
+                    return True
+            return _W()
 
     from jenga_amd import _capi
     from jenga_amd.dit import NON_SKIP_STEPS, JengaHYVideoDiT
@@ -145,13 +168,19 @@ def main():
         w_ = torch.ones(world, 16, device=dev)
         r_ = torch.empty_like(w_)
         dist.all_to_all_single(r_, w_)
-        dist.all_gather([torch.empty(16, device=dev) for _ in range(world)], w_[0].contiguous())
+        dist.all_gather_into_tensor(torch.empty(world * 16, device=dev), w_[0].contiguous())
+        ops = []
+        for step in range(1, world):     # the grouped send/recv the Ulysses exchange uses: create its channels now too
+            ops.append(dist.P2POp(dist.isend, w_[(rank + step) % world], (rank + step) % world))
+            ops.append(dist.P2POp(dist.irecv, r_[(rank - step) % world], (rank - step) % world))
+        for w__ in dist.batch_isend_irecv(ops):
+            w__.wait()
         dist.all_reduce(w_)
         torch.cuda.synchronize()
     if world > 1 or sim > 1:
         ulysses.init_sequence_parallel()
         for blk in list(model.double_blocks) + list(model.single_blocks):
-            blk.hybrid_seq_parallel_attn = ulysses.UlyssesAttenCarve()
+            blk.hybrid_seq_parallel_attn = ulysses.UlyssesAttenCarve(exchange=_LocalExchange(sim) if sim > 1 else None)
     from jenga_amd import prores
     preset = dict(PRESETS[a.preset])
     if a.rates:

@@ -17,6 +17,7 @@ Weights are synthetic (random init; there are no checkpoints in this environment
 real model (timestep MLPs, token refiner) are replaced by one linear each -- they run once per step on <= 256 tokens.
 """
 import math
+import os
 from typing import Tuple
 
 import torch
@@ -271,6 +272,7 @@ class JengaHYVideoDiT(nn.Module):
         # HunyuanVideo-I2V (jenga_hyi2v.py:79-92, 124-130): "token_replace" conditions the first latent frame's tokens
         # with the modulation of timestep 0; None = text-to-video
         self.i2v_condition_type = None
+        self.sp_check_agreement = os.environ.get("JENGA_SP_CHECK", "0") == "1"
 
     @torch.no_grad()
     def init_synthetic_weights(self, std=0.02, seed=0):
@@ -327,40 +329,44 @@ class JengaHYVideoDiT(nn.Module):
         dt = self.img_in.weight.dtype
         vec = self.time_in(self._sinusoid(t).to(dt)) + self.vector_in(text_states_2.to(dt))
         vec = vec + self.guidance_in(self._sinusoid(guidance).to(dt))
-        img = self.img_in(self.patchify(x).to(dt))
         txt = self.txt_in(text_states.to(dt))
-        txt_seq_len, img_seq_len = txt.shape[1], img.shape[1]
-        # Hilbert gather (K10): image tokens and RoPE rows into curve order
-        img = _capi.gather_rows(img, self.hilbert_order)
-        freqs_cos = _capi.gather_rows(freqs_cos.unsqueeze(0), self.hilbert_order)[0]
-        freqs_sin = _capi.gather_rows(freqs_sin.unsqueeze(0), self.hilbert_order)[0]
+        patches = self.patchify(x).to(dt)
+        txt_seq_len, img_seq_len = txt.shape[1], patches.shape[1]
+        sp = self.double_blocks[0].hybrid_seq_parallel_attn if len(self.double_blocks) else None
+        order = self.hilbert_order
+        n, r = 1, 0
+        if sp:
+            # sequence parallel: this rank embeds and carries ONLY its contiguous shard of the curve-ordered tokens
+            # (the reference embeds everything on every rank and chunks afterwards, jenga_hyvideo_multigpu.py:168-177;
+            # token-wise layers commute with the gather, so gathering the shard's rows first is the same arithmetic)
+            n, r = ulysses.get_sequence_parallel_world_size(), ulysses.get_sequence_parallel_rank()
+            assert img_seq_len % n == 0, f"cannot split {img_seq_len} image tokens over {n} ranks"
+            order = torch.chunk(order, n, dim=0)[r].contiguous()
+        # Hilbert gather (K10): image patches and RoPE rows into curve order (only this rank's rows)
+        img = self.img_in(_capi.gather_rows(patches, order))
+        freqs_cos = _capi.gather_rows(freqs_cos.unsqueeze(0), order)[0]
+        freqs_sin = _capi.gather_rows(freqs_sin.unsqueeze(0), order)[0]
         token_replace_vec = first_frame_mask = None
         if self.i2v_condition_type == "token_replace":
             token_replace_vec = self.time_in(self._sinusoid(torch.zeros_like(t)).to(dt)) + self.vector_in(text_states_2.to(dt))
-            first_frame_mask = (self.hilbert_order < th * tw)          # == mask[:th*tw] = 1 gathered into curve order
+            first_frame_mask = (order < th * tw)                       # == mask[:th*tw] = 1 gathered into curve order
         elif self.i2v_condition_type is not None:
             raise ValueError(f"unsupported i2v_condition_type {self.i2v_condition_type!r}")
         if txt_seq_len % 128:
             raise ValueError("the text length must be a multiple of 128 (2 blocks for T2V, 4 for I2V)")
-        sp = self.double_blocks[0].hybrid_seq_parallel_attn if len(self.double_blocks) else None
-        if sp:
-            n, r = ulysses.get_sequence_parallel_world_size(), ulysses.get_sequence_parallel_rank()
-            assert img_seq_len % n == 0, f"cannot split {img_seq_len} image tokens over {n} ranks"
-            img = torch.chunk(img, n, dim=1)[r].contiguous()
-            freqs_cos = torch.chunk(freqs_cos, n, dim=0)[r].contiguous()
-            freqs_sin = torch.chunk(freqs_sin, n, dim=0)[r].contiguous()
-            if first_frame_mask is not None:
-                first_frame_mask = torch.chunk(first_frame_mask, n, dim=0)[r].contiguous()
         loc_len = img.shape[1]
         cu_seqlens_q = get_cu_seqlens(text_mask, loc_len)
         cu_seqlens_kv = cu_seqlens_q
         max_seqlen_q = max_seqlen_kv = loc_len + txt_seq_len
         should_calc = (not self.enable_skip) or (self.cnt in NON_SKIP_STEPS) or self.start_stage
         self.start_stage = False
-        if sp and self.enable_skip and torch.distributed.is_initialized():
-            flag = torch.tensor([1 if should_calc else 0], device=img.device)       # C4: agree on skip/compute
+        if sp and self.enable_skip and torch.distributed.is_initialized() and self.sp_check_agreement:
+            # C4 (jenga_hyvideo_multigpu.py:233-236): the reference all-reduces the skip flag every step and reads it
+            # back on the host.  Every rank holds the same step counter, so the decision is already identical; the
+            # all-reduce (and its host synchronisation) is kept as a debug assertion only (JENGA_SP_CHECK=1).
+            flag = torch.tensor([1 if should_calc else 0], device=img.device)
             torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MIN, group=ulysses.get_sp_group().group)
-            should_calc = bool(flag.item())
+            assert bool(flag.item()) == should_calc, "ranks disagree on the step-skip decision"
         if not should_calc:
             img = img + self.previous_residual
         else:
@@ -383,10 +389,12 @@ class JengaHYVideoDiT(nn.Module):
         self.cnt += 1
         if self.cnt == self.num_steps:
             self.cnt = 0
-        if sp:
-            img = ulysses.get_sp_group().all_gather(img.contiguous(), dim=1)       # C3
-        img = _capi.gather_rows(img.contiguous(), self.linear_to_hilbert)            # Hilbert scatter (K10)
+        # final layer on the LOCAL shard (token-wise), then gather the 64-channel patches instead of the 3072-channel
+        # hidden states (C3: 48x fewer bytes than the reference's all_gather of img, jenga_hyvideo_multigpu.py:193)
         shift, scale = self.final_mod(F.silu(vec)).chunk(2, dim=1)
         img = self.final_linear(modulate(self.final_norm(img), shift, scale))
+        if sp:
+            img = ulysses.get_sp_group().all_gather(img.contiguous(), dim=1)
+        img = _capi.gather_rows(img.contiguous(), self.linear_to_hilbert)            # Hilbert scatter (K10)
         img = self.unpatchify(img, tt, th, tw)
         return {"x": img} if return_dict else img

@@ -50,7 +50,7 @@ class _SPGroup:
             return x
         x = x.contiguous()
         out = torch.empty((n,) + tuple(x.shape), dtype=x.dtype, device=x.device)
-        dist.all_gather_into_tensor(out, x, group=self.group)
+        dist.all_gather_into_tensor(out.view((-1,) + tuple(x.shape[1:])), x, group=self.group)
         return torch.cat(list(out.unbind(0)), dim=dim) if dim != 0 else out.reshape((-1,) + tuple(x.shape[1:]))
 
 
@@ -145,7 +145,8 @@ class DistExchange:
         if self.size() == 1:
             out[0].copy_(x)
             return _Done()
-        return dist.all_gather_into_tensor(out, x.contiguous(), group=self.group, async_op=True)
+        x = x.contiguous()   # (gloo wants the output as the inputs stacked along dim 0 of the INPUT's rank)
+        return dist.all_gather_into_tensor(out.view((-1,) + tuple(x.shape[1:])), x, group=self.group, async_op=True)
 
 
 def _wait_all(works):

@@ -23,14 +23,20 @@ def _free_port():
     return p
 
 
-def _oracle_attn(q_all, k_all, v_all, top_k, seqlens, text_blocks, text_amp, p, neighbors):
+def _oracle_select(q_all, k_all, top_k, text_blocks, p, neighbors):
+    """Stand-in for the HIP selection on CPU tensors: hands the selection parameters on to _oracle_attend (the oracle's
+    op does selection + attention in one call)."""
+    return dict(top_k=top_k, p=p, neighbors=neighbors), None
+
+
+def _oracle_attend(q_all, k_all, v_all, sel, _cnt, seqlens, text_blocks, text_amp):
     from oracle import attention as oa
     S = q_all.shape[1]
     cu = np.array([0, int(seqlens[0]), S], np.int64)
-    nb = None if neighbors is None else np.asarray(neighbors)
-    o = oa.block_sparse_attention(to_np(q_all), to_np(k_all), to_np(v_all), top_k, "bfloat16", cu_seqlens_q=cu,
+    nb = None if sel["neighbors"] is None else np.asarray(sel["neighbors"])
+    o = oa.block_sparse_attention(to_np(q_all), to_np(k_all), to_np(v_all), sel["top_k"], "bfloat16", cu_seqlens_q=cu,
                                   text_blocks=text_blocks, text_amp=text_amp, block_neighbor_list=nb,
-                                  shape_xfuse=True, p_remain_rates=p)
+                                  shape_xfuse=True, p_remain_rates=sel["p"])
     return torch.from_numpy(o).to(q_all.dtype)
 
 
@@ -46,7 +52,7 @@ def _make_case():
     return q, k, v, nbm, nimg, tb
 
 
-def _worker(rank, world, port, ret):
+def _worker(rank, world, port, ret, mode):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
@@ -63,7 +69,9 @@ def _worker(rank, world, port, ret):
         cu = torch.tensor([0, S_loc + n_valid, S_loc + tb * 128], dtype=torch.int32)
         top_k_local = int((1 - 0.5) * (S_loc // 128))                   # models_mul...:242 on the LOCAL block count
         from oracle import ulysses as ou
-        sp = ulysses.UlyssesAttenCarve(attn_fn=_oracle_attn, pack_fn=ou.pack_heads, unpack_fn=ou.unpack_heads)
+        sp = ulysses.UlyssesAttenCarve(select_fn=_oracle_select, attend_fn=_oracle_attend, pack_fn=ou.pack_heads,
+                                       unpack_fn=ou.unpack_heads,
+                                       exchange=ulysses.DistExchange(ulysses.get_sp_group().group, mode=mode))
         out = my_parallel_attention(sp, loc(q), loc(k), loc(v), img_q_len=S_loc, img_kv_len=S_loc, cu_seqlens_q=cu,
                                     cu_seqlens_kv=cu, top_k=world * top_k_local, text_amp=0.25,
                                     block_neighbor_list=torch.from_numpy(nbm), p_remain_rates=0.3)
@@ -75,12 +83,14 @@ def _worker(rank, world, port, ret):
         dist.destroy_process_group()
 
 
-def test_ulysses_two_ranks_match_oracle_and_single_rank():
+@pytest.mark.parametrize("mode", ["p2p", "a2a"])
+def test_ulysses_two_ranks_match_oracle_and_single_rank(mode):
+    """mode "p2p": Q, K (and V) leave in one grouped send/recv batch; "a2a": one all_to_all_single per tensor."""
     world = 2
     port = _free_port()
     mgr = mp.Manager()
     ret = mgr.dict()
-    mp.spawn(_worker, args=(world, port, ret), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port, ret, mode), nprocs=world, join=True)
     from oracle import attention as oa
     from oracle import ulysses as ou
     q, k, v, nbm, nimg, tb = _make_case()
