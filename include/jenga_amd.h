@@ -115,6 +115,20 @@ int jenga_wan_ln_modulate(void* stream, const float* x, void* y, const float* we
 int jenga_wan_gate_residual(void* stream, const float* x, const void* y, const float* gate, float* out, int64_t rows,
                             int64_t C, int64_t x_row_stride, int64_t y_row_stride, int64_t o_row_stride, int y_dtype);
 
+/* jenga_qk_norm_rope_pool: jenga_rmsnorm_rope for Q AND K plus the two jenga_block_pool passes of a
+ * layer in one kernel.  xq, xk [B, n_blocks*128, H, 128] share one set of strides (the q and k slices of a fused QKV
+ * GEMM output), oq, ok likewise; RoPE on tokens < s_rope.  The mean of every 128-token block of the WRITTEN q / k rows
+ * goes to qpool [B,H,nq_pool,128] / kpool [B,H,nk_pool,128] at block index pool_block0 + j (only where that index is
+ * inside the pooled tensor; either pointer may be NULL) -- bit-identical to jenga_block_pool of the outputs, so that
+ * image and text streams of a double block fill one pooled tensor in two calls.  H <= 64 (one thread group per head).
+ * Replaces per layer: 2-4 jenga_rmsnorm_rope launches + 2 jenga_block_pool passes (1.4 GB of reads) and reads the
+ * cos / sin tables once instead of twice. */
+int jenga_qk_norm_rope_pool(void* stream, const void* xq, const void* xk, void* oq, void* ok, const void* wq,
+                            const void* wk, const float* cosT, const float* sinT, void* qpool, void* kpool, int64_t B,
+                            int64_t n_blocks, int64_t H, int64_t x_sb, int64_t x_ss, int64_t x_sh, int64_t o_sb,
+                            int64_t o_ss, int64_t o_sh, int64_t s_rope, int64_t pool_block0, int64_t nq_pool,
+                            int64_t nk_pool, float eps, int dtype);
+
 /* ---------------------------------------------------------------------------------------------------
  * Block selection.  Replaces _build_block_index_with_importance_optimized
  * (hyvideo/modules/attention_block_triton_diffres.py:198-295; Wan first_frame_blocks rule

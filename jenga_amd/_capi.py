@@ -33,6 +33,7 @@ SIGNATURES = {
     "jenga_gelu_tanh": (_i32, [_vp, _vp, _vp] + [_i64] * 4 + [_i32]),
     "jenga_wan_ln_modulate": (_i32, [_vp] * 7 + [_i64] * 4 + [_f32, _i32, _i32]),
     "jenga_wan_gate_residual": (_i32, [_vp] * 5 + [_i64] * 5 + [_i32]),
+    "jenga_qk_norm_rope_pool": (_i32, [_vp] * 11 + [_i64] * 13 + [_f32, _i32]),
     "jenga_block_pool": (_i32, [_vp, _vp, _vp] + [_i64] * 6 + [_i32]),
     "jenga_block_select": (_i32, [_vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp] + [_i64] * 6 + [_f32, _i64, _i32]),
     "jenga_pack_v_bytes": (ctypes.c_size_t, [_i64, _i64, _i64]),
@@ -186,6 +187,51 @@ def rmsnorm_rope(x, weight, cos, sin, s_rope=None, eps=1e-6, out=None):
         _check(lib().jenga_rmsnorm_rope(_stream(x.device), _p(x), _p(out), _p(weight), _p(cos), _p(sin), B, S, H,
                                         *xs, *os_, s_rope, float(eps), dtype_code(x.dtype)), "jenga_rmsnorm_rope")
     return out
+
+
+def qk_norm_rope_pool(xq, xk, wq, wk, cos, sin, out_q, out_k, s_rope=None, qpool=None, kpool=None, pool_block0=0,
+                      eps=1e-6):
+    """Fused per-head RMSNorm + RoPE of Q and K (+ 128-token block means of the results).
+    xq, xk [B,S,H,128] with the SAME strides (the q / k slices of one QKV GEMM output), S a multiple of 128;
+    out_q, out_k [B,S,H,128] with the same strides as each other; qpool [B,H,nq,128] / kpool [B,H,nk,128] receive the
+    means of blocks pool_block0 .. pool_block0 + S/128 - 1 (where inside the pooled tensor)."""
+    _need_gpu(xq, "qk_norm_rope_pool")
+    B, S, H, D = xq.shape
+    if D != 128 or S % 128 or xk.shape != xq.shape or out_q.shape != xq.shape or out_k.shape != xq.shape:
+        raise ValueError("qk_norm_rope_pool: q / k / outputs must be [B, n*128, H, 128] of one shape")
+    if _bshd_strides(xq) != _bshd_strides(xk) or _bshd_strides(out_q) != _bshd_strides(out_k):
+        raise ValueError("qk_norm_rope_pool: q and k (and their outputs) must share their strides")
+    if H > 64:
+        raise ValueError("qk_norm_rope_pool: at most 64 heads")
+    wq = None if wq is None else wq.to(device=xq.device, dtype=xq.dtype).contiguous()
+    wk = None if wk is None else wk.to(device=xq.device, dtype=xq.dtype).contiguous()
+    if cos is not None:
+        if cos.dtype != torch.float32 or sin.dtype != torch.float32 or cos.shape[-1] != 128:
+            raise ValueError("cos/sin must be float32 [S,128]")
+        cos, sin = cos.contiguous(), sin.contiguous()
+        if s_rope is None:
+            s_rope = cos.shape[0]
+        if s_rope > cos.shape[0] or s_rope > S:
+            raise ValueError("s_rope exceeds the table / sequence length")
+    else:
+        s_rope = 0
+    nq = nk = 0
+    if qpool is not None:
+        if qpool.dim() != 4 or qpool.shape[0] != B or qpool.shape[1] != H or qpool.shape[3] != 128 \
+                or not qpool.is_contiguous() or qpool.dtype != xq.dtype:
+            raise ValueError("qpool must be a contiguous [B,H,nq,128] tensor of the input dtype")
+        nq = qpool.shape[2]
+    if kpool is not None:
+        if kpool.dim() != 4 or kpool.shape[0] != B or kpool.shape[1] != H or kpool.shape[3] != 128 \
+                or not kpool.is_contiguous() or kpool.dtype != xq.dtype:
+            raise ValueError("kpool must be a contiguous [B,H,nk,128] tensor of the input dtype")
+        nk = kpool.shape[2]
+    with torch.cuda.device(xq.device):
+        _check(lib().jenga_qk_norm_rope_pool(_stream(xq.device), _p(xq), _p(xk), _p(out_q), _p(out_k), _p(wq), _p(wk),
+                                             _p(cos), _p(sin), _p(qpool), _p(kpool), B, S // 128, H,
+                                             *_bshd_strides(xq), *_bshd_strides(out_q), int(s_rope), int(pool_block0),
+                                             nq, nk, float(eps), dtype_code(xq.dtype)), "jenga_qk_norm_rope_pool")
+    return out_q, out_k
 
 
 def rmsnorm_rows(x, weight, eps):

@@ -8,12 +8,16 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libjenga_amd.so")
 ARCH = "gfx950"
 
-# (source, extra flags).  rowops: the reference's eager fp32 arithmetic has no fused multiply-adds.
+# (source, extra flags).  rowops / select: the reference's eager arithmetic is "fp32 operation, THEN cast to the tensor
+# dtype": no fused multiply-adds (-ffp-contract=off) and no v_fma_mix*_f16 -- hipcc otherwise folds `half(float(a) * b)`
+# into one mixed-precision instruction that rounds the exact product ONCE, where torch rounds to fp32 first and to fp16
+# second (found in round 2: 1e-4 of the fp16 RMSNorm outputs differed by an ulp from the reference for that reason).
+EAGER = ["-ffp-contract=off", "-Xclang", "-target-feature", "-Xclang", "-fma-mix-insts"]
 SOURCES = [
     ("capi.cpp", []),
     ("gilbert.hip", []),
-    ("rowops.hip", ["-ffp-contract=off"]),
-    ("select.hip", ["-ffp-contract=off"]),
+    ("rowops.hip", EAGER),
+    ("select.hip", EAGER),
     # no NaNs are produced on the attention path (masked logits are -inf, never inf-inf); without this flag every
     # fmaxf on an MFMA result is preceded by a canonicalising v_max.  Infinities stay honoured.
     ("bsattn.hip", ["-fno-honor-nans"]),
@@ -35,7 +39,8 @@ def needs_build():
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(HERE, "..", "include", "jenga_amd.h")]
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(HERE, "..", "include", "jenga_amd.h"),
+                                                                os.path.abspath(__file__)]   # (the flags live here)
     return any(os.path.getmtime(d) > t for d in deps)
 
 

@@ -76,6 +76,109 @@ __global__ void rmsnorm_rope_kernel(const uint16_t* __restrict__ x, uint16_t* __
     }
 }
 
+// ------------------------------------------------------------------------------------------------ Q+K norm+RoPE+pool
+// the RMSNorm / RoPE pass and the two block-pooling passes of a layer in ONE kernel.  One workgroup
+// per 128-token block, 16 lanes per head (blockDim = 16 H): a thread keeps its 8-element slice of ONE head for the
+// whole block, so the pooled mean of Q and K is accumulated in registers while the rows stream through -- in exactly
+// the order of block_pool_kernel (8 tokens summed, 16 partial sums added in ascending order, one rounding), on the
+// values already rounded to the storage dtype, i.e. pooled outputs are bit-identical to pooling the written tensors.
+// The cos / sin row of a token is fetched once for Q and K and all heads (rmsnorm_rope_kernel, called per tensor,
+// fetched the tables twice per layer).  Arithmetic of the norm and the rotation: rmsnorm_rope_kernel's, verbatim.
+template <typename T>
+__device__ __forceinline__ void norm_rope_row(float (&f)[8], const float (&wv)[8], bool has_w, float eps, bool rope,
+                                              const float (&c)[8], const float (&sn)[8]) {
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) ss = __fadd_rn(ss, __fmul_rn(f[i], f[i]));
+    ss += __shfl_xor(ss, 1);
+    ss += __shfl_xor(ss, 2);
+    ss += __shfl_xor(ss, 4);
+    ss += __shfl_xor(ss, 8);
+    const float r = __fdiv_rn(1.0f, __fsqrt_rn(__fadd_rn(__fdiv_rn(ss, 128.0f), eps)));
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        float y = round_to<T>(__fmul_rn(f[i], r));
+        if (has_w) y = round_to<T>(__fmul_rn(y, wv[i]));
+        f[i] = y;
+    }
+    if (rope) {
+        float g[8];
+#pragma unroll
+        for (int i = 0; i < 8; i += 2) {
+            g[i] = __fadd_rn(__fmul_rn(f[i], c[i]), __fmul_rn(-f[i + 1], sn[i]));
+            g[i + 1] = __fadd_rn(__fmul_rn(f[i + 1], c[i + 1]), __fmul_rn(f[i], sn[i + 1]));
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) f[i] = g[i];
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) f[i] = round_to<T>(f[i]);   // what the store writes (and what gets pooled)
+}
+
+template <typename T>
+__global__ void qk_norm_rope_pool_kernel(const uint16_t* __restrict__ xq, const uint16_t* __restrict__ xk,
+                                         uint16_t* __restrict__ oq, uint16_t* __restrict__ ok,
+                                         const uint16_t* __restrict__ wq, const uint16_t* __restrict__ wk,
+                                         const float* __restrict__ cosT, const float* __restrict__ sinT,
+                                         uint16_t* __restrict__ qpool, uint16_t* __restrict__ kpool, long long B,
+                                         long long nblk, long long H, long long x_sb, long long x_ss, long long x_sh,
+                                         long long o_sb, long long o_ss, long long o_sh, long long s_rope,
+                                         long long pool_block0, long long nq_pool, long long nk_pool, float eps) {
+    const int sub = threadIdx.x & 15;
+    const long long h = threadIdx.x >> 4;   // blockDim.x == 16 * H
+    float wqv[8], wkv[8];
+    if (wq) unpack8<T>(*reinterpret_cast<const uint4*>(wq + sub * 8), wqv);
+    if (wk) unpack8<T>(*reinterpret_cast<const uint4*>(wk + sub * 8), wkv);
+    for (long long wg = blockIdx.x; wg < B * nblk; wg += gridDim.x) {
+        const long long j = wg % nblk, b = wg / nblk;
+        float sq[8] = {0, 0, 0, 0, 0, 0, 0, 0}, sk[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int g = 0; g < 16; ++g) {
+            float aq[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ak[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll 4
+            for (int i = 0; i < 8; ++i) {
+                const long long s_tok = j * 128 + g * 8 + i;
+                const long long xoff = b * x_sb + s_tok * x_ss + h * x_sh + sub * 8;
+                const long long ooff = b * o_sb + s_tok * o_ss + h * o_sh + sub * 8;
+                float fq[8], fk[8];
+                unpack8<T>(*reinterpret_cast<const uint4*>(xq + xoff), fq);
+                unpack8<T>(*reinterpret_cast<const uint4*>(xk + xoff), fk);
+                const bool rope = cosT && s_tok < s_rope;
+                float c[8], sn[8];
+                if (rope) {
+                    const float4* cp = reinterpret_cast<const float4*>(cosT + s_tok * 128 + sub * 8);
+                    const float4* sp = reinterpret_cast<const float4*>(sinT + s_tok * 128 + sub * 8);
+                    const float4 c0 = cp[0], c1 = cp[1], s0 = sp[0], s1 = sp[1];
+                    c[0] = c0.x; c[1] = c0.y; c[2] = c0.z; c[3] = c0.w; c[4] = c1.x; c[5] = c1.y; c[6] = c1.z; c[7] = c1.w;
+                    sn[0] = s0.x; sn[1] = s0.y; sn[2] = s0.z; sn[3] = s0.w; sn[4] = s1.x; sn[5] = s1.y; sn[6] = s1.z; sn[7] = s1.w;
+                }
+                norm_rope_row<T>(fq, wqv, wq != nullptr, eps, rope, c, sn);
+                norm_rope_row<T>(fk, wkv, wk != nullptr, eps, rope, c, sn);
+                *reinterpret_cast<uint4*>(oq + ooff) = pack8<T>(fq);
+                *reinterpret_cast<uint4*>(ok + ooff) = pack8<T>(fk);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    aq[e] += fq[e];
+                    ak[e] += fk[e];
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                sq[e] += aq[e];
+                sk[e] += ak[e];
+            }
+        }
+        float pq[8], pk[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            pq[e] = sq[e] / 128.0f;
+            pk[e] = sk[e] / 128.0f;
+        }
+        const long long jp = pool_block0 + j;
+        if (qpool && jp < nq_pool) *reinterpret_cast<uint4*>(qpool + ((b * H + h) * nq_pool + jp) * 128 + sub * 8) = pack8<T>(pq);
+        if (kpool && jp < nk_pool) *reinterpret_cast<uint4*>(kpool + ((b * H + h) * nk_pool + jp) * 128 + sub * 8) = pack8<T>(pk);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ block pooling
 // One workgroup per (b, h, block): 128 tokens x 128 dims.  thread -> (token group tg = t/16, slice = t%16);
 // each thread sums 8 tokens in fp32, LDS tree over the 16 groups, one rounding of mean to dtype.
@@ -314,6 +417,38 @@ extern "C" int jenga_rmsnorm_rope(void* stream, const void* x, void* out, const 
     if (dtype == JENGA_BF16) LAUNCH_NR(BF16); else LAUNCH_NR(FP16);
 #undef LAUNCH_NR
     JENGA_CHECK_LAUNCH("jenga_rmsnorm_rope");
+    return JENGA_OK;
+}
+
+extern "C" int jenga_qk_norm_rope_pool(void* stream, const void* xq, const void* xk, void* oq, void* ok,
+                                       const void* wq, const void* wk, const float* cosT, const float* sinT,
+                                       void* qpool, void* kpool, int64_t B, int64_t n_blocks, int64_t H, int64_t x_sb,
+                                       int64_t x_ss, int64_t x_sh, int64_t o_sb, int64_t o_ss, int64_t o_sh,
+                                       int64_t s_rope, int64_t pool_block0, int64_t nq_pool, int64_t nk_pool, float eps,
+                                       int dtype) {
+    if (!xq || !xk || !oq || !ok || B < 0 || n_blocks < 0 || H <= 0 || H > 64 || !strides_ok(x_sb, x_ss, x_sh) ||
+        !strides_ok(o_sb, o_ss, o_sh) || ((uintptr_t)xq & 15) || ((uintptr_t)xk & 15) || ((uintptr_t)oq & 15) ||
+        ((uintptr_t)ok & 15) || ((cosT == nullptr) != (sinT == nullptr)) || pool_block0 < 0) {
+        set_error("jenga_qk_norm_rope_pool: bad arguments (1 <= H <= 64, strides multiples of 8 elements, pointers "
+                  "16-B aligned)");
+        return JENGA_EINVAL;
+    }
+    if (dtype != JENGA_BF16 && dtype != JENGA_FP16) {
+        set_error("jenga_qk_norm_rope_pool: dtype must be bf16 or fp16");
+        return JENGA_EUNSUPPORTED;
+    }
+    const long long n = (long long)B * n_blocks;
+    if (n == 0) return JENGA_OK;
+#define LAUNCH_QKP(T)                                                                                             \
+    hipLaunchKernelGGL(qk_norm_rope_pool_kernel<T>, dim3(grid_for(n, 65536)), dim3((unsigned)(16 * H)), 0,        \
+                       (hipStream_t)stream, (const uint16_t*)xq, (const uint16_t*)xk, (uint16_t*)oq, (uint16_t*)ok, \
+                       (const uint16_t*)wq, (const uint16_t*)wk, cosT, sinT, (uint16_t*)qpool, (uint16_t*)kpool,  \
+                       (long long)B, (long long)n_blocks, (long long)H, (long long)x_sb, (long long)x_ss,          \
+                       (long long)x_sh, (long long)o_sb, (long long)o_ss, (long long)o_sh, (long long)s_rope,     \
+                       (long long)pool_block0, (long long)nq_pool, (long long)nk_pool, eps)
+    if (dtype == JENGA_BF16) LAUNCH_QKP(BF16); else LAUNCH_QKP(FP16);
+#undef LAUNCH_QKP
+    JENGA_CHECK_LAUNCH("jenga_qk_norm_rope_pool");
     return JENGA_OK;
 }
 

@@ -133,13 +133,28 @@ class MMDoubleStreamBlock(nn.Module):
         block_neighbor_list = curve_sel[0][2] if curve_sel is not None else None
         top_k = _select_top_k(sa_drop_rate, S_img // per_block_token)
         cos, sin = freqs_cis
-        # QK-norm + RoPE fused, written straight into the concatenated (image | text) buffers
+        # QK-norm + RoPE (+ the block means the selection needs) fused: one kernel per stream handles Q and K, writes
+        # straight into the concatenated (image | text) buffers and fills the pooled tensors
         q = torch.empty((B, S_img + S_txt, H, 128), dtype=img.dtype, device=img.device)
         k = torch.empty_like(q)
-        _capi.rmsnorm_rope(img_qkv[:, :, 0], self.img_attn_q_norm.weight, cos, sin, out=q[:, :S_img])
-        _capi.rmsnorm_rope(img_qkv[:, :, 1], self.img_attn_k_norm.weight, cos, sin, out=k[:, :S_img])
-        _capi.rmsnorm_rope(txt_qkv[:, :, 0], self.txt_attn_q_norm.weight, None, None, out=q[:, S_img:])
-        _capi.rmsnorm_rope(txt_qkv[:, :, 1], self.txt_attn_k_norm.weight, None, None, out=k[:, S_img:])
+        sparse = (not self.hybrid_seq_parallel_attn) and sa_drop_rate != 0.0 and S_img % 128 == 0 and S_txt % 128 == 0
+        pooled = None
+        if sparse:      # (sequence parallel: pooling happens after the exchange, on the gathered sequence)
+            nimg_, nb_ = S_img // 128, (S_img + S_txt) // 128
+            pooled = (torch.empty((B, H, nimg_, 128), dtype=img.dtype, device=img.device),
+                      torch.empty((B, H, nb_, 128), dtype=img.dtype, device=img.device))
+        if S_img % 128 == 0 and S_txt % 128 == 0:
+            qp, kp = pooled if pooled else (None, None)
+            _capi.qk_norm_rope_pool(img_qkv[:, :, 0], img_qkv[:, :, 1], self.img_attn_q_norm.weight,
+                                    self.img_attn_k_norm.weight, cos, sin, q[:, :S_img], k[:, :S_img], qpool=qp, kpool=kp)
+            _capi.qk_norm_rope_pool(txt_qkv[:, :, 0], txt_qkv[:, :, 1], self.txt_attn_q_norm.weight,
+                                    self.txt_attn_k_norm.weight, None, None, q[:, S_img:], k[:, S_img:], qpool=None,
+                                    kpool=kp, pool_block0=S_img // 128)
+        else:
+            _capi.rmsnorm_rope(img_qkv[:, :, 0], self.img_attn_q_norm.weight, cos, sin, out=q[:, :S_img])
+            _capi.rmsnorm_rope(img_qkv[:, :, 1], self.img_attn_k_norm.weight, cos, sin, out=k[:, :S_img])
+            _capi.rmsnorm_rope(txt_qkv[:, :, 0], self.txt_attn_q_norm.weight, None, None, out=q[:, S_img:])
+            _capi.rmsnorm_rope(txt_qkv[:, :, 1], self.txt_attn_k_norm.weight, None, None, out=k[:, S_img:])
         if self.hybrid_seq_parallel_attn:
             # my_parallel_attention's argument convention (attenion.py:159-195) without concatenating V first: the
             # exchange packs the image part and slices the text part separately anyway
@@ -158,7 +173,7 @@ class MMDoubleStreamBlock(nn.Module):
             _capi.pack_v(txt_qkv[:, :, 2], S_txt // 128, out=vt, dst_block0=nimg, dst_blocks_total=nb)
             seqlens = cu_seqlens_q[1:2]
             attn = op.attencarve_packed(q, k, vt, top_k, seqlens, txt_block_num, txt_amp, p_remain_rates,
-                                        block_neighbor_list).view(B, S_img + S_txt, H * 128)
+                                        block_neighbor_list, pooled=pooled).view(B, S_img + S_txt, H * 128)
         img_attn, txt_attn = attn[:, :S_img], attn[:, S_img:]
         # gated residual adds fused; the MLP input is again LayerNorm + modulate in one pass
         img = _capi.gate_residual(img, self.img_attn_proj(img_attn), img_mod1_gate, gate2=tr[2], mask=fm)
@@ -205,8 +220,20 @@ class MMSingleStreamBlock(nn.Module):
         qkv = lin1[..., : 3 * C].unflatten(-1, (3, H, 128))                        # strided views, no copies
         mlp = lin1[..., 3 * C:]
         cos, sin = freqs_cis
-        q = _capi.rmsnorm_rope(qkv[:, :, 0], self.q_norm.weight, cos, sin, s_rope=S_img)   # RoPE on image tokens only
-        k = _capi.rmsnorm_rope(qkv[:, :, 1], self.k_norm.weight, cos, sin, s_rope=S_img)
+        sparse = (not self.hybrid_seq_parallel_attn) and sa_drop_rate != 0.0 and S % 128 == 0 and S_img % 128 == 0
+        pooled = None
+        if S % 128 == 0:   # Q and K in one kernel (RoPE on image tokens only), block means for the selection on the way
+            q = torch.empty((B, S, H, 128), dtype=x.dtype, device=x.device)
+            k = torch.empty_like(q)
+            if sparse:
+                pooled = (torch.empty((B, H, S_img // 128, 128), dtype=x.dtype, device=x.device),
+                          torch.empty((B, H, S // 128, 128), dtype=x.dtype, device=x.device))
+            _capi.qk_norm_rope_pool(qkv[:, :, 0], qkv[:, :, 1], self.q_norm.weight, self.k_norm.weight, cos, sin, q, k,
+                                    s_rope=S_img, qpool=pooled[0] if pooled else None,
+                                    kpool=pooled[1] if pooled else None)
+        else:
+            q = _capi.rmsnorm_rope(qkv[:, :, 0], self.q_norm.weight, cos, sin, s_rope=S_img)
+            k = _capi.rmsnorm_rope(qkv[:, :, 1], self.k_norm.weight, cos, sin, s_rope=S_img)
         block_neighbor_list = curve_sel[0][2] if curve_sel is not None else None
         top_k = _select_top_k(sa_drop_rate, S_img // per_block_token)
         # concat buffer for linear2: attention writes its [B,S,H*128] output straight into the left part
@@ -222,7 +249,7 @@ class MMSingleStreamBlock(nn.Module):
         else:
             vt = _capi.pack_v(qkv[:, :, 2], S // 128)
             op.attencarve_packed(q, k, vt, top_k, cu_seqlens_q[1:2], txt_block_num, txt_amp, p_remain_rates,
-                                 block_neighbor_list, out=cat[..., :C].unflatten(-1, (H, 128)))
+                                 block_neighbor_list, out=cat[..., :C].unflatten(-1, (H, 128)), pooled=pooled)
         _capi.gelu_tanh(mlp, out=cat[..., C:])
         return _capi.gate_residual(x, self.linear2(cat), mod_gate, gate2=tr[2], mask=fm)
 

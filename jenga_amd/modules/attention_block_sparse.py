@@ -25,20 +25,24 @@ def _seqlens_from_cu(cu_seqlens_q, device):
 
 
 def build_block_index(query, key, top_k, text_blocks, prob_threshold, block_neighbor_list=None,
-                      first_frame_blocks=0, want_mask=False):
+                      first_frame_blocks=0, want_mask=False, pooled=None):
     """query/key [B,S,H,128] (S multiple of 128).  -> (mask|None, idx, cnt) for the image query blocks.
-    Replaces _build_block_index_with_importance_optimized (:198-295)."""
+    Replaces _build_block_index_with_importance_optimized (:198-295).  pooled = (qpool [B,H,nimg,128],
+    kpool [B,H,nb,128]) when the caller's norm+RoPE kernel already produced the block means."""
     B, S, H, D = query.shape
     nb = S // BLOCK
     nimg = nb - text_blocks
-    qpool = _capi.block_pool(query, nimg)
-    kpool = _capi.block_pool(key, nb)
+    if pooled is not None:
+        qpool, kpool = pooled
+    else:
+        qpool = _capi.block_pool(query, nimg)
+        kpool = _capi.block_pool(key, nb)
     return _capi.block_select(qpool, kpool, block_neighbor_list, nimg, text_blocks, top_k, prob_threshold,
                               first_frame_blocks=first_frame_blocks, want_mask=want_mask)
 
 
 def attencarve_packed(q, k, vt, top_k, seqlens, text_blocks, text_amp, prob_threshold, block_neighbor_list,
-                      first_frame_blocks=0, out=None, return_lists=False):
+                      first_frame_blocks=0, out=None, return_lists=False, pooled=None):
     """Core used by the DiT blocks: q/k [B,S,H,128] already normed+roped (any strides), vt = packed V workspace
     (jenga_pack_v), seqlens int32 [B] on the device.  Selection + one attention launch; returns o [B,S,H,128]
     (written into `out` if given, which may be a strided view, e.g. the left part of the single-stream blocks'
@@ -49,7 +53,7 @@ def attencarve_packed(q, k, vt, top_k, seqlens, text_blocks, text_amp, prob_thre
     idx = cnt = None
     if nimg > 0:
         _, idx, cnt = build_block_index(q, k, top_k, text_blocks, prob_threshold, block_neighbor_list,
-                                        first_frame_blocks)
+                                        first_frame_blocks, pooled=pooled)
     o = _capi.bsattn_fwd(q, k, vt, seqlens, idx, cnt, nimg, D ** -0.5, text_amp, nimg, out=out)
     return (o, idx, cnt) if return_lists else o
 
