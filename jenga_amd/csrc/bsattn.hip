@@ -286,7 +286,9 @@ __device__ __forceinline__ void attn_block(const AttnParams& P, unsigned char* s
                     float tmax = fmaxf(s0[0], s1[0]);                                                            \
                     _Pragma("unroll") for (int r = 1; r < 16; ++r) tmax = fmaxf(tmax, fmaxf(s0[r], s1[r]));      \
                     tmax = fmaxf(tmax, __shfl_xor(tmax, 32));                                                    \
-                    const float delta = (tmax > LAZY_THR) ? ceilf(tmax) : 0.f;                                   \
+                    /* once in here, re-reference whenever the row max is above m~ at all: with `> LAZY_THR` a    \
+                       row carrying several scores 5..8 above m~ kept taking this branch on every tile */        \
+                    const float delta = (tmax > 0.f) ? ceilf(tmax) : 0.f;                                        \
                     const float f2 = __builtin_amdgcn_exp2f(-delta);                                             \
                     neg_m -= delta;                                                                              \
                     l_i *= f2;                                                                                   \
@@ -895,14 +897,11 @@ extern "C" int jenga_bsattn_fwd(void* stream, const void* q, const void* k, cons
     hipError_t e;
     if (flags & JENGA_ATTN_PINGPONG) {
         const size_t smem_pp = PP_LDS_BYTES;
-        static bool attr_pp = false;
-        if (!attr_pp) {
-            (void)hipFuncSetAttribute((const void*)bsattn_pp_kernel<BF16>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      (int)smem_pp);
-            (void)hipFuncSetAttribute((const void*)bsattn_pp_kernel<FP16>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      (int)smem_pp);
-            attr_pp = true;
-        }
+        // (set on every call: cheap, and correct on whichever device / context is current)
+        (void)hipFuncSetAttribute((const void*)bsattn_pp_kernel<BF16>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)smem_pp);
+        (void)hipFuncSetAttribute((const void*)bsattn_pp_kernel<FP16>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)smem_pp);
         if (dtype == JENGA_BF16)
             hipLaunchKernelGGL(bsattn_pp_kernel<BF16>, dim3((unsigned)grid), dim3(512), smem_pp, (hipStream_t)stream, P);
         else
@@ -916,20 +915,12 @@ extern "C" int jenga_bsattn_fwd(void* stream, const void* q, const void* k, cons
     }
     const size_t smem = W4_LDS_BYTES;
     if (dtype == JENGA_BF16) {
-        static bool attr_done = false;
-        if (!attr_done) {
-            (void)hipFuncSetAttribute((const void*)bsattn_fwd_kernel<BF16>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      (int)smem);
-            attr_done = true;
-        }
+        (void)hipFuncSetAttribute((const void*)bsattn_fwd_kernel<BF16>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)smem);
         hipLaunchKernelGGL(bsattn_fwd_kernel<BF16>, dim3((unsigned)grid), dim3(256), smem, (hipStream_t)stream, P);
     } else {
-        static bool attr_done16 = false;
-        if (!attr_done16) {
-            (void)hipFuncSetAttribute((const void*)bsattn_fwd_kernel<FP16>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      (int)smem);
-            attr_done16 = true;
-        }
+        (void)hipFuncSetAttribute((const void*)bsattn_fwd_kernel<FP16>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)smem);
         hipLaunchKernelGGL(bsattn_fwd_kernel<FP16>, dim3((unsigned)grid), dim3(256), smem, (hipStream_t)stream, P);
     }
     e = hipGetLastError();

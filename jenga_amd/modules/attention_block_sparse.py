@@ -151,14 +151,21 @@ def block_sparse_attention_i2v(query, key, value, top_k, block_size_M=128, block
 def block_sparse_attention_wan(query, key, value, top_k, block_size_M=128, block_size_N=128, cu_seqlens_q=None,
                                cu_seqlens_kv=None, max_seqlen_q=None, max_seqlen_kv=None, text_blocks=0,
                                text_amp=0.0, block_neighbor_list=None, shape_xfuse=False, p_remain_rates=0.9,
-                               first_frame_blocks=0, return_mask=False):
+                               first_frame_blocks=0, return_mask=False, kv_lens=None):
     """Wan flavour: always pads, computes in bf16 whatever the input dtype, seqlen = unpadded S, dense first-frame
-    rule, returns the input dtype."""
+    rule, returns the input dtype.  kv_lens (int32 [B] tensor, jenga_amd extension): keys at or beyond it are masked
+    -- what WanSelfAttention's dense branch gets from flash_attention(k_lens=seq_lens) (wan/modules/model_mul.py:153-159)
+    when teacache_forward padded the tokens beyond the real sequence; the reference's sparse branch has no such mask."""
     out_dtype = query.dtype
     B, S, H, D = query.shape
     pad = (BLOCK - S % BLOCK) % BLOCK
     q, k, v = (_pad_seq(_unit_inner(t.to(torch.bfloat16)), pad) for t in (query, key, value))
-    seqlens = torch.full((B,), S, dtype=torch.int32, device=query.device)
+    if kv_lens is not None:
+        seqlens = torch.clamp(torch.as_tensor(kv_lens).to(device=query.device, dtype=torch.int32).reshape(-1), max=S)
+        if seqlens.numel() != B:
+            raise ValueError("kv_lens must have one entry per batch element")
+    else:
+        seqlens = torch.full((B,), S, dtype=torch.int32, device=query.device)
     res = _combined(q, k, v, top_k, seqlens, text_blocks, text_amp, p_remain_rates, block_neighbor_list,
                     shape_xfuse, first_frame_blocks=first_frame_blocks, context_size=S, return_mask=return_mask)
     if return_mask:

@@ -102,8 +102,10 @@ class WanSelfAttention(nn.Module):
         else:
             top_k = math.ceil(int(num_blocks * (1 - sa_drop_rate)))
             ffb = math.ceil(num_blocks // 21)
+        dense = sa_drop_rate <= 0.25
         out = _op.block_sparse_attention_wan(qr, kr, v.to(torch.bfloat16), top_k, text_blocks=0,
-                                             block_neighbor_list=block_neighbor_list if sa_drop_rate > 0.25 else None,
-                                             p_remain_rates=p_remain_rates if sa_drop_rate > 0.25 else 2.0,
-                                             first_frame_blocks=ffb)
+                                             block_neighbor_list=None if dense else block_neighbor_list,
+                                             p_remain_rates=2.0 if dense else p_remain_rates,
+                                             first_frame_blocks=ffb,
+                                             kv_lens=seq_lens if dense else None)   # k_lens mask: dense branch only
         return self.o(out.to(x.dtype).flatten(2))

@@ -29,6 +29,37 @@ def pooled_scores(q_img, k, dtype, block=128):
     return rnd(s * np.float32(D ** -0.5))                                       # `* head_dim**-0.5` in dtype
 
 
+def scores_from_pooled(qp, kp, dtype):
+    """Pooled block means qp [B,H,nq,D], kp [B,H,nk,D] (dtype values) -> scores in dtype: the bmm output rounded to
+    dtype, then `* head_dim**-0.5` in dtype (:221-232).  Lets a test feed the HIP pooling kernel's own output, which
+    separates pooling-order noise from selection bugs."""
+    rnd = rounder(dtype)
+    s = rnd(np.einsum("bhqd,bhkd->bhqk", qp.astype(np.float32), kp.astype(np.float32), dtype=np.float32))
+    return rnd(s * np.float32(qp.shape[-1] ** -0.5))
+
+
+def build_block_mask_from_pooled(qp, kp, top_k, text_start_block, num_blocks, p, text_blocks, neighbors, dtype,
+                                 first_frame_blocks=0):
+    """build_block_mask with the pooling step (:216-217) already done."""
+    B, H, nq, _ = qp.shape
+    scores = scores_from_pooled(qp, kp, dtype)
+    probs = row_probs(scores[..., :text_start_block], dtype)
+    order, n = blocks_needed(probs, top_k, p, dtype)
+    mask = np.zeros((B, H, nq, num_blocks), bool)
+    rank = np.arange(order.shape[-1])
+    sel = rank[None, None, None, :] < n[..., None]
+    bi, hi, qi, ri = np.nonzero(sel)
+    mask[bi, hi, qi, order[bi, hi, qi, ri]] = True
+    if neighbors is not None:
+        nbm = np.asarray(neighbors, bool)[:nq, :text_start_block]
+        mask[:, :, :nbm.shape[0], :nbm.shape[1]] |= nbm[None, None]
+    if first_frame_blocks > 0:
+        mask[:, :, :first_frame_blocks, :first_frame_blocks] = True
+    if text_blocks > 0 and text_start_block is not None:
+        mask[:, :, :, text_start_block:min(text_start_block + text_blocks, num_blocks)] = True
+    return mask, n
+
+
 def row_probs(scores_img, dtype):
     """softmax over the image columns, result rounded to dtype (:238)."""
     rnd = rounder(dtype)

@@ -709,3 +709,26 @@ def test_padded_flavours_randomized_vs_oracle(dev, seed):
     assert got.shape == ref.shape and np.isfinite(got).all()
     err = np.abs(got - ref)
     assert (err.max(axis=-1) > 3e-2).mean() <= 0.0, (wan, H, nimg, S, top_k, p, err.max())
+
+
+def test_wan_dense_branch_masks_keys_beyond_seq_lens(dev):
+    """WanSelfAttention's dense branch (sa_drop_rate <= 0.25) is flash_attention(..., k_lens=seq_lens)
+    (wan/modules/model_mul.py:153-159): when teacache_forward padded the tokens, keys at or beyond the real length must
+    not be attended.  Valid rows must equal dense attention over the first seq_len keys only."""
+    from jenga_amd.modules.attention_block_sparse import block_sparse_attention_wan
+    from oracle import attention as oa
+    gen = torch.Generator().manual_seed(3)
+    S, L, H = 640, 601, 2                                   # 39 padding tokens at the tail
+    q = torch.randn(1, S, H, 128, generator=gen).to(torch.bfloat16)
+    k = torch.randn(1, S, H, 128, generator=gen).to(torch.bfloat16)
+    v = torch.randn(1, S, H, 128, generator=gen).to(torch.bfloat16)
+    k[:, L:] = k[:, :S - L] * 3.0                           # make the padding keys attractive: a missing mask shows
+    out = block_sparse_attention_wan(q.to(dev), k.to(dev), v.to(dev), top_k=5, text_blocks=0, p_remain_rates=2.0,
+                                     shape_xfuse=True, kv_lens=torch.tensor([L]))
+    qn, kn, vn = (to_np(t.transpose(1, 2)) for t in (q, k, v))
+    ref = oa.sparse_rows(qn, kn, vn, [L], np.ones((1, H, 5, 5), bool), 128 ** -0.5, "bfloat16", 0.0, 5)
+    got = out.transpose(1, 2).float().cpu().numpy()
+    assert np.abs(got[:, :, :L] - ref[:, :, :L]).max() <= 2e-2
+    unmasked = block_sparse_attention_wan(q.to(dev), k.to(dev), v.to(dev), top_k=5, text_blocks=0, p_remain_rates=2.0,
+                                          shape_xfuse=True).transpose(1, 2).float().cpu().numpy()
+    assert np.abs(unmasked[:, :, :L] - ref[:, :, :L]).max() > 0.1      # the test input does discriminate

@@ -1,0 +1,210 @@
+"""GPU (-m gpu): block selection beyond the golden cases of test_gpu_parity.py.
+
+* every golden case's Hamming distance to the reference mask is PRINTED and written to
+  gpurun_out/parity_records/select_hamming.json ("bounded, never reported");
+* at the HunyuanVideo 720p size (900 blocks) and at the Wan2.1-14B 720p size (591 blocks, first-frame rule, padded
+  tail) the HIP kept lists are compared with the oracle's selection computed FROM THE HIP POOLED TENSORS, which
+  separates pooling-order noise from selection bugs;
+* the kept-count rule `#(cumsum <= p) + 1` follows torch's CPU cumsum semantics on a 16-bit tensor (sequential fp32
+  accumulation, every partial rounded to the dtype) -- that is what the reference goldens were generated with.  A
+  16-bit cumsum ON A GPU may accumulate differently; the last test measures, on flat rows, how far the count of this
+  library is from a device-side torch.cumsum and records it."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import inputs
+from helpers import tie_tolerant_mask_equal, to_np
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    return torch.device("cuda:0")
+
+
+def _record(name, obj):
+    d = os.path.join(ROOT, "gpurun_out", "parity_records")
+    os.makedirs(d, exist_ok=True)
+    path = os.path.join(d, name)
+    data = json.load(open(path)) if os.path.exists(path) else {}
+    data.update(obj)
+    json.dump(data, open(path, "w"), indent=1, sort_keys=True)
+    print("PARITY-RECORD", name, json.dumps(obj))
+
+
+@pytest.mark.parametrize("index", range(len(inputs.SELECT_SPECS)))
+def test_golden_cases_hamming_is_reported(golden_dir, dev, index):
+    from jenga_amd.modules.attention_block_sparse import build_block_index
+    name, flav, dt, H, nb_img, tb, top_k, p, temp, ffb = inputs.SELECT_SPECS[index]
+    g = np.load(os.path.join(golden_dir, "select_cases.npz"))
+    q, k = inputs.select_inputs(index)
+    nbm = g["neighbors"]
+    qf = torch.cat([q, torch.zeros(1, H, tb * 128, 128, dtype=q.dtype)], dim=2) if tb else q
+    mask, idx, cnt = build_block_index(qf.transpose(1, 2).to(dev), k.transpose(1, 2).to(dev), top_k, tb, p,
+                                       torch.from_numpy(nbm), first_frame_blocks=ffb, want_mask=True)
+    mask = mask.bool().cpu().numpy()
+    ref = g[f"{name}_mask"]
+    forced = np.zeros_like(ref)
+    forced[..., :nb_img] |= nbm[None, None, :nb_img, :nb_img]
+    if ffb:
+        forced[:, :, :ffb, :ffb] = True
+    ok, _ = tie_tolerant_mask_equal(mask, ref, g[f"{name}_probs_f32"][None], g[f"{name}_n"][None], nb_img, forced)
+    ham = int((mask != ref).sum())
+    rows_diff = int((mask != ref).any(-1).sum())
+    _record("select_hamming.json", {name: dict(hamming=ham, of=int(ref.size), rows_differing=rows_diff,
+                                               rows=int(ref.shape[1] * ref.shape[2]), tie_exact=bool(ok))})
+    # round 2: every golden case is tie-exact (the Hamming distance above is the reference's unstable sort picking
+    # other members of a group of EQUAL probabilities -- flat rows in bf16 have many); no fallback bound any more
+    assert ok, f"{name}: mask is not legal under the tie freedom (hamming {ham}/{ref.size})"
+
+
+def _compare_with_oracle_from_pooled(dev, q, k, nimg, tb, top_k, p, nbm, ffb, sample_rows, tag):
+    """q,k [1,S,H,128] on the device (already padded to blocks).  HIP lists vs oracle selection from the HIP pooled
+    tensors, on `sample_rows` query blocks of every head."""
+    from jenga_amd import _capi
+    from oracle import attention as oa
+    nb = nimg + tb
+    H = q.shape[2]
+    qpool = _capi.block_pool(q, nimg)
+    kpool = _capi.block_pool(k, nb)
+    _, idx, cnt = _capi.block_select(qpool, kpool, nbm, nimg, tb, top_k, p, first_frame_blocks=ffb)
+    torch.cuda.synchronize()
+    rows = sorted(set(sample_rows))
+    qp = to_np(qpool[:, :, rows])
+    kp = to_np(kpool)
+    nb_np = None if nbm is None else nbm.cpu().numpy()[rows]
+    # the oracle works on whole rows of the neighbour matrix / first-frame rule: evaluate row by row
+    ham_tot, size_tot, n_diff = 0, 0, 0
+    idx_c, cnt_c = idx.cpu().numpy(), cnt.cpu().numpy()
+    for i, m in enumerate(rows):
+        neigh = None if nb_np is None else nb_np[i:i + 1]
+        ref, n_ref = oa.build_block_mask_from_pooled(qp[:, :, i:i + 1], kp, top_k, nimg, nb, p, tb, neigh, "bfloat16")
+        if ffb and m < ffb:
+            ref[..., :ffb] = True
+        for h in range(H):
+            got = np.zeros(nb, bool)
+            got[idx_c[0, h, m, :cnt_c[0, h, m]]] = True
+            d = int((got != ref[0, h, 0]).sum())
+            ham_tot += d
+            n_diff += d > 0
+            size_tot += nb
+    _record("select_full_size.json", {tag: dict(hamming=ham_tot, of=size_tot, rows_differing=int(n_diff),
+                                                rows=len(rows) * H)})
+    # given identical pooled inputs only exp / division rounding can differ (<= 1 ulp of a probability): a handful
+    # of boundary blocks at most
+    assert ham_tot <= max(2, size_tot // 2000), (ham_tot, size_tot)
+    return idx, cnt
+
+
+def test_hunyuan_720p_lists_vs_oracle_from_hip_pooled(dev):
+    from jenga_amd import gilbert as G
+    t, h, w = 32, 45, 80
+    nimg, tb, H = t * h * w // 128, 2, 2
+    nb = nimg + tb
+    g = torch.Generator(device=dev).manual_seed(5)
+    cent = torch.randn(1, nb, 1, H, 128, generator=g, device=dev) * 0.7
+    q = (torch.randn(1, nb, 128, H, 128, generator=g, device=dev) + cent[:, torch.randint(0, nimg, (nb,), device=dev)])
+    k = torch.randn(1, nb, 128, H, 128, generator=g, device=dev) + cent
+    q = q.to(torch.bfloat16).view(1, nb * 128, H, 128)
+    k = k.to(torch.bfloat16).view(1, nb * 128, H, 128)
+    nbm = G.gilbert_block_neighbor_mapping(t, h, w, as_tensor=True)
+    rows = list(range(0, 900, 37)) + [1, 449, 898, 899]
+    for top_k, p, tag in ((int(0.3 * nimg), 0.3, "hy720p_r0.7_p0.3"), (int((1 - 0.8) * nimg), 0.3, "hy720p_r0.8_p0.3"),
+                          (10, 0.9, "hy720p_topk10_p0.9")):
+        _compare_with_oracle_from_pooled(dev, q, k, nimg, tb, top_k, p, nbm, 0, rows, tag)
+
+
+def test_wan14b_720p_full_shape_properties(dev):
+    """BASELINE.json configs[3] at full shape (two of the 40 heads): 21x45x80 = 75 600 tokens, padded to 591 blocks,
+    first_frame_blocks = 591 // 21 = 28, text_blocks = 0, p = 0.8, drop rates 0.7: (a) V == 1 -> every returned row
+    is 1 (softmax weights sum to one through the padded tail, the first-frame rule and the kv-length mask);
+    (b) list invariants incl. the dense first-frame corner; (c) lists vs the oracle from the HIP pooled tensors;
+    (d) sampled rows vs the oracle, incl. the last (padded) query block."""
+    from jenga_amd import _capi, gilbert as G
+    from jenga_amd.modules.attention_block_sparse import block_sparse_attention_wan
+    from oracle import attention as oa
+    t, h, w = 21, 45, 80
+    L, H = t * h * w, 2
+    nb = (L + 127) // 128
+    assert nb == 591
+    ffb = nb // 21
+    g = torch.Generator(device=dev).manual_seed(14)
+    Lp = nb * 128
+    cent = torch.randn(1, nb, 1, H, 128, generator=g, device=dev) * 0.8
+    q = (torch.randn(1, nb, 128, H, 128, generator=g, device=dev) + cent[:, torch.randint(0, nb, (nb,), device=dev)])
+    k = torch.randn(1, nb, 128, H, 128, generator=g, device=dev) + cent
+    q = q.view(1, Lp, H, 128)[:, :L].to(torch.bfloat16).contiguous()
+    k = k.view(1, Lp, H, 128)[:, :L].to(torch.bfloat16).contiguous()
+    nbm = G.sliced_gilbert_block_neighbor_mapping(t, h, w, as_tensor=True)
+    top_k = int(np.ceil(int(nb * (1 - 0.7))))
+    ones = torch.ones(1, L, H, 128, device=dev, dtype=torch.bfloat16)
+    o1, mask = block_sparse_attention_wan(q, k, ones, top_k, text_blocks=0, block_neighbor_list=nbm, p_remain_rates=0.8,
+                                          first_frame_blocks=ffb, shape_xfuse=True, return_mask=True)
+    assert o1.shape == (1, L, H, 128)
+    assert torch.all((o1.float() - 1).abs() <= 2 ** -7), (o1.float() - 1).abs().max().item()
+    m = mask.bool()
+    assert m[0, :, :ffb, :ffb].all()                                  # first-frame rows see the first-frame columns
+    assert (m & nbm.to(dev)[None, None]).sum() == nbm.sum() * H       # neighbours kept
+    assert int(m.sum(-1).min()) >= top_k
+    # (c) selection from the HIP pooled tensors (the op pads with zeros exactly like this)
+    pad = Lp - L
+    qp_ = torch.nn.functional.pad(q, [0, 0, 0, 0, 0, pad])
+    kp_ = torch.nn.functional.pad(k, [0, 0, 0, 0, 0, pad])
+    rows = list(range(0, nb, 29)) + [0, 27, 28, nb - 1]
+    _compare_with_oracle_from_pooled(dev, qp_, kp_, nb, 0, top_k, 0.8, nbm, ffb, rows, "wan14b_720p_r0.7_p0.8")
+    # (d) sampled rows of the real op vs the oracle on their kept blocks
+    v = torch.randn(1, L, H, 128, generator=g, device=dev).to(torch.bfloat16)
+    o = block_sparse_attention_wan(q, k, v, top_k, text_blocks=0, block_neighbor_list=nbm, p_remain_rates=0.8,
+                                   first_frame_blocks=ffb, shape_xfuse=True)
+    vp_ = torch.nn.functional.pad(v, [0, 0, 0, 0, 0, pad])
+    mc = m.cpu().numpy()
+    for (hh, mq) in [(0, 0), (1, 300), (0, nb - 1)]:
+        blocks = np.nonzero(mc[0, hh, mq])[0].tolist()
+        n = len(blocks)
+        kk = torch.cat([kp_[0, b * 128:(b + 1) * 128, hh] for b in blocks]).float().cpu().numpy()[None, None]
+        vv = torch.cat([vp_[0, b * 128:(b + 1) * 128, hh] for b in blocks]).float().cpu().numpy()[None, None]
+        qq = qp_[0, mq * 128:(mq + 1) * 128, hh].float().cpu().numpy()[None, None]
+        # kv-length mask: the last kept block may be the padded one -> compacted seqlen
+        last_is_tail = blocks[-1] == nb - 1
+        seq_c = n * 128 - (pad if last_is_tail else 0)
+        ref = oa.sparse_rows(qq, kk, vv, [seq_c if mq != nb - 1 else seq_c], np.ones((1, 1, 1, n), bool), 128 ** -0.5,
+                             "bfloat16", 0.0, n)
+        rows_valid = 128 - pad if mq == nb - 1 else 128
+        got = o[0, mq * 128:mq * 128 + rows_valid, hh].float().cpu().numpy()
+        # (query rows of the compacted problem are all < seq_c except in the tail block, where the op slices them off)
+        assert np.abs(got - ref[0, 0, :rows_valid]).max() <= 2e-2, (hh, mq, np.abs(got - ref[0, 0, :rows_valid]).max())
+
+
+def test_kept_count_rule_vs_device_cumsum_is_measured(dev):
+    """Flat rows (every probability ~1/900, far below half a bf16 ulp of the running sum): the library follows torch's
+    CPU semantics (the reference goldens); a bf16 torch.cumsum on the DEVICE is evaluated next to it and the difference
+    of the kept counts is recorded, not asserted (the reference's CUDA behaviour is not reproducible here)."""
+    from jenga_amd import _capi
+    from oracle import attention as oa
+    H, nimg, tb = 2, 900, 2
+    nb = nimg + tb
+    g = torch.Generator(device=dev).manual_seed(9)
+    qpool = (torch.randn(1, H, nimg, 128, generator=g, device=dev) * 0.12).to(torch.bfloat16)
+    kpool = (torch.randn(1, H, nb, 128, generator=g, device=dev) * 0.12).to(torch.bfloat16)
+    out = {}
+    for p in (0.3, 0.5, 0.9):
+        _, idx, cnt = _capi.block_select(qpool, kpool, None, nimg, tb, 0, p)
+        n_hip = (cnt - tb).cpu().numpy()                                  # image blocks kept (top_k = 0, no neighbours)
+        scores = oa.scores_from_pooled(to_np(qpool), to_np(kpool), "bfloat16")
+        probs = oa.row_probs(scores[..., :nimg], "bfloat16")
+        _, n_cpu = oa.blocks_needed(probs, 0, p, "bfloat16")
+        assert np.abs(n_hip - np.minimum(n_cpu, nimg)).max() <= 1, "CPU-torch cumsum semantics are the contract"
+        pr = torch.from_numpy(probs).to(dev).to(torch.bfloat16)
+        sp, _ = torch.sort(pr, dim=-1, descending=True)
+        n_dev = ((torch.cumsum(sp, dim=-1) <= p).sum(-1) + 1).clamp(max=nimg).cpu().numpy()
+        d = n_dev.astype(np.int64) - n_hip
+        out[f"p={p}"] = dict(mean_kept_library=float(n_hip.mean()), mean_kept_device_cumsum=float(n_dev.mean()),
+                             max_abs_diff=int(np.abs(d).max()), mean_diff=float(d.mean()))
+    _record("cumsum_semantics.json", out)

@@ -172,3 +172,32 @@ def test_wan_block_glue_against_reference_block(golden_dir):
     x2 = ow.gate_residual(x1, to_np(from_bits(g["later_y3"], "bfloat16")))
     h2 = ow.ln_modulate(x2, None, None, em[3], em[4], 1e-6, "bfloat16")
     assert_ulp_close(h2, to_np(from_bits(g["later_h2"], "bfloat16")), "bfloat16", max_frac=2e-3)
+
+
+def test_eager_torch_restatement_matches_the_numpy_oracle():
+    """oracle/eager_torch.py (what bench.py times as the reference's PyTorch-CPU path) against the numpy oracle, which
+    is pinned to the reference goldens above: identical block masks (bf16, peaky scores: no ties) and, in fp32, the
+    same attention as the numpy restatement of the Triton kernel up to its bf16 rounding points."""
+    from oracle import eager_torch as et
+    gen = torch.Generator().manual_seed(31)
+    H, nimg, tb = 2, 12, 2
+    nb = nimg + tb
+    q, k = inputs.peaky_qk(gen, 1, H, nimg, nb, 128, 1.2)
+    qf = torch.cat([q, torch.randn(1, H, tb * 128, 128, generator=gen)], dim=2)
+    v = torch.randn(1, H, nb * 128, 128, generator=gen)
+    nbm = og.gilbert_block_neighbor_mapping(2, 12, 64, 128)
+    qb, kb = q.to(torch.bfloat16), k.to(torch.bfloat16)
+    mask_t = et.build_block_mask(qb, kb, 3, nimg, nb, 0.3, tb, neighbors=nbm)
+    mask_n = oa.build_block_mask(to_np(qb), to_np(kb), 3, nimg, nb, 0.3, tb, nbm, "bfloat16")
+    assert np.array_equal(mask_t.numpy(), mask_n)
+    seqlen = nimg * 128 + 50
+    o = et.masked_attention(qf, k, v, mask_t, seqlen, nimg, q_chunk_blocks=5)
+    ref = oa.sparse_rows(to_np(qf[:, :, :nimg * 128]), to_np(k), to_np(v), [seqlen], mask_n, 128 ** -0.5, "bfloat16",
+                         0.0, nimg)
+    err = np.abs(o[:, :, :nimg * 128].numpy() - ref)
+    assert err.max() < 3e-2 and err.mean() < 2e-3, (err.max(), err.mean())      # fp32 SDPA vs bf16 rounding points
+    reft = oa.text_rows(to_np(qf[:, :, nimg * 128:]), to_np(k), to_np(v), 128 ** -0.5, "bfloat16")
+    assert np.abs(o[:, :, nimg * 128:].numpy() - reft).max() < 3e-2
+    # the time-capped form used by the bench returns the fraction of rows it got through
+    o2, frac = et.masked_attention(qf, k, v, mask_t, seqlen, nimg, q_chunk_blocks=5, budget_s=1e9, clock=lambda: 0.0)
+    assert frac == 1.0 and torch.equal(o2, o)
