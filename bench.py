@@ -32,6 +32,20 @@ MFMA_PEAK_TFLOPS = 2500.0  # dense bf16, /opt/skills/guides/MI355X_MICROARCH.md
 FLOPS_PER_PAIR = 4 * 128 ** 3  # one 128x128 query block against one 128-key block, head_dim 128: QK^T + PV
 
 
+PRESETS = {   # scripts/hyvideo_jenga_{base,turbo,flash,3stage}.sh and scripts/hyvideo_multigpu_jenga_*.sh
+    # base: BASELINE.json configs[1] quotes Jenga-Base at sa-drop 0.7/0.8 (the reference's README table); the shipped
+    # single-GPU script uses 0.75/0.85 (less attention work) = "base-mgpu" here (the 8-GPU script has the same rates)
+    "base": dict(res=[1.0, 1.0], steps=[0.5, 1.0], rates=[0.7, 0.8], shifts=[7, 7], p=0.3),
+    "turbo": dict(res=[0.75, 1.0], steps=[0.5, 1.0], rates=[0.7, 0.8], shifts=[7, 9], p=0.3),
+    "flash": dict(res=[0.75, 1.0], steps=[0.5, 1.0], rates=[0.8, 0.95], shifts=[7, 9], p=0.5),
+    "3stage": dict(res=[0.5, 0.75, 1.0], steps=[0.3, 0.5, 1.0], rates=[0.75, 0.85, 0.85], shifts=[7, 9, 11], p=0.3),
+    "base-mgpu": dict(res=[1.0, 1.0], steps=[0.5, 1.0], rates=[0.75, 0.85], shifts=[7, 7], p=0.3),
+    "turbo-mgpu": dict(res=[0.75, 1.0], steps=[0.5, 1.0], rates=[0.75, 0.85], shifts=[7, 9], p=0.3),
+    "flash-mgpu": dict(res=[0.75, 1.0], steps=[0.5, 1.0], rates=[0.8, 0.95], shifts=[7, 9], p=0.5),
+    "3stage-mgpu": dict(res=[0.5, 0.75, 1.0], steps=[0.3, 0.5, 1.0], rates=[0.75, 0.85, 0.85], shifts=[7, 9, 11], p=0.3),
+}
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -40,9 +54,15 @@ def parse():
     ap.add_argument("--rates", type=float, nargs="+", default=None,
                     help="sa-drop-rates per stage; default per preset (base: 0.7 0.8 = BASELINE.json configs[1]; "
                          "0.75 0.85 = the shipped scripts/hyvideo_jenga_base.sh)")
-    ap.add_argument("--preset", choices=["base", "turbo", "3stage"], default="base",
-                    help="scripts/hyvideo_jenga_{base,turbo,3stage}.sh: resolution / step / shift / drop-rate lists")
-    ap.add_argument("--p-remain", type=float, default=0.3)
+    ap.add_argument("--preset", choices=sorted(PRESETS), default="base",
+                    help="scripts/hyvideo[_multigpu]_jenga_{base,turbo,flash,3stage}.sh: resolution / step / shift / "
+                         "drop-rate / p-remain lists (the *-mgpu presets carry the rate sets of the 8-GPU scripts)")
+    ap.add_argument("--p-remain", type=float, default=None, help="default: the preset's")
+    ap.add_argument("--peaky", type=float, default=0.0, metavar="GAIN",
+                    help="> 0: scale the Q/K RMSNorm weights by GAIN (block scores x GAIN^2).  Random weights give "
+                         "nearly flat pooled scores, where the p-remain rule keeps ~p of all blocks; a trained model's "
+                         "block softmax is peaked and top_k decides (SURVEY.md 8(d) asks for both regimes). "
+                         "The realised kept block pairs per launch are in the JSON either way")
     ap.add_argument("--latent", type=int, nargs=3, default=[32, 90, 160], help="latent T H W (720x1280x125f)")
     ap.add_argument("--depth", type=int, nargs=2, default=None, help="override (double, single) block counts (debug only)")
     ap.add_argument("--valid-text", type=int, default=64)
@@ -57,13 +77,6 @@ def parse():
     return ap.parse_args()
 
 
-PRESETS = {   # scripts/hyvideo_jenga_base.sh:19-25, hyvideo_jenga_turbo.sh, hyvideo_jenga_3stage.sh
-    # base: BASELINE.json configs[1] quotes Jenga-Base at sa-drop 0.7/0.8 (the reference's README table); the shipped
-    # script uses 0.75/0.85 (less attention work) -- ask for it with --rates 0.75 0.85
-    "base": dict(res=[1.0, 1.0], steps=[0.5, 1.0], rates=[0.7, 0.8], shifts=[7, 7]),
-    "turbo": dict(res=[0.75, 1.0], steps=[0.5, 1.0], rates=[0.7, 0.8], shifts=[7, 9]),
-    "3stage": dict(res=[0.5, 0.75, 1.0], steps=[0.3, 0.5, 1.0], rates=[0.75, 0.85, 0.85], shifts=[7, 9, 11]),
-}
 
 
 def stage_of(i, split):
@@ -221,6 +234,13 @@ def main():
     if a.rates:
         preset["rates"] = list(a.rates) + [a.rates[-1]] * (len(preset["res"]) - len(a.rates))
     a.rates = preset["rates"]
+    if a.p_remain is None:
+        a.p_remain = preset["p"]
+    if a.peaky > 0:
+        with torch.no_grad():
+            for name, p_ in model.named_parameters():
+                if name.endswith(("q_norm.weight", "k_norm.weight")):
+                    p_.mul_(a.peaky)
     T, Hh, W = a.latent
     shapes, split = prores.stage_plan((T, Hh, W), 50, preset["res"], preset["steps"])
     g = torch.Generator(device=dev).manual_seed(42)
@@ -336,7 +356,7 @@ def main():
     ps = prof.summary()
     traffic = None
     try:   # HBM-side bytes per launch from the committed PMC passes (profiles/), scaled by this run's kept pairs
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_bsattn_final.json")))
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_bsattn_lp.json")))
         traffic = int(pmc["derived"]["traffic_bytes_per_kept_pair"] * ps["pairs"] / max(ps["launches"], 1))
     except Exception:
         pass
@@ -355,6 +375,7 @@ def main():
                    "scheduler_shift_list": preset["shifts"],
                    "stage_tokens": [(sh[0] * (sh[1] // 2) * (sh[2] // 2)) for sh in shapes],
                    "sa_drop_rates": a.rates, "p_remain_rates": a.p_remain, "valid_text_tokens": a.valid_text,
+                   "qk_norm_gain": a.peaky if a.peaky > 0 else 1.0,
                    "schedule": "full 50-step loop" if not sampled else
                    f"sampled steps {plan}; sec/video = sum over (stage, computed|skipped) classes of "
                    f"count x mean step time, counts {dict((f'{k[0]}{k[1]}', n) for k, n in counts.items())}",
@@ -364,10 +385,10 @@ def main():
                    "parallelism": (f"rank 0 of a simulated ulysses{sim} job on ONE GPU, exchanges replaced by local copies"
                                    if sim > 1 else "single GPU" if world == 1 else f"ulysses{world} (RCCL all-to-all)"),
                    "weights": "random init N(0,0.02), seed 0", "finite_output": finite},
-        "roofline": {"kernel": "jenga::bsattn_fwd_kernel<bf16>", "bound": "mfma", "achieved": round(ach, 1),
+        "roofline": {"kernel": "jenga::bsattn_lp_kernel<bf16>" if (_capi.ATTN_DEFAULT_FLAGS & 8) else "jenga::bsattn_fwd_kernel<bf16>", "bound": "mfma", "achieved": round(ach, 1),
                      "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_PEAK_TFLOPS, 4),
                      "traffic": traffic,
-                     "traffic_source": "profiles/r01_pmc_bsattn_final.json: (2*FETCH_SIZE + WRITE_SIZE) per kept block pair "
+                     "traffic_source": "profiles/r02_pmc_bsattn_lp.json: (2*FETCH_SIZE + WRITE_SIZE) per kept block pair "
                                        "from separate rocprofv3 --pmc passes, x this run's pairs per launch",
                      "launches": ps["launches"],
                      "avg_launch_ms": round(ps["total_ms"] / max(ps["launches"], 1), 3),

@@ -23,6 +23,7 @@ the large permutations.  No reference source is copied.  What is called:
   hyvideo/modules/norm_layers.py    RMSNorm
 """
 import argparse
+import math
 import contextlib
 import hashlib
 import importlib.util
@@ -699,6 +700,41 @@ def gen_scheduler():
         out[f"renoise_{int(shift)}"] = sch.add_noise_to_step(lat, noise, sch.timesteps[26]).prev_sample.numpy()
         out[f"step_{int(shift)}"] = sch.step(npred, t, lat, return_dict=False)[0].numpy()
     np.savez_compressed(os.path.join(OUT, "scheduler_cases.npz"), **out)
+
+    # ---- the stage switch, composed exactly as pipeline_hunyuan_video_prores.py:724-739 orders the reference
+    #      scheduler's own calls (re-shift + set_timesteps, _step_index = i, predict_x0_from_xt at timesteps[i],
+    #      trilinear interpolate to the next stage's latent size, add_noise_to_step at timesteps[i+1]).
+    #      The pipeline class itself needs diffusers; only its call ORDER is restated here, every call is the reference's.
+    sw = {}
+    num_steps, res_rates, step_rates, shifts = 50, [0.75, 1.0], [0.5, 1.0], [7.0, 9.0]
+    T, height, width = 3, 128, 192                                                     # pixels
+    split = [int(num_steps * r) for r in step_rates]                                   # :422
+    step_shapes = [[T, int(height * r), int(width * r)] for r in res_rates]            # :423-424
+    lat_shapes = [[sh[0], sh[1] // 16 * 2, sh[2] // 16 * 2] for sh in step_shapes]     # :574 / :705
+    tok_sizes = [[sh[0], sh[1] // 16, sh[2] // 16] for sh in step_shapes]              # :576 / :709
+    token_diff = (tok_sizes[0][1] * tok_sizes[0][2]) / (tok_sizes[-1][1] * tok_sizes[-1][2])   # :577
+    sw["text_amp_stage0"] = np.float64(-1 * math.log(math.sqrt(token_diff), 2) * 1.0)         # :594 (scale_txt_amp 1)
+    sw["text_amp_after_switch"] = np.float64(0.0)                                             # :755
+    sw["split"], sw["lat_shapes"], sw["tok_sizes"] = np.array(split), np.array(lat_shapes), np.array(tok_sizes)
+    g2 = torch.Generator().manual_seed(11)
+    lat0 = torch.randn(1, 4, *lat_shapes[0], generator=g2).to(torch.bfloat16)
+    npred0 = torch.randn(1, 4, *lat_shapes[0], generator=g2).to(torch.bfloat16)
+    noise1 = torch.randn(1, 4, *lat_shapes[1], generator=g2).to(torch.bfloat16)
+    sw["lat"], sw["npred"], sw["noise"] = (t.float().numpy() for t in (lat0, npred0, noise1))
+    i = split[0]
+    sch = m.FlowMatchDiscreteScheduler(shift=shifts[0], reverse=True, solver="euler")
+    sch.set_timesteps(num_steps)
+    sch.config.shift = shifts[1]                                                       # :726
+    sch.set_timesteps(num_steps)                                                       # :727
+    sch._step_index = i                                                                # :728
+    timesteps = sch.timesteps
+    x0 = sch.predict_x0_from_xt(npred0, timesteps[i], lat0, return_dict=False)[0]      # :731-733
+    x0 = torch.nn.functional.interpolate(x0, size=lat_shapes[1], mode="trilinear")     # :737
+    out_lat = sch.add_noise_to_step(x0, noise1, timesteps[i + 1]).prev_sample          # :739
+    sw["switched"] = out_lat.numpy()
+    sw["shifts"] = np.array(shifts)
+    sw["sigmas_after"] = sch.sigmas.numpy()
+    np.savez_compressed(os.path.join(OUT, "stage_switch_case.npz"), **sw)
 
 
 if __name__ == "__main__":

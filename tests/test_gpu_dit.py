@@ -371,3 +371,19 @@ def test_i2v_single_block_vs_reference_block(dev):
     err = np.abs(got - ref)
     bound = 2 * np.exp2(np.floor(np.log2(np.maximum(np.abs(ref), 1e-3))) - 10) + 1.2e-2
     assert (err <= bound).all() and err.mean() <= 1.5e-3, (err.max(), err.mean())
+
+
+def test_stage_switch_on_device_vs_reference_composition(golden_dir, dev):
+    """Row f-1 on the GPU: prores.switch_stage with device tensors against the fixture generated from the reference
+    scheduler (tests/golden/stage_switch_case.npz); fp32 elementwise math + trilinear interpolation: 1e-6."""
+    import numpy as np
+    from jenga_amd import prores
+    g = np.load(os.path.join(golden_dir, "stage_switch_case.npz"))
+    shifts = g["shifts"].tolist()
+    lat, npred, noise = (torch.from_numpy(g[k]).to(torch.bfloat16).to(dev) for k in ("lat", "npred", "noise"))
+    shapes = [tuple(x) for x in g["lat_shapes"].tolist()]
+    s = prores.FlowMatchSchedule(50, shift=shifts[0])
+    out = prores.switch_stage(s, npred, int(g["split"][0]), lat, shapes[1], shifts[1], noise)
+    assert out.device.type == "cuda" and out.dtype == torch.float32
+    err = np.abs(out.cpu().numpy() - g["switched"])
+    assert err.max() <= 1e-6 * max(1.0, np.abs(g["switched"]).max()), err.max()

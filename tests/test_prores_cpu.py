@@ -42,3 +42,20 @@ def test_switch_stage_composes_the_three_steps():
     ref = prores.FlowMatchSchedule(50, shift=9.0)
     x0 = torch.nn.functional.interpolate(ref.predict_x0_from_xt(npred, 25, lat), size=[3, 6, 8], mode="trilinear")
     assert torch.equal(out, ref.add_noise_to_step(x0, noise, 26)) and s.shift == 9.0
+
+
+def test_switch_stage_matches_the_reference_composition(golden_dir):
+    """tests/golden/stage_switch_case.npz: the reference scheduler's own predict_x0_from_xt -> trilinear interpolate ->
+    add_noise_to_step after the re-shift, in the order pipeline_hunyuan_video_prores.py:724-739 calls them, plus the
+    per-stage quantities the switch swaps (latent shapes :423-424/:705, split steps :422, text_amp :577/:594/:755)."""
+    g = np.load(os.path.join(golden_dir, "stage_switch_case.npz"))
+    shifts = g["shifts"].tolist()
+    lat, npred, noise = (torch.from_numpy(g[k]).to(torch.bfloat16) for k in ("lat", "npred", "noise"))
+    lat_shapes = [tuple(x) for x in g["lat_shapes"].tolist()]
+    shapes, split = prores.stage_plan(lat_shapes[-1], 50, [0.75, 1.0], [0.5, 1.0])
+    assert shapes == lat_shapes and split == g["split"].tolist()
+    assert abs(prores.stage_text_amp(shapes[0], shapes[-1]) - float(g["text_amp_stage0"])) < 1e-12
+    s = prores.FlowMatchSchedule(50, shift=shifts[0])
+    out = prores.switch_stage(s, npred, split[0], lat, shapes[1], shifts[1], noise)
+    assert np.array_equal(s.sigmas.numpy(), g["sigmas_after"])
+    assert np.array_equal(out.numpy(), g["switched"])
