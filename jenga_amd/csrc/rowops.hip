@@ -116,55 +116,73 @@ __device__ __forceinline__ void norm_rope_row(float (&f)[8], const float (&wv)[8
 }
 
 template <typename T>
-__global__ void qk_norm_rope_pool_kernel(const uint16_t* __restrict__ xq, const uint16_t* __restrict__ xk,
+__global__ void __launch_bounds__(128) qk_norm_rope_pool_kernel(const uint16_t* __restrict__ xq, const uint16_t* __restrict__ xk,
                                          uint16_t* __restrict__ oq, uint16_t* __restrict__ ok,
                                          const uint16_t* __restrict__ wq, const uint16_t* __restrict__ wk,
                                          const float* __restrict__ cosT, const float* __restrict__ sinT,
                                          uint16_t* __restrict__ qpool, uint16_t* __restrict__ kpool, long long B,
                                          long long nblk, long long H, long long x_sb, long long x_ss, long long x_sh,
                                          long long o_sb, long long o_ss, long long o_sh, long long s_rope,
-                                         long long pool_block0, long long nq_pool, long long nk_pool, float eps) {
+                                         long long pool_block0, long long nq_pool, long long nk_pool, float eps,
+                                         int HG) {
+    // blockDim.x == 16 * HG: a workgroup owns HG heads of one 128-token block; the H / HG workgroups of a block sit
+    // on one XCD next to each other in launch order (they share the block's cos / sin rows through that L2)
     const int sub = threadIdx.x & 15;
-    const long long h = threadIdx.x >> 4;   // blockDim.x == 16 * H
+    const int ngrp = (int)(H / HG);
     float wqv[8], wkv[8];
     if (wq) unpack8<T>(*reinterpret_cast<const uint4*>(wq + sub * 8), wqv);
     if (wk) unpack8<T>(*reinterpret_cast<const uint4*>(wk + sub * 8), wkv);
-    for (long long wg = blockIdx.x; wg < B * nblk; wg += gridDim.x) {
+    for (long long id = blockIdx.x; id < ((B * nblk + 7) / 8) * 8 * ngrp; id += gridDim.x) {
+        // id = 8 * (ngrp * (blk / 8) + grp) + blk % 8  ->  the groups of a block share id % 8 (= the XCD)
+        const long long blk8 = id / (8 * ngrp), rem = id % (8 * ngrp);
+        const long long wg = blk8 * 8 + (rem & 7);
+        const long long h = (rem >> 3) * HG + (threadIdx.x >> 4);
+        if (wg >= B * nblk) continue;
         const long long j = wg % nblk, b = wg / nblk;
         float sq[8] = {0, 0, 0, 0, 0, 0, 0, 0}, sk[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        for (int g = 0; g < 16; ++g) {
-            float aq[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ak[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll 4
-            for (int i = 0; i < 8; ++i) {
-                const long long s_tok = j * 128 + g * 8 + i;
-                const long long xoff = b * x_sb + s_tok * x_ss + h * x_sh + sub * 8;
-                const long long ooff = b * o_sb + s_tok * o_ss + h * o_sh + sub * 8;
-                float fq[8], fk[8];
-                unpack8<T>(*reinterpret_cast<const uint4*>(xq + xoff), fq);
-                unpack8<T>(*reinterpret_cast<const uint4*>(xk + xoff), fk);
-                const bool rope = cosT && s_tok < s_rope;
-                float c[8], sn[8];
-                if (rope) {
-                    const float4* cp = reinterpret_cast<const float4*>(cosT + s_tok * 128 + sub * 8);
-                    const float4* sp = reinterpret_cast<const float4*>(sinT + s_tok * 128 + sub * 8);
-                    const float4 c0 = cp[0], c1 = cp[1], s0 = sp[0], s1 = sp[1];
-                    c[0] = c0.x; c[1] = c0.y; c[2] = c0.z; c[3] = c0.w; c[4] = c1.x; c[5] = c1.y; c[6] = c1.z; c[7] = c1.w;
-                    sn[0] = s0.x; sn[1] = s0.y; sn[2] = s0.z; sn[3] = s0.w; sn[4] = s1.x; sn[5] = s1.y; sn[6] = s1.z; sn[7] = s1.w;
-                }
-                norm_rope_row<T>(fq, wqv, wq != nullptr, eps, rope, c, sn);
-                norm_rope_row<T>(fk, wkv, wk != nullptr, eps, rope, c, sn);
-                *reinterpret_cast<uint4*>(oq + ooff) = pack8<T>(fq);
-                *reinterpret_cast<uint4*>(ok + ooff) = pack8<T>(fk);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    aq[e] += fq[e];
-                    ak[e] += fk[e];
-                }
+        float aq[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ak[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        // the raw rows of the NEXT token are in flight while this one is normalised (each thread walks 128 tokens;
+        // deeper register rings spill at the 128 registers that 1024-thread launch bounds leave, and do not help)
+        const long long x0 = b * x_sb + (j * 128) * x_ss + h * x_sh + sub * 8;
+        uint4 rq = *reinterpret_cast<const uint4*>(xq + x0), rk = *reinterpret_cast<const uint4*>(xk + x0);
+#pragma unroll 1
+        for (int t = 0; t < 128; ++t) {
+            const long long s_tok = j * 128 + t;
+            const uint4 cq = rq, ck = rk;
+            if (t + 1 < 128) {
+                rq = *reinterpret_cast<const uint4*>(xq + x0 + (long long)(t + 1) * x_ss);
+                rk = *reinterpret_cast<const uint4*>(xk + x0 + (long long)(t + 1) * x_ss);
             }
+            const long long ooff = b * o_sb + s_tok * o_ss + h * o_sh + sub * 8;
+            float fq[8], fk[8];
+            unpack8<T>(cq, fq);
+            unpack8<T>(ck, fk);
+            const bool rope = cosT && s_tok < s_rope;
+            float c[8], sn[8];
+            if (rope) {
+                const float4* cp = reinterpret_cast<const float4*>(cosT + s_tok * 128 + sub * 8);
+                const float4* sp = reinterpret_cast<const float4*>(sinT + s_tok * 128 + sub * 8);
+                const float4 c0 = cp[0], c1 = cp[1], s0 = sp[0], s1 = sp[1];
+                c[0] = c0.x; c[1] = c0.y; c[2] = c0.z; c[3] = c0.w; c[4] = c1.x; c[5] = c1.y; c[6] = c1.z; c[7] = c1.w;
+                sn[0] = s0.x; sn[1] = s0.y; sn[2] = s0.z; sn[3] = s0.w; sn[4] = s1.x; sn[5] = s1.y; sn[6] = s1.z; sn[7] = s1.w;
+            }
+            norm_rope_row<T>(fq, wqv, wq != nullptr, eps, rope, c, sn);
+            norm_rope_row<T>(fk, wkv, wk != nullptr, eps, rope, c, sn);
+            *reinterpret_cast<uint4*>(oq + ooff) = pack8<T>(fq);
+            *reinterpret_cast<uint4*>(ok + ooff) = pack8<T>(fk);
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                sq[e] += aq[e];
-                sk[e] += ak[e];
+                aq[e] += fq[e];
+                ak[e] += fk[e];
+            }
+            if ((t & 7) == 7) {   // block_pool_kernel's order: 8 tokens summed, the 16 partial sums added in order
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    sq[e] += aq[e];
+                    sk[e] += ak[e];
+                    aq[e] = 0.f;
+                    ak[e] = 0.f;
+                }
             }
         }
         float pq[8], pk[8];
@@ -439,13 +457,17 @@ extern "C" int jenga_qk_norm_rope_pool(void* stream, const void* xq, const void*
     }
     const long long n = (long long)B * n_blocks;
     if (n == 0) return JENGA_OK;
+    int HG = 1;   // heads per workgroup: the largest divisor of H that is <= 8 (two waves: fine-grained, full occupancy)
+    for (int d = 8; d >= 1; --d)
+        if (H % d == 0) { HG = d; break; }
+    const long long n_wg = (n + 7) / 8 * 8 * (H / HG);
 #define LAUNCH_QKP(T)                                                                                             \
-    hipLaunchKernelGGL(qk_norm_rope_pool_kernel<T>, dim3(grid_for(n, 65536)), dim3((unsigned)(16 * H)), 0,        \
+    hipLaunchKernelGGL(qk_norm_rope_pool_kernel<T>, dim3(grid_for(n_wg, 1 << 20)), dim3((unsigned)(16 * HG)), 0,  \
                        (hipStream_t)stream, (const uint16_t*)xq, (const uint16_t*)xk, (uint16_t*)oq, (uint16_t*)ok, \
                        (const uint16_t*)wq, (const uint16_t*)wk, cosT, sinT, (uint16_t*)qpool, (uint16_t*)kpool,  \
                        (long long)B, (long long)n_blocks, (long long)H, (long long)x_sb, (long long)x_ss,          \
                        (long long)x_sh, (long long)o_sb, (long long)o_ss, (long long)o_sh, (long long)s_rope,     \
-                       (long long)pool_block0, (long long)nq_pool, (long long)nk_pool, eps)
+                       (long long)pool_block0, (long long)nq_pool, (long long)nk_pool, eps, HG)
     if (dtype == JENGA_BF16) LAUNCH_QKP(BF16); else LAUNCH_QKP(FP16);
 #undef LAUNCH_QKP
     JENGA_CHECK_LAUNCH("jenga_qk_norm_rope_pool");
