@@ -737,13 +737,71 @@ def gen_scheduler():
     np.savez_compressed(os.path.join(OUT, "stage_switch_case.npz"), **sw)
 
 
+def gen_wan_sched():
+    """FlowUniPCMultistepScheduler (wan/utils/fm_solvers_unipc.py; diffusers absent -> its imports are stubbed for the
+    import only): schedules and the Turbo stage switch composed as jenga_wan.py:217-243 orders the scheduler's calls."""
+    for name in ("diffusers", "diffusers.configuration_utils", "diffusers.utils", "diffusers.schedulers",
+                 "diffusers.schedulers.scheduling_utils"):
+        sys.modules.setdefault(name, types.ModuleType(name))
+
+    class _Cfg:
+        pass
+
+    def register_to_config(init):
+        def wrapped(self, *a, **kw):
+            import inspect
+            ba = inspect.signature(init).bind(self, *a, **kw)
+            ba.apply_defaults()
+            self.config = _Cfg()
+            for k, v in list(ba.arguments.items())[1:]:
+                setattr(self.config, k, v)
+            init(self, *a, **kw)
+        return wrapped
+
+    sys.modules["diffusers.configuration_utils"].ConfigMixin = type("ConfigMixin", (), {})
+    sys.modules["diffusers.configuration_utils"].register_to_config = register_to_config
+    su = sys.modules["diffusers.schedulers.scheduling_utils"]
+    su.SchedulerMixin = type("SchedulerMixin", (), {})
+    import enum
+    su.KarrasDiffusionSchedulers = enum.Enum("KarrasDiffusionSchedulers", {})
+    su.SchedulerOutput = type("SchedulerOutput", (), {"__init__": lambda self, prev_sample=None: setattr(self, "prev_sample", prev_sample)})
+    sys.modules["diffusers.utils"].deprecate = lambda *a, **k: None
+    sys.modules["diffusers.utils"].is_scipy_available = lambda: False
+    m = _load("ref_unipc", "wan/utils/fm_solvers_unipc.py")
+    out = {}
+    steps, idx = 50, 25
+    for shift in (3.0, 5.0):
+        sch = m.FlowUniPCMultistepScheduler(num_train_timesteps=1000, shift=1, use_dynamic_shifting=False)   # :138-141
+        sch.set_timesteps(steps, device="cpu", shift=shift)                                                  # :142-143
+        out[f"sigmas_{int(shift)}"] = sch.sigmas.numpy()
+        out[f"timesteps_{int(shift)}"] = sch.timesteps.numpy()
+    g = torch.Generator().manual_seed(17)
+    lat = torch.randn(4, 3, 6, 8, generator=g)                  # latents are fp32 in the Wan pipeline
+    npred = torch.randn(4, 3, 6, 8, generator=g)
+    noise = torch.randn(4, 3, 8, 12, generator=g)
+    out["lat"], out["npred"], out["noise"] = lat.numpy(), npred.numpy(), noise.numpy()
+    sch = m.FlowUniPCMultistepScheduler(num_train_timesteps=1000, shift=1, use_dynamic_shifting=False)
+    sch.set_timesteps(steps, device="cpu", shift=3.0)
+    timesteps = sch.timesteps
+    sch._step_index = idx                                       # the loop has called step() idx times by now
+    clean = sch.step_to_zero(npred.unsqueeze(0), timesteps[idx], lat.unsqueeze(0), return_dict=False)[0]      # :220-225
+    clean = torch.nn.functional.interpolate(clean, size=[3, 8, 12], mode="trilinear")                          # :228
+    noisy = sch.add_noise(clean, noise.unsqueeze(0), timesteps[idx + 1].unsqueeze(0))                          # :229-233
+    sch.disable_corrector = [24, 25, 26, 27, 28, 29, 30, 31, 32, 33, 34, 35, 36, 37]                           # :237
+    sch.set_timesteps(steps, device="cpu", shift=3.0 + 2)                                                      # :238-239
+    out["switched"] = noisy.squeeze(0).numpy()
+    out["sigmas_after"] = sch.sigmas.numpy()
+    out["timesteps_after"] = sch.timesteps.numpy()
+    np.savez_compressed(os.path.join(OUT, "wan_sched_cases.npz"), **out)
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--big", action="store_true", help="also hash the full-size curves (about 1 min)")
     ap.add_argument("--only", default="")
     a = ap.parse_args()
     torch.set_grad_enabled(False)
-    if a.only not in ("wan", "sched", "wanblock", "hyblocks", "wanforward", "hyforward", "i2vblock", "wan1p3b"):
+    if a.only not in ("wan", "sched", "wansched", "wanblock", "hyblocks", "wanforward", "hyforward", "i2vblock", "wan1p3b"):
         gen_gilbert(a.big)
     if a.only in ("", "select", "attn"):
         gen_select()
@@ -767,4 +825,6 @@ if __name__ == "__main__":
         gen_wan_forward()
     if a.only in ("", "sched"):
         gen_scheduler()
+    if a.only in ("", "sched", "wansched"):
+        gen_wan_sched()
     print("golden fixtures written to", OUT)

@@ -69,3 +69,25 @@ def test_teacache_stage_start_forces_compute():
     tea.stage_start = True
     calc, _ = tea.decide(e, e.unsqueeze(1))
     assert calc
+
+
+def test_wan_flow_schedule_and_turbo_switch_match_the_reference_scheduler(golden_dir):
+    """tests/golden/wan_sched_cases.npz: FlowUniPCMultistepScheduler's own sigmas / timesteps and the Turbo stage switch
+    composed as jenga_wan.py:217-243 orders its step_to_zero / add_noise / set_timesteps calls."""
+    import os
+    from jenga_amd.wan_driver import WAN_TURBO_DISABLE_CORRECTOR, WanFlowSchedule, wan_switch_stage
+    g = np.load(os.path.join(golden_dir, "wan_sched_cases.npz"))
+    for shift in (3.0, 5.0):
+        s = WanFlowSchedule(50, shift)
+        assert np.array_equal(s.sigmas.numpy(), g[f"sigmas_{int(shift)}"])
+        assert np.array_equal(s.timesteps.numpy(), g[f"timesteps_{int(shift)}"])
+    s = WanFlowSchedule(50, 3.0)
+    lat, npred, noise = (torch.from_numpy(g[k]) for k in ("lat", "npred", "noise"))
+    out = wan_switch_stage(s, npred, 25, lat, (3, 8, 12), noise, 50)
+    assert np.array_equal(out.numpy(), g["switched"])
+    assert np.array_equal(s.sigmas.numpy(), g["sigmas_after"]) and np.array_equal(s.timesteps.numpy(), g["timesteps_after"])
+    assert s.shift == 5.0 and s.disable_corrector == WAN_TURBO_DISABLE_CORRECTOR
+    # the corrector gate right after the switch (fm_solvers_unipc.py:688-692, 723-725)
+    assert not s.use_corrector(26) and s.use_corrector(23) and not s.use_corrector(0)
+    assert s.order_after_gate(2) == 1 and s.disable_corrector == [] and s.order_after_gate(2) == 2
+    assert s.use_corrector(26)
