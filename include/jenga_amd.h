@@ -145,6 +145,12 @@ int jenga_block_pool(void* stream, const void* x, void* pooled, int64_t B, int64
  * fp32 with each partial rounded to dtype, compared with p rounded to dtype (:241-247);
  * n = max(#(cumsum <= p) + 1, top_k) (:245-250); keep the first n sorted columns (:253-276); OR the static
  * neighbour rows (:280-289); first_frame rule (Wan); all text columns [nk_img, nk_img+text_blocks) (:292-293).
+ * CONTRACT of the cumulative sum: the parity target is what torch.cumsum computes for a 16-bit tensor on the CPU
+ * (one fp32 running sum per row, every partial rounded to dtype) -- the semantics of the reference's goldens, which
+ * can only be generated on the CPU here.  torch's DEVICE cumsum of a bf16 row is a blocked scan whose partials round
+ * differently; against it the kept count of a 900-block row differs by up to 3 / 7 / 18 blocks at p = 0.3 / 0.5 /
+ * 0.9 on flat scores (tests/test_gpu_select.py records the measured difference,
+ * profiles/r02_parity_cumsum_semantics.json) and by 0 where top_k or a peaked softmax decides n.
  *   qpool [B,H,nq,128], kpool [B,H,nk_all,128] (from jenga_block_pool), nk_all = nk_img + text_blocks
  *   neighbors: uint8 [nb_rows, nb_cols] row-major (row stride nb_cols) or NULL
  * Outputs (either may be NULL):
@@ -181,12 +187,16 @@ int jenga_bsattn_fwd(void* stream, const void* q, const void* k, const void* vt,
                      int64_t n_blocks, int64_t nq_img, int64_t q_sb, int64_t q_ss, int64_t q_sh, int64_t k_sb,
                      int64_t k_ss, int64_t k_sh, int64_t o_sb, int64_t o_ss, int64_t o_sh, float sm_scale,
                      float text_amp, int64_t text_block_start, int dtype, int flags);
-/* flags */
+/* flags: which of the three parity-equivalent kernels runs (DESIGN.md section 3 has the measurements)
+ *   neither PINGPONG nor LP: the round-1 kernel (csrc/bsattn.hip), 4-wave workgroup per 128-row query block */
 #define JENGA_ATTN_XCD_REMAP 1 /* contiguous q-block ranges per XCD (L2 locality); 0 = plain head-major order */
 #define JENGA_ATTN_PINGPONG 2  /* 8-wave workgroups, MFMA / softmax phases of the two waves per SIMD in anti-phase */
-#define JENGA_ATTN_LP 8        /* same decomposition, in-wave software pipeline (softmax inside the MFMA stream) */
+#define JENGA_ATTN_LP 8        /* same decomposition, in-wave software pipeline (softmax inside the MFMA stream):
+                                  csrc/bsattn3.hip, the default of the Python modules (XCD_REMAP | LP) */
 
-/* Step 2, second generation (the default path of the Python modules): two Hilbert-adjacent query blocks per
+/* Step 2, pair variant (a measured alternative, not the default: it halves the staged bytes of shared kv blocks but
+ * even with 85 % of the blocks shared it ran 1017 TFLOP/s against 1044-1056 for jenga_bsattn_fwd on the same lists,
+ * DESIGN.md section 3): two Hilbert-adjacent query blocks per
  * workgroup, kv blocks kept by BOTH staged once for 256 query rows, one wave per SIMD with the softmax of one
  * (32-row, 64-key) item interleaved into the MFMA stream of its neighbours (csrc/bsattn2.hip).
  *   jenga_pair_merge: idx/cnt of jenga_block_select ->

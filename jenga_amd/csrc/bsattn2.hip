@@ -1,6 +1,11 @@
 // Block-sparse attention forward, second generation ("pair kernel"), gfx950, head_dim 128, 128-token blocks.
+// NOT the default: on the benchmark's lists (adjacent query blocks share ~35 % of their kept blocks) it runs
+// 930-1015 TFLOP/s against 1055-1110 for bsattn3.hip, and with 85 % shared (synthetic lists) 1017 against 1044-1056
+// for bsattn.hip.  It is kept, parity-tested, as the measured record of the design the round-1 review asked for: the
+// only variant whose staged bytes per FLOP fall with list overlap -- and the evidence that bytes are not what binds
+// (DESIGN.md section 3).
 //
-// What changed against bsattn.hip (kept as the legacy path, JENGA_ATTN_LEGACY):
+// What changed against bsattn.hip:
 //   * a workgroup = 4 waves = TWO Hilbert-adjacent query blocks A, B of one head (256 query rows).  Wave w owns rows
 //     [32w, 32w+32) of A and the same rows of B, so all four SIMDs carry the same load whatever the lists look like.
 //   * the two kept lists are merged beforehand (jenga_pair_merge) into three ascending lists: kv blocks both query
