@@ -27,12 +27,23 @@ B)
   ;;
 P)
   # board power / clock while each kernel variant loops for ~15 s (is the clock drop a power cap?)
-  for v in "lp:9:" "legacy:5:" "lp_l2:9:--l2-resident 64" "lp_same:9:--same-list"; do
+  for v in "lp:9:" "lp_l2:9:--l2-resident 64"; do
     IFS=: read tag fl extra <<< "$v"
-    timeout 300 python tools/power_sample.py --out $O/power_$tag.json -- python tools/bench_attn.py --drop 0.7 --iters 300 --attn-only --flags $fl $extra > $O/power_$tag.log 2>&1
+    timeout 400 python tools/power_sample.py --out $O/power_$tag.json -- python tools/bench_attn.py --drop 0.7 --iters 600 --attn-only --flags $fl $extra > $O/power_$tag.log 2>&1
     python - $O/power_$tag.json <<'PY'
 import json,sys
 d=json.load(open(sys.argv[1])); print(sys.argv[1], d.get("power_cap_W"), d.get("power_W"), d.get("sclk_MHz"), d.get("stdout_tail","")[-300:])
+PY
+  done
+  ;;
+S)
+  # sustained (30 s) runs of the three kernels: steady-state power / clock / throughput, flat lists and 85 %-shared lists
+  for v in "s_lp:9:" "s_legacy:5:" "s_pair:1:" "s_lp_ov:9:--pair-overlap 0.8" "s_pair_ov:1:--pair-overlap 0.8" "s_legacy_ov:5:--pair-overlap 0.8"; do
+    IFS=: read tag fl extra <<< "$v"
+    timeout 400 python tools/power_sample.py --out $O/power_$tag.json -- python tools/bench_attn.py --drop 0.7 --iters 500 --attn-only --flags $fl $extra > $O/power_$tag.log 2>&1
+    python - $O/power_$tag.json <<'PY'
+import json,sys
+d=json.load(open(sys.argv[1])); print(sys.argv[1], d.get("power_W"), d.get("sclk_MHz"), d.get("stdout_tail","")[-160:])
 PY
   done
   ;;

@@ -52,16 +52,22 @@ def main():
     p = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
     t0 = time.time()
     series = []
+    smi_series = []
     smi_mid = None
     while p.poll() is None:
         t = time.time() - t0
         if hw:
-            f = hw[0]
-            pw = _read(f["power1_average"])
-            if pw is None:
-                pw = _read(f["power1_input"])
-            series.append((round(t, 3), pw / 1e6 if pw is not None else None,
-                           (_read(f["freq1_input"]) or 0) / 1e6))
+            # the busiest card (a box may expose more hwmon nodes than HIP devices)
+            best = None
+            for f in hw:
+                pw = _read(f["power1_average"])
+                if pw is None:
+                    pw = _read(f["power1_input"])
+                if pw is not None and (best is None or pw > best[0]):
+                    best = (pw, (_read(f["freq1_input"]) or 0))
+            series.append((round(t, 3), best[0] / 1e6 if best else None, (best[1] if best else 0) / 1e6))
+            if len(series) % 40 == 0:
+                smi_series.append((round(t, 1), smi()))
             time.sleep(a.period)
         else:
             s = smi()
@@ -74,6 +80,8 @@ def main():
     res["stdout_tail"] = so[-1500:]
     res["stderr_tail"] = se[-500:]
     res["smi_mid_run"] = smi_mid
+    res["smi_series"] = smi_series
+    res["hwmon_nodes"] = len(hw)
     if hw:
         res["power_cap_W"] = (_read(hw[0]["power1_cap"]) or 0) / 1e6
         pw = [s[1] for s in series if s[1] is not None]
