@@ -133,10 +133,14 @@ __device__ __forceinline__ void lp_exact(LpState& st, const f32x16& s, uint4 (&p
 
 // One basic block of the pipeline (see the header).  HALF: which 32-key half of the 64-key tiles kt (item i) and vt
 // (item i-2) this block works on.
-template <typename T, bool TEXT, int HALF, bool DO_PV, bool DO_QK, bool DO_SM>
+// KOFF / VOFF: byte offset of the ring slot inside the K / V^T ring when it is known at compile time (the unrolled
+// main loop) -- it then folds into the ds_read offset field together with the HALF / d-block offsets and the eight K
+// + two V^T per-item address adds disappear; -1: the slot is in the pointer (kt / vt = smem + slot * LP_TILE).
+template <typename T, bool TEXT, int HALF, bool DO_PV, bool DO_QK, bool DO_SM, int KOFF = -1, int VOFF = -1>
 __device__ __forceinline__ void lp_bb(LpState& st, const unsigned char* kt, const unsigned char* vt, f32x16& sn,
                                       const f32x16& sp, const uint4 (&pf_old)[2], uint4 (&pf_new)[2],
                                       const int (&k_addr)[8], const int (&v_addr)[4], float qk_scale) {
+    constexpr int KO = KOFF < 0 ? 0 : KOFF, VO = VOFF < 0 ? 0 : VOFF;
     f32x16 zero16;
 #pragma unroll
     for (int r = 0; r < 16; ++r) zero16[r] = 0.f;
@@ -156,10 +160,10 @@ __device__ __forceinline__ void lp_bb(LpState& st, const unsigned char* kt, cons
         if (!LP_RD_ON(F_)) {                                                                                          \
             if ((F_) < 16) fr[(F_) & 15] = fr[((F_) & 15) ^ 1];                                                       \
         } else if ((F_) < 8) {                                                                                        \
-            if (DO_QK) fr[F_] = *reinterpret_cast<const uint4*>(kt + k_addr[F_] + HALF * 8192);                       \
+            if (DO_QK) fr[F_] = *reinterpret_cast<const uint4*>(kt + k_addr[F_] + (HALF * 8192 + KO));                \
         } else if ((F_) < 16) {                                                                                       \
             if (DO_PV) fr[F_] = *reinterpret_cast<const uint4*>(vt + v_addr[2 * HALF + (((F_) - 8) >> 2)] +           \
-                                                                (((F_) - 8) & 3) * 4096);                             \
+                                                                ((((F_) - 8) & 3) * 4096 + VO));                      \
         }                                                                                                             \
     } while (0)
 #ifdef JENGA_X_NOSM
@@ -392,24 +396,26 @@ __device__ __forceinline__ void attn_block_lp(const LpParams& P, unsigned char* 
         return __builtin_amdgcn_readlane(lchunk, i - lbase);
     };
     // tile t = half (t & 1) of kept block t >> 1
-    auto issue_k = [&](int t) {
+    auto issue_k_at = [&](int t, int slot) {
 #ifdef JENGA_LP_LOADERS
         if (!is_loader) return;
 #endif
         const int tc = t < 2 * nkept ? t : 2 * nkept - 1;
         const int blk = blk_at(tc >> 1);
         lp_stage4(kbh + ((long long)blk * 128 + (tc & 1) * 64) * P.k_ss,
-                  smem_base + LP_K_RING + (t % 3) * LP_TILE + wave_u * 4096, k_src0, k_src1, k_src2, k_src3);
+                  smem_base + LP_K_RING + slot * LP_TILE + wave_u * 4096, k_src0, k_src1, k_src2, k_src3);
     };
-    auto issue_v = [&](int t) {
+    auto issue_v_at = [&](int t, int slot) {
 #ifdef JENGA_LP_LOADERS
         if (!is_loader) return;
 #endif
         const int tc = t < 2 * nkept ? t : 2 * nkept - 1;
         const int blk = blk_at(tc >> 1);
         lp_stage4(vbh + ((long long)blk * 2 + (tc & 1)) * (128 * 64),
-                  smem_base + LP_V_RING + (t & 1) * LP_TILE + wave_u * 4096, v_src0, v_src1, v_src2, v_src3);
+                  smem_base + LP_V_RING + slot * LP_TILE + wave_u * 4096, v_src0, v_src1, v_src2, v_src3);
     };
+    auto issue_k = [&](int t) { issue_k_at(t, t % 3); };
+    auto issue_v = [&](int t) { issue_v_at(t, t & 1); };
     auto kslot = [&](int t) { return smem + (t % 3) * LP_TILE; };   // + k_addr (LP_K_RING inside)
     auto vslot = [&](int t) { return smem + (t & 1) * LP_TILE; };   // + v_addr (LP_V_RING inside)
 
@@ -461,9 +467,29 @@ __device__ __forceinline__ void attn_block_lp(const LpParams& P, unsigned char* 
         return;
     }
 #endif
+    // step t0 + J of the unrolled loop, t0 = 1 (mod 6): every ring slot is a compile-time constant
+#define LP_STEP_C(T0_, J_)                                                                                            \
+    do {                                                                                                              \
+        issue_v_at((T0_) + (J_), (1 + (J_)) & 1);                                                                     \
+        lp_bb<T, TEXT, 0, true, true, true, ((1 + (J_)) % 3) * LP_TILE, ((J_) & 1) * LP_TILE>(                        \
+            st, smem, smem, sA, sB, pfA, pfB, k_addr, v_addr, P.qk_scale);                                            \
+        issue_k_at((T0_) + (J_) + 2, (J_) % 3);                                                                       \
+        lp_bb<T, TEXT, 1, true, true, true, ((1 + (J_)) % 3) * LP_TILE, ((J_) & 1) * LP_TILE>(                        \
+            st, smem, smem, sB, sA, pfB, pfA, k_addr, v_addr, P.qk_scale);                                            \
+        LP_WAIT_KEEP4();                                                                                              \
+        __syncthreads();                                                                                              \
+    } while (0)
     if (t_fast > 0) {
         LP_STEP(0, false, false);
-        for (int t = 1; t < t_fast; ++t) LP_STEP(t, true, true);
+        int t = 1;
+#ifndef JENGA_LP_NO_UNROLL
+        if (!TEXT) {
+            for (; t + 6 <= t_fast; t += 6) {
+                LP_STEP_C(t, 0); LP_STEP_C(t, 1); LP_STEP_C(t, 2); LP_STEP_C(t, 3); LP_STEP_C(t, 4); LP_STEP_C(t, 5);
+            }
+        }
+#endif
+        for (; t < t_fast; ++t) LP_STEP(t, true, true);
         // drain: softmax of the last item, P.V of the last tile
         lp_bb<T, TEXT, 0, true, false, true>(st, nullptr, vslot(t_fast - 1), sA, sB, pfA, pfB, k_addr, v_addr,
                                              P.qk_scale);
@@ -471,6 +497,7 @@ __device__ __forceinline__ void attn_block_lp(const LpParams& P, unsigned char* 
                                               P.qk_scale);
     }
 #undef LP_STEP
+#undef LP_STEP_C
     if (!TEXT) {
         for (int t = t_fast; t < t_all; ++t) {
             issue_v(t);
