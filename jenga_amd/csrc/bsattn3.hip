@@ -136,15 +136,21 @@ __device__ __forceinline__ void lp_exact(LpState& st, const f32x16& s, uint4 (&p
 // KOFF / VOFF: byte offset of the ring slot inside the K / V^T ring when it is known at compile time (the unrolled
 // main loop) -- it then folds into the ds_read offset field together with the HALF / d-block offsets and the eight K
 // + two V^T per-item address adds disappear; -1: the slot is in the pointer (kt / vt = smem + slot * LP_TILE).
-template <typename T, bool TEXT, int HALF, bool DO_PV, bool DO_QK, bool DO_SM, int KOFF = -1, int VOFF = -1>
+// PRE: 1 = during its P.V MFMAs this (HALF 0) block also issues the K fragment reads of the NEXT block (HALF 1 of the
+// same tile, into frk, which lives in the caller), 2 = this block's K fragments were issued that way (no up-front
+// reads): the fragment pipeline then runs through the block boundary instead of draining and refilling there.
+template <typename T, bool TEXT, int HALF, bool DO_PV, bool DO_QK, bool DO_SM, int KOFF = -1, int VOFF = -1, int PRE = 0>
 __device__ __forceinline__ void lp_bb(LpState& st, const unsigned char* kt, const unsigned char* vt, f32x16& sn,
                                       const f32x16& sp, const uint4 (&pf_old)[2], uint4 (&pf_new)[2],
-                                      const int (&k_addr)[8], const int (&v_addr)[4], float qk_scale) {
+                                      const int (&k_addr)[8], const int (&v_addr)[4], float qk_scale,
+                                      uint4 (&frk)[8]) {
     constexpr int KO = KOFF < 0 ? 0 : KOFF, VO = VOFF < 0 ? 0 : VOFF;
+    static_assert(PRE == 0 || (DO_QK && DO_PV), "the cross-block fragment pipeline is for full blocks");
+    static_assert(PRE != 1 || HALF == 0, "only the first half prefetches (the next tile may still be in flight)");
     f32x16 zero16;
 #pragma unroll
     for (int r = 0; r < 16; ++r) zero16[r] = 0.f;
-    uint4 fr[16];
+    uint4 frv[8];
     float tt[16], xx[16];
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
     uint32_t ww[8];
@@ -158,12 +164,15 @@ __device__ __forceinline__ void lp_bb(LpState& st, const unsigned char* kt, cons
 #define LP_READ(F_)                                                                                                   \
     do {                                                                                                              \
         if (!LP_RD_ON(F_)) {                                                                                          \
-            if ((F_) < 16) fr[(F_) & 15] = fr[((F_) & 15) ^ 1];                                                       \
+            if ((F_) < 8) frk[(F_) & 7] = frk[((F_) & 7) ^ 1];                                                        \
+            else if ((F_) < 16) frv[(F_) & 7] = frv[((F_) & 7) ^ 1];                                                  \
         } else if ((F_) < 8) {                                                                                        \
-            if (DO_QK) fr[F_] = *reinterpret_cast<const uint4*>(kt + k_addr[F_] + (HALF * 8192 + KO));                \
+            if (DO_QK) frk[(F_) & 7] = *reinterpret_cast<const uint4*>(kt + k_addr[(F_) & 7] + (HALF * 8192 + KO));   \
         } else if ((F_) < 16) {                                                                                       \
-            if (DO_PV) fr[F_] = *reinterpret_cast<const uint4*>(vt + v_addr[2 * HALF + (((F_) - 8) >> 2)] +           \
-                                                                ((((F_) - 8) & 3) * 4096 + VO));                      \
+            if (DO_PV) frv[(F_) & 7] = *reinterpret_cast<const uint4*>(vt + v_addr[2 * HALF + (((F_) - 8) >> 2)] +    \
+                                                                       ((((F_) - 8) & 3) * 4096 + VO));               \
+        } else if ((F_) < 24 && PRE == 1) { /* K fragment (F_ - 16) of the next block: the other half of this tile */ \
+            frk[(F_) & 7] = *reinterpret_cast<const uint4*>(kt + k_addr[(F_) & 7] + (8192 + KO));                     \
         }                                                                                                             \
     } while (0)
 #ifdef JENGA_X_NOSM
@@ -182,7 +191,8 @@ __device__ __forceinline__ void lp_bb(LpState& st, const unsigned char* kt, cons
                 if ((M_) >= 1 && (M_) < 17) xx[((M_) - 1) & 15] = __builtin_amdgcn_exp2f(sp[((M_) - 1) & 15]);        \
             }                                                                                                         \
             if ((M_) >= 2 && (M_) < 18) {                                                                             \
-                acc[((M_) - 2) & 3] += xx[((M_) - 2) & 15];                                                           \
+                if ((M_) < 6) acc[((M_) - 2) & 3] = xx[((M_) - 2) & 15];                                              \
+                else acc[((M_) - 2) & 3] += xx[((M_) - 2) & 15];                                                      \
                 if (((M_) - 2) & 1) ww[(((M_) - 2) & 15) >> 1] = pack2<T>(xx[((M_) - 3) & 15], xx[((M_) - 2) & 15]);  \
             }                                                                                                         \
         }                                                                                                             \
@@ -208,16 +218,17 @@ __device__ __forceinline__ void lp_bb(LpState& st, const unsigned char* kt, cons
     do {                                                                                                              \
         if (!((M_) & 1) && (((M_) < 8 && DO_QK) || ((M_) >= 8 && DO_PV))) {                                           \
             if (!DO_QK) LP_LGKM(14 - (M_) > 8 ? 0 : 14 - (M_));   /* drain forms: fragments 8..15 read up front */    \
+            else if (PRE == 1) LP_LGKM(6);   /* the next block's reads keep the queue at eight */                     \
             else LP_LGKM((M_) <= 8 ? 6 : 14 - (M_));                                                                  \
             __builtin_amdgcn_sched_barrier(0);   /* or hipcc moves the MFMA above the wait and adds its own */        \
         }                                                                                                             \
         if ((M_) < 8) {                                                                                               \
             if (DO_QK) {                                                                                              \
-                if ((M_) == 0) { if (TEXT) LP_MFMA(sn, fr[M_], st.qf[M_], zero16); else LP_MFMA(sn, fr[M_], st.qf[M_], st.cinit); } \
-                else LP_MFMA(sn, fr[M_], st.qf[M_], sn);                                                              \
+                if ((M_) == 0) { if (TEXT) LP_MFMA(sn, frk[(M_) & 7], st.qf[(M_) & 7], zero16); else LP_MFMA(sn, frk[(M_) & 7], st.qf[(M_) & 7], st.cinit); } \
+                else LP_MFMA(sn, frk[(M_) & 7], st.qf[(M_) & 7], sn);                                                 \
             }                                                                                                         \
         } else if (DO_PV) {                                                                                           \
-            LP_MFMA(st.o[((M_) - 8) & 3], fr[M_], pf_old[((M_) - 8) >> 2], st.o[((M_) - 8) & 3]);                     \
+            LP_MFMA(st.o[((M_) - 8) & 3], frv[(M_) & 7], pf_old[((M_) - 8) >> 2], st.o[((M_) - 8) & 3]);              \
         }                                                                                                             \
         if (((M_) & 1) == 0) {                                                                                        \
             LP_READ((M_) + 8); LP_READ((M_) + 9);                                                                     \
@@ -225,7 +236,9 @@ __device__ __forceinline__ void lp_bb(LpState& st, const unsigned char* kt, cons
         LP_SM(M_);                                                                                                    \
         __builtin_amdgcn_sched_barrier(0);                                                                            \
     } while (0)
-    LP_READ(0); LP_READ(1); LP_READ(2); LP_READ(3); LP_READ(4); LP_READ(5); LP_READ(6); LP_READ(7);
+    if (PRE != 2) {
+        LP_READ(0); LP_READ(1); LP_READ(2); LP_READ(3); LP_READ(4); LP_READ(5); LP_READ(6); LP_READ(7);
+    }
     if (!DO_QK) {
         LP_READ(8); LP_READ(9); LP_READ(10); LP_READ(11); LP_READ(12); LP_READ(13); LP_READ(14); LP_READ(15);
     }
@@ -249,7 +262,7 @@ __device__ __forceinline__ void lp_bb(LpState& st, const unsigned char* kt, cons
         psum = 1.f + sp[0] * 1e-30f;
         pf_new[0] = pf_new[1] = make_uint4(0x3c003c00u, 0x3c003c00u, 0x3c003c00u, 0x3c003c00u);
 #else
-        if (__any(!(psum <= LP_RAISE_SUM) || (st.l + psum < lp_tiny<T>())))
+        if (__builtin_amdgcn_ballot_w64(!(psum <= LP_RAISE_SUM) || (st.l + psum < lp_tiny<T>())) != 0ull)
             lp_exact<T, TEXT>(st, sp, pf_new, psum, qk_scale, DO_QK ? &sn : nullptr);
 #endif
         st.l += psum;
@@ -402,7 +415,9 @@ __device__ __forceinline__ void attn_block_lp(const LpParams& P, unsigned char* 
 #endif
         const int tc = t < 2 * nkept ? t : 2 * nkept - 1;
         const int blk = blk_at(tc >> 1);
-        lp_stage4(kbh + ((long long)blk * 128 + (tc & 1) * 64) * P.k_ss,
+        // byte offset = row * (k_ss * 2): one 32 x 32 -> 64 bit scalar multiply (launcher: k_ss * 2 < 2^32)
+        lp_stage4(reinterpret_cast<const unsigned char*>(kbh) +
+                      (unsigned long long)((unsigned)blk * 128u + (unsigned)(tc & 1) * 64u) * kss_b,
                   smem_base + LP_K_RING + slot * LP_TILE + wave_u * 4096, k_src0, k_src1, k_src2, k_src3);
     };
     auto issue_v_at = [&](int t, int slot) {
@@ -411,7 +426,8 @@ __device__ __forceinline__ void attn_block_lp(const LpParams& P, unsigned char* 
 #endif
         const int tc = t < 2 * nkept ? t : 2 * nkept - 1;
         const int blk = blk_at(tc >> 1);
-        lp_stage4(vbh + ((long long)blk * 2 + (tc & 1)) * (128 * 64),
+        lp_stage4(reinterpret_cast<const unsigned char*>(vbh) +
+                      (unsigned long long)((unsigned)blk * 2u + (unsigned)(tc & 1)) * (128u * 64u * 2u),
                   smem_base + LP_V_RING + slot * LP_TILE + wave_u * 4096, v_src0, v_src1, v_src2, v_src3);
     };
     auto issue_k = [&](int t) { issue_k_at(t, t % 3); };
@@ -431,6 +447,14 @@ __device__ __forceinline__ void attn_block_lp(const LpParams& P, unsigned char* 
 
     f32x16 sA, sB;
     uint4 pfA[2], pfB[2];
+    uint4 frk[8];   // K fragments of the item in flight (lp_bb, PRE)
+#ifdef JENGA_LP_NO_PREFETCH
+#define LP_PRE0 0
+#define LP_PRE1 0
+#else
+#define LP_PRE0 1
+#define LP_PRE1 2
+#endif
 #pragma unroll
     for (int r = 0; r < 16; ++r) sA[r] = sB[r] = 0.f;
     pfA[0] = pfA[1] = pfB[0] = pfB[1] = make_uint4(0u, 0u, 0u, 0u);
@@ -448,10 +472,10 @@ __device__ __forceinline__ void attn_block_lp(const LpParams& P, unsigned char* 
     do {                                                                                                              \
         issue_v(T_);                                                                                                  \
         lp_bb<T, TEXT, 0, PV_, true, SM0_>(st, kslot(T_), vslot((T_) - 1), sA, sB, pfA, pfB, k_addr, v_addr,          \
-                                           P.qk_scale);                                                               \
+                                           P.qk_scale, frk);                                                          \
         issue_k((T_) + 2);                                                                                            \
         lp_bb<T, TEXT, 1, PV_, true, true>(st, kslot(T_), vslot((T_) - 1), sB, sA, pfB, pfA, k_addr, v_addr,          \
-                                           P.qk_scale);                                                               \
+                                           P.qk_scale, frk);                                                          \
         LP_WAIT_KEEP4();                                                                                              \
         __syncthreads();                                                                                              \
     } while (0)
@@ -471,11 +495,11 @@ __device__ __forceinline__ void attn_block_lp(const LpParams& P, unsigned char* 
 #define LP_STEP_C(T0_, J_)                                                                                            \
     do {                                                                                                              \
         issue_v_at((T0_) + (J_), (1 + (J_)) & 1);                                                                     \
-        lp_bb<T, TEXT, 0, true, true, true, ((1 + (J_)) % 3) * LP_TILE, ((J_) & 1) * LP_TILE>(                        \
-            st, smem, smem, sA, sB, pfA, pfB, k_addr, v_addr, P.qk_scale);                                            \
+        lp_bb<T, TEXT, 0, true, true, true, ((1 + (J_)) % 3) * LP_TILE, ((J_) & 1) * LP_TILE, LP_PRE0>(               \
+            st, smem, smem, sA, sB, pfA, pfB, k_addr, v_addr, P.qk_scale, frk);                                       \
         issue_k_at((T0_) + (J_) + 2, (J_) % 3);                                                                       \
-        lp_bb<T, TEXT, 1, true, true, true, ((1 + (J_)) % 3) * LP_TILE, ((J_) & 1) * LP_TILE>(                        \
-            st, smem, smem, sB, sA, pfB, pfA, k_addr, v_addr, P.qk_scale);                                            \
+        lp_bb<T, TEXT, 1, true, true, true, ((1 + (J_)) % 3) * LP_TILE, ((J_) & 1) * LP_TILE, LP_PRE1>(               \
+            st, smem, smem, sB, sA, pfB, pfA, k_addr, v_addr, P.qk_scale, frk);                                       \
         LP_WAIT_KEEP4();                                                                                              \
         __syncthreads();                                                                                              \
     } while (0)
@@ -492,12 +516,14 @@ __device__ __forceinline__ void attn_block_lp(const LpParams& P, unsigned char* 
         for (; t < t_fast; ++t) LP_STEP(t, true, true);
         // drain: softmax of the last item, P.V of the last tile
         lp_bb<T, TEXT, 0, true, false, true>(st, nullptr, vslot(t_fast - 1), sA, sB, pfA, pfB, k_addr, v_addr,
-                                             P.qk_scale);
+                                             P.qk_scale, frk);
         lp_bb<T, TEXT, 1, true, false, false>(st, nullptr, vslot(t_fast - 1), sB, sA, pfB, pfA, k_addr, v_addr,
-                                              P.qk_scale);
+                                              P.qk_scale, frk);
     }
 #undef LP_STEP
 #undef LP_STEP_C
+#undef LP_PRE0
+#undef LP_PRE1
     if (!TEXT) {
         for (int t = t_fast; t < t_all; ++t) {
             issue_v(t);
@@ -593,6 +619,10 @@ int jenga_bsattn_lp_launch(void* stream, const void* q, const void* k, const voi
     } else {
         P.xcd_chunk = 0;
         P.img_per_head = (int)nq_img;
+    }
+    if (k_ss < 0 || k_ss >= (1LL << 31)) {
+        set_error("jenga_bsattn_fwd: k token stride %lld out of range", (long long)k_ss);
+        return JENGA_EINVAL;
     }
     const long long grid = (long long)P.n_text_wg_pad + B * H * (long long)P.img_per_head;
     if (grid <= 0 || grid > 0x7fffffffLL) {
