@@ -72,6 +72,28 @@ __device__ __forceinline__ void lp_stage4(const void* base, unsigned lds, unsign
                  : "s"(lds), "s"(base), "v"(o0), "v"(o1), "v"(o2), "v"(o3)
                  : "memory");
 }
+// one piece: in the unrolled main loop the four pieces of a stage go out in four MFMA slots of the block (1, 5, 9,
+// 13) instead of back to back in front of it -- less queueing in the vector-memory path, +2 % sustained
+// (JENGA_LP_NO_DMA_SPREAD restores the up-front form)
+struct LpDma {
+    const void* base;
+    unsigned lds;
+    unsigned o[4];
+};
+template <int I>
+__device__ __forceinline__ void lp_stage1(const LpDma& d) {
+#ifdef JENGA_X_NODMA
+    return;
+#endif
+    if (I == 0)
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %1" : : "s"(d.lds), "s"(d.base), "v"(d.o[0]) : "memory");
+    else if (I == 1)
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %1 offset:1024" : : "s"(d.lds), "s"(d.base), "v"(d.o[1]) : "memory");
+    else if (I == 2)
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %1 offset:2048" : : "s"(d.lds), "s"(d.base), "v"(d.o[2]) : "memory");
+    else
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %1 offset:3072" : : "s"(d.lds), "s"(d.base), "v"(d.o[3]) : "memory");
+}
 #define LP_WAIT_ALL() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
 #ifdef JENGA_X_NOWAIT
 #define LP_WAIT_KEEP4()
@@ -143,7 +165,7 @@ template <typename T, bool TEXT, int HALF, bool DO_PV, bool DO_QK, bool DO_SM, i
 __device__ __forceinline__ void lp_bb(LpState& st, const unsigned char* kt, const unsigned char* vt, f32x16& sn,
                                       const f32x16& sp, const uint4 (&pf_old)[2], uint4 (&pf_new)[2],
                                       const int (&k_addr)[8], const int (&v_addr)[4], float qk_scale,
-                                      uint4 (&frk)[8]) {
+                                      uint4 (&frk)[8], const LpDma* dma = nullptr) {
     constexpr int KO = KOFF < 0 ? 0 : KOFF, VO = VOFF < 0 ? 0 : VOFF;
     static_assert(PRE == 0 || (DO_QK && DO_PV), "the cross-block fragment pipeline is for full blocks");
     static_assert(PRE != 1 || HALF == 0, "only the first half prefetches (the next tile may still be in flight)");
@@ -232,6 +254,12 @@ __device__ __forceinline__ void lp_bb(LpState& st, const unsigned char* kt, cons
         }                                                                                                             \
         if (((M_) & 1) == 0) {                                                                                        \
             LP_READ((M_) + 8); LP_READ((M_) + 9);                                                                     \
+        }                                                                                                             \
+        if (dma) {                                                                                                    \
+            if ((M_) == 1) lp_stage1<0>(*dma);                                                                        \
+            if ((M_) == 5) lp_stage1<1>(*dma);                                                                        \
+            if ((M_) == 9) lp_stage1<2>(*dma);                                                                        \
+            if ((M_) == 13) lp_stage1<3>(*dma);                                                                       \
         }                                                                                                             \
         LP_SM(M_);                                                                                                    \
         __builtin_amdgcn_sched_barrier(0);                                                                            \
@@ -430,6 +458,26 @@ __device__ __forceinline__ void attn_block_lp(const LpParams& P, unsigned char* 
                       (unsigned long long)((unsigned)blk * 2u + (unsigned)(tc & 1)) * (128u * 64u * 2u),
                   smem_base + LP_V_RING + slot * LP_TILE + wave_u * 4096, v_src0, v_src1, v_src2, v_src3);
     };
+    auto desc_k_at = [&](int t, int slot) {
+        const int tc = t < 2 * nkept ? t : 2 * nkept - 1;
+        const int blk = blk_at(tc >> 1);
+        LpDma d;
+        d.base = reinterpret_cast<const unsigned char*>(kbh) +
+                 (unsigned long long)((unsigned)blk * 128u + (unsigned)(tc & 1) * 64u) * kss_b;
+        d.lds = smem_base + LP_K_RING + slot * LP_TILE + wave_u * 4096;
+        d.o[0] = k_src0; d.o[1] = k_src1; d.o[2] = k_src2; d.o[3] = k_src3;
+        return d;
+    };
+    auto desc_v_at = [&](int t, int slot) {
+        const int tc = t < 2 * nkept ? t : 2 * nkept - 1;
+        const int blk = blk_at(tc >> 1);
+        LpDma d;
+        d.base = reinterpret_cast<const unsigned char*>(vbh) +
+                 (unsigned long long)((unsigned)blk * 2u + (unsigned)(tc & 1)) * (128u * 64u * 2u);
+        d.lds = smem_base + LP_V_RING + slot * LP_TILE + wave_u * 4096;
+        d.o[0] = v_src0; d.o[1] = v_src1; d.o[2] = v_src2; d.o[3] = v_src3;
+        return d;
+    };
     auto issue_k = [&](int t) { issue_k_at(t, t % 3); };
     auto issue_v = [&](int t) { issue_v_at(t, t & 1); };
     auto kslot = [&](int t) { return smem + (t % 3) * LP_TILE; };   // + k_addr (LP_K_RING inside)
@@ -492,6 +540,23 @@ __device__ __forceinline__ void attn_block_lp(const LpParams& P, unsigned char* 
     }
 #endif
     // step t0 + J of the unrolled loop, t0 = 1 (mod 6): every ring slot is a compile-time constant
+#ifndef JENGA_LP_NO_DMA_SPREAD
+#define LP_STEP_C(T0_, J_)                                                                                            \
+    do {                                                                                                              \
+        {                                                                                                             \
+            const LpDma dv_ = desc_v_at((T0_) + (J_), (1 + (J_)) & 1);                                                \
+            lp_bb<T, TEXT, 0, true, true, true, ((1 + (J_)) % 3) * LP_TILE, ((J_) & 1) * LP_TILE, LP_PRE0>(           \
+                st, smem, smem, sA, sB, pfA, pfB, k_addr, v_addr, P.qk_scale, frk, &dv_);                             \
+        }                                                                                                             \
+        {                                                                                                             \
+            const LpDma dk_ = desc_k_at((T0_) + (J_) + 2, (J_) % 3);                                                  \
+            lp_bb<T, TEXT, 1, true, true, true, ((1 + (J_)) % 3) * LP_TILE, ((J_) & 1) * LP_TILE, LP_PRE1>(           \
+                st, smem, smem, sB, sA, pfB, pfA, k_addr, v_addr, P.qk_scale, frk, &dk_);                             \
+        }                                                                                                             \
+        LP_WAIT_KEEP4();                                                                                              \
+        __syncthreads();                                                                                              \
+    } while (0)
+#else
 #define LP_STEP_C(T0_, J_)                                                                                            \
     do {                                                                                                              \
         issue_v_at((T0_) + (J_), (1 + (J_)) & 1);                                                                     \
@@ -503,6 +568,7 @@ __device__ __forceinline__ void attn_block_lp(const LpParams& P, unsigned char* 
         LP_WAIT_KEEP4();                                                                                              \
         __syncthreads();                                                                                              \
     } while (0)
+#endif
     if (t_fast > 0) {
         LP_STEP(0, false, false);
         int t = 1;
