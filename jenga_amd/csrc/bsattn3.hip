@@ -175,6 +175,7 @@ __device__ __forceinline__ void lp_bb(LpState& st, const unsigned char* kt, cons
     uint4 frv[8];
     float tt[16], xx[16];
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    float half_ = 0.f;
     uint32_t ww[8];
 #ifdef JENGA_X_NOREADS      /* EXPERIMENT (wrong results): no fragment reads at all */
 #define LP_RD_ON(F_) false
@@ -202,20 +203,40 @@ __device__ __forceinline__ void lp_bb(LpState& st, const unsigned char* kt, cons
 #else
 #define LP_SM_ON true
 #endif
-    /* image rows: the scores are S - m~ already (C operand); TEXT rows: raw scores, scaled and shifted here */
+    /* image rows: the scores are S - m~ already (C operand); TEXT rows: raw scores, scaled and shifted here.
+       Image rows: all 16 scores exist when the block starts, so element e is exponentiated in slot X(e) = e / 2 for
+       e < 4, e - 2 after that, added / packed one slot later, and the 4-way sum tree closes in slot 15: what is left
+       behind the last MFMA is the cross-half permlane and the ballot.  TEXT rows keep the three-stage form (their
+       scale-and-shift stage needs a slot of its own) that ends two slots later. */
+#define LP_SM_X(E_) ((E_) < 4 ? ((E_) >> 1) : (E_) - 2)
 #define LP_SM(M_)                                                                                                     \
     do {                                                                                                              \
         if (DO_SM && LP_SM_ON) {                                                                                      \
             if (TEXT) {                                                                                               \
                 if ((M_) < 16) tt[(M_) & 15] = sp[(M_) & 15] * qk_scale + st.neg_m;                                   \
                 if ((M_) >= 1 && (M_) < 17) xx[((M_) - 1) & 15] = __builtin_amdgcn_exp2f(tt[((M_) - 1) & 15]);        \
+                if ((M_) >= 2 && (M_) < 18) {                                                                         \
+                    if ((M_) < 6) acc[((M_) - 2) & 3] = xx[((M_) - 2) & 15];                                          \
+                    else acc[((M_) - 2) & 3] += xx[((M_) - 2) & 15];                                                  \
+                    if (((M_) - 2) & 1) {                                                                             \
+                        ww[(((M_) - 2) & 15) >> 1] = pack2<T>(xx[((M_) - 3) & 15], xx[((M_) - 2) & 15]);              \
+                        asm volatile("" : "+v"(ww[(((M_) - 2) & 15) >> 1]));   /* stay in this slot */                \
+                    }                                                                                                 \
+                }                                                                                                     \
+                if ((M_) == 17) half_ = (acc[0] + acc[1]) + (acc[2] + acc[3]);                                        \
             } else {                                                                                                  \
-                if ((M_) >= 1 && (M_) < 17) xx[((M_) - 1) & 15] = __builtin_amdgcn_exp2f(sp[((M_) - 1) & 15]);        \
-            }                                                                                                         \
-            if ((M_) >= 2 && (M_) < 18) {                                                                             \
-                if ((M_) < 6) acc[((M_) - 2) & 3] = xx[((M_) - 2) & 15];                                              \
-                else acc[((M_) - 2) & 3] += xx[((M_) - 2) & 15];                                                      \
-                if (((M_) - 2) & 1) ww[(((M_) - 2) & 15) >> 1] = pack2<T>(xx[((M_) - 3) & 15], xx[((M_) - 2) & 15]);  \
+                _Pragma("unroll") for (int e_ = 0; e_ < 16; ++e_) {                                                   \
+                    if (LP_SM_X(e_) + 1 == (M_)) {                                                                    \
+                        if (e_ < 4) acc[e_ & 3] = xx[e_]; else acc[e_ & 3] += xx[e_];                                 \
+                        if (e_ & 1) {                                                                                 \
+                            ww[e_ >> 1] = pack2<T>(xx[e_ - 1], xx[e_]);                                               \
+                            asm volatile("" : "+v"(ww[e_ >> 1]));   /* stay in this slot */                           \
+                        }                                                                                             \
+                    }                                                                                                 \
+                }                                                                                                     \
+                _Pragma("unroll") for (int e_ = 0; e_ < 16; ++e_)                                                     \
+                    if (LP_SM_X(e_) == (M_)) xx[e_] = __builtin_amdgcn_exp2f(sp[e_]);                                 \
+                if ((M_) == 15) half_ = (acc[0] + acc[1]) + (acc[2] + acc[3]);                                        \
             }                                                                                                         \
         }                                                                                                             \
     } while (0)
@@ -277,11 +298,11 @@ __device__ __forceinline__ void lp_bb(LpState& st, const unsigned char* kt, cons
     LP_SM(17);
 #undef LP_READ
 #undef LP_SM
+#undef LP_SM_X
 #undef LP_SLOT
 #undef LP_MFMA
 #undef LP_LGKM
     if (DO_SM) {
-        const float half_ = (acc[0] + acc[1]) + (acc[2] + acc[3]);
         const auto sw_ = __builtin_amdgcn_permlane32_swap(__float_as_uint(half_), __float_as_uint(half_), false, false);
         float psum = __uint_as_float(sw_[0]) + __uint_as_float(sw_[1]);   // both half-lanes: the row's 32 keys
         pf_new[0] = make_uint4(ww[0], ww[1], ww[2], ww[3]);
@@ -290,7 +311,9 @@ __device__ __forceinline__ void lp_bb(LpState& st, const unsigned char* kt, cons
         psum = 1.f + sp[0] * 1e-30f;
         pf_new[0] = pf_new[1] = make_uint4(0x3c003c00u, 0x3c003c00u, 0x3c003c00u, 0x3c003c00u);
 #else
-        if (__builtin_amdgcn_ballot_w64(!(psum <= LP_RAISE_SUM) || (st.l + psum < lp_tiny<T>())) != 0ull)
+        // two ballots straight off the compares (a ballot of an OR-ed condition goes through v_cndmask + v_cmp_ne)
+        if ((__builtin_amdgcn_ballot_w64(!(psum <= LP_RAISE_SUM)) |
+             __builtin_amdgcn_ballot_w64(st.l + psum < lp_tiny<T>())) != 0ull)
             lp_exact<T, TEXT>(st, sp, pf_new, psum, qk_scale, DO_QK ? &sn : nullptr);
 #endif
         st.l += psum;
@@ -458,9 +481,25 @@ __device__ __forceinline__ void attn_block_lp(const LpParams& P, unsigned char* 
                       (unsigned long long)((unsigned)blk * 2u + (unsigned)(tc & 1)) * (128u * 64u * 2u),
                   smem_base + LP_V_RING + slot * LP_TILE + wave_u * 4096, v_src0, v_src1, v_src2, v_src3);
     };
+    // unrolled main loop: the 64-entry window is checked ONCE per six steps (lp_window), the per-stage lookups are a
+    // bare v_readlane -- the per-lookup check costs ~10 scalar instructions in front of every block
+    auto lp_window = [&](int t) {
+        if (TEXT) return;
+        const int first = t >> 1, last = (t + 7) >> 1;
+        if (first < lbase || last >= lbase + 64) {
+            lbase = first;
+            lchunk = (lbase + lane < nkept) ? list[lbase + lane] : 0;
+            __builtin_amdgcn_s_waitcnt(0x0F70);
+        }
+    };
+    auto blk_fast = [&](int i) -> int {
+        if (i >= nkept) i = nkept - 1;
+        if (TEXT) return i;
+        return __builtin_amdgcn_readlane(lchunk, i - lbase);
+    };
     auto desc_k_at = [&](int t, int slot) {
         const int tc = t < 2 * nkept ? t : 2 * nkept - 1;
-        const int blk = blk_at(tc >> 1);
+        const int blk = blk_fast(tc >> 1);
         LpDma d;
         d.base = reinterpret_cast<const unsigned char*>(kbh) +
                  (unsigned long long)((unsigned)blk * 128u + (unsigned)(tc & 1) * 64u) * kss_b;
@@ -470,7 +509,7 @@ __device__ __forceinline__ void attn_block_lp(const LpParams& P, unsigned char* 
     };
     auto desc_v_at = [&](int t, int slot) {
         const int tc = t < 2 * nkept ? t : 2 * nkept - 1;
-        const int blk = blk_at(tc >> 1);
+        const int blk = blk_fast(tc >> 1);
         LpDma d;
         d.base = reinterpret_cast<const unsigned char*>(vbh) +
                  (unsigned long long)((unsigned)blk * 2u + (unsigned)(tc & 1)) * (128u * 64u * 2u);
@@ -575,6 +614,7 @@ __device__ __forceinline__ void attn_block_lp(const LpParams& P, unsigned char* 
 #ifndef JENGA_LP_NO_UNROLL
         if (!TEXT) {
             for (; t + 6 <= t_fast; t += 6) {
+                lp_window(t);
                 LP_STEP_C(t, 0); LP_STEP_C(t, 1); LP_STEP_C(t, 2); LP_STEP_C(t, 3); LP_STEP_C(t, 4); LP_STEP_C(t, 5);
             }
         }
