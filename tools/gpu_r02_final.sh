@@ -17,6 +17,16 @@ A)
   run 3stage --preset 3stage --no-cpu-baseline
   run 3stage_i2v --preset 3stage --i2v --no-cpu-baseline
   ;;
+A2)
+  run default_final
+  run full50 --steps 50 --warmup 1 --no-cpu-baseline
+  run turbo --preset turbo --no-cpu-baseline
+  run flash --preset flash --no-cpu-baseline
+  run 3stage --preset 3stage --no-cpu-baseline
+  run 3stage_i2v --preset 3stage --i2v --no-cpu-baseline
+  run sim8_base --simulate-ranks 8 --steps 3 --no-cpu-baseline
+  run sim8_turbo --simulate-ranks 8 --preset turbo-mgpu --steps 3 --no-cpu-baseline
+  ;;
 B)
   run peaky4 --peaky 4 --no-cpu-baseline
   run peaky8 --peaky 8 --no-cpu-baseline
