@@ -23,6 +23,14 @@
 // V one step of lead; `s_waitcnt vmcnt(4)` + s_barrier end a step.
 // Lazy integer running max without a first-tile case (m~ starts at 0, moves up or down by integers in the exact
 // path), whole-row sums in both half-lanes, dtype-dependent lower threshold: as in bsattn2.hip.
+//
+// The steady state of an image query block runs in a main loop unrolled over the six-step period of the two rings
+// (LP_STEP_C): ring slots are compile-time constants there and fold into the ds_read offset fields; the K fragments of
+// a tile's second half are requested under the first half's P.V MFMAs (PRE); the four LDS-DMA pieces of a stage go out
+// in MFMA slots 1 / 5 / 9 / 13 of a block; the kept-list window is checked once per six steps.  A wave's instruction
+// stream is in-order, so each of these took instructions out of the gaps between its MFMAs: MFMA-pipe busy 64 % -> 79 %
+// (profiles/r02_pmc_bsattn_lp*.json).  The first step, the < 6 remainder steps, the tail blocks that need text_amp or
+// the kv-length mask, and the text rows use the generic forms (LP_STEP, lp_slow_tile).
 #include "common.h"
 
 namespace jenga {
