@@ -33,6 +33,59 @@ __device__ __forceinline__ float block_reduce_sum(float v, float* scratch) {
 
 constexpr int MAX_PER_THREAD = 8;  // 256 threads x 8 = up to 2048 image key blocks
 
+// Bitonic sort (descending) of npow2 = 256 * E unique 32-bit keys held in LDS, E consecutive keys per thread in
+// registers: compare-exchange distances below E stay inside a thread, distances below 64 * E are wave shuffles, and
+// only the two or three largest distances go through LDS with a barrier (the plain LDS form below pays 55 barriers
+// at 1024 keys).  Keys are unique, so every correct sort gives the same order: results are unchanged bit for bit.
+template <int E>
+__device__ __forceinline__ void bitonic_sort_desc_regs(uint32_t* keys, int npow2, int tid) {
+    uint32_t v[E];
+#pragma unroll
+    for (int r = 0; r < E; ++r) v[r] = keys[tid * E + r];
+    for (int k = 2; k <= npow2; k <<= 1) {
+        int j = k >> 1;
+        for (; j >= E; j >>= 1) {   // partner element lives in thread tid ^ (j / E), same register index
+            const int pj = j / E;
+            uint32_t pv[E];
+            if (pj < 64) {
+#pragma unroll
+                for (int r = 0; r < E; ++r) pv[r] = (uint32_t)__shfl_xor((int)v[r], pj);
+            } else {
+                __syncthreads();
+#pragma unroll
+                for (int r = 0; r < E; ++r) keys[tid * E + r] = v[r];
+                __syncthreads();
+#pragma unroll
+                for (int r = 0; r < E; ++r) pv[r] = keys[(tid ^ pj) * E + r];
+            }
+            const int i0 = tid * E;   // (i & j) and (i & k) do not depend on r here: j, k >= E
+            const bool take_max = (((i0 & j) == 0) == ((i0 & k) == 0));
+#pragma unroll
+            for (int r = 0; r < E; ++r) v[r] = take_max ? (v[r] > pv[r] ? v[r] : pv[r]) : (v[r] < pv[r] ? v[r] : pv[r]);
+        }
+#pragma unroll
+        for (int jj = E / 2; jj > 0; jj >>= 1) {   // inside the thread, compile-time register indices
+            if (jj < k) {
+#pragma unroll
+                for (int r = 0; r < E; ++r) {
+                    if ((r & jj) == 0) {
+                        const int i = tid * E + r;
+                        const bool desc = ((i & k) == 0);
+                        const uint32_t a = v[r], b = v[r | jj];
+                        const bool sw = desc ? (a < b) : (a > b);
+                        v[r] = sw ? b : a;
+                        v[r | jj] = sw ? a : b;
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < E; ++r) keys[tid * E + r] = v[r];
+    __syncthreads();
+}
+
 template <typename T>
 __global__ void __launch_bounds__(256)
 block_select_kernel(const uint16_t* __restrict__ qpool, const uint16_t* __restrict__ kpool,
@@ -102,6 +155,11 @@ block_select_kernel(const uint16_t* __restrict__ qpool, const uint16_t* __restri
     }
     __syncthreads();
     // ---- bitonic sort, descending on (probability bits, then lower column first) ----
+    if (npow2 == 1024) bitonic_sort_desc_regs<4>(keys, npow2, tid);
+    else if (npow2 == 512) bitonic_sort_desc_regs<2>(keys, npow2, tid);
+    else if (npow2 == 256) bitonic_sort_desc_regs<1>(keys, npow2, tid);
+    else if (npow2 == 2048) bitonic_sort_desc_regs<8>(keys, npow2, tid);
+    else
     for (int k = 2; k <= npow2; k <<= 1) {
         for (int j = k >> 1; j > 0; j >>= 1) {
             for (int i = tid; i < npow2; i += 256) {
