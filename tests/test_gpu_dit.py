@@ -387,3 +387,19 @@ def test_stage_switch_on_device_vs_reference_composition(golden_dir, dev):
     assert out.device.type == "cuda" and out.dtype == torch.float32
     err = np.abs(out.cpu().numpy() - g["switched"])
     assert err.max() <= 1e-6 * max(1.0, np.abs(g["switched"]).max()), err.max()
+
+
+def test_wan_turbo_switch_on_device_vs_reference_scheduler(golden_dir, dev):
+    """Row f-4 on the GPU: wan_driver.wan_switch_stage with device tensors against the fixture generated from the
+    reference FlowUniPCMultistepScheduler (tests/golden/wan_sched_cases.npz); fp32 elementwise math + trilinear
+    interpolation: 1e-6 relative."""
+    import numpy as np
+    from jenga_amd.wan_driver import WanFlowSchedule, wan_switch_stage
+    g = np.load(os.path.join(golden_dir, "wan_sched_cases.npz"))
+    s = WanFlowSchedule(50, 3.0)
+    lat, npred, noise = (torch.from_numpy(g[k]).to(dev) for k in ("lat", "npred", "noise"))
+    out = wan_switch_stage(s, npred, 25, lat, (3, 8, 12), noise, 50)
+    assert out.device.type == "cuda" and out.dtype == torch.float32
+    err = np.abs(out.cpu().numpy() - g["switched"])
+    assert err.max() <= 1e-6 * max(1.0, np.abs(g["switched"]).max()), err.max()
+    assert np.array_equal(s.sigmas.numpy(), g["sigmas_after"]) and s.shift == 5.0

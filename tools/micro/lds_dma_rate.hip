@@ -75,11 +75,16 @@ template <int MODE> void run(const unsigned char* src, size_t span_tiles, int ti
     printf("%-28s span %8.1f MB: %7.3f ms  %6.2f TB/s  = %5.1f B/clk/CU at 2.0 GHz\n", name, span_tiles * 32768 / 1e6, ms,
            bytes / ms / 1e9, bytes / 256 / (ms * 1e-3 * 2.0e9));
 }
-int main() {
+int main(int argc, char** argv) {
     const size_t maxbytes = (2048ull << 20) + (1 << 20);
     unsigned char* src; hipMalloc(&src, maxbytes); hipMemset(src, 1, maxbytes);
     float* out; hipMalloc(&out, 512 * 256 * 4);
     const int tiles = 2000;
+    if (argc > 1) {   // "sweep": the delivery rate against the size of the window the tiles are drawn from
+        for (size_t mb : {1ul, 2ul, 4ul, 8ul, 16ul, 24ul, 32ul, 48ul, 64ul, 96ul, 128ul, 192ul, 256ul, 384ul, 512ul, 2048ul})
+            run<0>(src, (mb << 20) / 32768, tiles, out, "LDS-DMA");
+        return 0;
+    }
     for (size_t mb : {1ul, 16ul, 128ul, 2048ul}) {
         run<0>(src, (mb << 20) / 32768, tiles, out, "LDS-DMA");
         run<2>(src, (mb << 20) / 32768, tiles, out, "LDS-DMA, XOR-swizzled source");
