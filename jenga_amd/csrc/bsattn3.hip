@@ -538,7 +538,13 @@ __device__ __forceinline__ void attn_block_lp(const LpParams& P, unsigned char* 
             if (bl >= P.text_block_start || (bl + 1) * 128 > seqlen) --n_fast; else break;
         }
     }
-    const int t_fast = 2 * n_fast, t_all = 2 * nkept;
+    // tiles lying entirely behind the kv length contribute exp2(-inf) = 0: not staged at all (the list is ascending,
+    // so they are its last tiles -- with 64 valid text tokens: the second half of text block 0 and all of block 1)
+    int t_all = 2 * nkept;
+    if (!TEXT) {
+        while (t_all > 0 && blk_at((t_all - 1) >> 1) * 128 + ((t_all - 1) & 1) * 64 >= seqlen) --t_all;
+    }
+    const int t_fast = 2 * n_fast < t_all ? 2 * n_fast : t_all;
 
     f32x16 sA, sB;
     uint4 pfA[2], pfB[2];
