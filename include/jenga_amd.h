@@ -206,6 +206,9 @@ int jenga_bsattn_fwd(void* stream, const void* q, const void* k, const void* vt,
  *   jenga_bsattn_pair_fwd: same arguments and semantics as jenga_bsattn_fwd with (pidx, pcnt) in place of (idx, cnt).
  *       The kv blocks of a row are visited in the order (only-this-row, shared) instead of ascending; online softmax
  *       is order independent up to fp32 rounding and every rescale stays an exact power of two. */
+/*   flags of jenga_bsattn_pair_fwd: JENGA_ATTN_XCD_REMAP; with JENGA_ATTN_LP the 8-wave "LP pair" experiment runs
+ *   instead (csrc/bsattn4.hip: two query blocks per 512-thread workgroup, shared kv blocks staged once for both;
+ *   restriction: no masked image block in an unshared list, i.e. seqlens >= the image length). */
 int jenga_pair_merge(void* stream, const int32_t* idx, const int32_t* cnt, int64_t B, int64_t H, int64_t nq_img,
                      int64_t n_blocks, int32_t* pidx, int32_t* pcnt);
 int jenga_bsattn_pair_fwd(void* stream, const void* q, const void* k, const void* vt, void* o,

@@ -14,6 +14,7 @@ ATTN_XCD_REMAP = 1
 ATTN_PINGPONG = 2
 ATTN_LEGACY = 4      # (Python-side switch) the round-1 kernel: one 128-row query block per 4-wave workgroup
 ATTN_LP = 8          # round-1 decomposition + in-wave software pipeline (csrc/bsattn3.hip)
+ATTN_PAIR = 64       # (Python-side switch) with ATTN_LP: the 8-wave LP pair experiment (csrc/bsattn4.hip)
 ATTN_DEFAULT_FLAGS = int(os.environ.get("JENGA_ATTN_FLAGS", str(ATTN_XCD_REMAP | 8)))   # LP kernel (csrc/bsattn3.hip)
 
 _vp, _i64, _i32, _f32 = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_float
@@ -449,7 +450,7 @@ def bsattn_fwd(q, k, vt, seqlens, idx, cnt, nq_img, sm_scale, text_amp, text_blo
     fl = ATTN_DEFAULT_FLAGS if flags is None else flags
     if not xcd_remap:
         fl &= ~ATTN_XCD_REMAP
-    legacy = bool(fl & (ATTN_LEGACY | ATTN_PINGPONG | ATTN_LP))
+    legacy = bool(fl & (ATTN_LEGACY | ATTN_PINGPONG | ATTN_LP)) and not (fl & ATTN_PAIR)
     prof = ATTN_PROFILE
     with torch.cuda.device(q.device):
         pidx = pcnt = None
@@ -465,7 +466,8 @@ def bsattn_fwd(q, k, vt, seqlens, idx, cnt, nq_img, sm_scale, text_amp, text_blo
                                           _p(cnt), *common, fl & ~ATTN_LEGACY), "jenga_bsattn_fwd")
         else:
             _check(lib().jenga_bsattn_pair_fwd(_stream(q.device), _p(q), _p(k), _p(vt), _p(out), _p(seqlens),
-                                               _p(pidx), _p(pcnt), *common, fl), "jenga_bsattn_pair_fwd")
+                                               _p(pidx), _p(pcnt), *common, fl & ~(ATTN_PAIR | ATTN_LEGACY)),
+                   "jenga_bsattn_pair_fwd")
         if prof is not None:
             e1.record()
             prof.events.append((e0, e1))

@@ -25,6 +25,7 @@ SOURCES = [
     # instruction table); the softmax of the pair kernel is placed instruction by instruction into the MFMA gaps
     ("bsattn2.hip", ["-fno-honor-nans", "-fno-slp-vectorize"]),
     ("bsattn3.hip", ["-fno-honor-nans", "-fno-slp-vectorize"]),
+    ("bsattn4.hip", ["-fno-honor-nans", "-fno-slp-vectorize"]),
 ]
 
 

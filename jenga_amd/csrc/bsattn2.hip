@@ -846,6 +846,10 @@ extern "C" int jenga_bsattn_pair_fwd(void* stream, const void* q, const void* k,
         set_error("jenga_bsattn_pair_fwd: key sequence stride %lld out of range", (long long)k_ss);
         return JENGA_EINVAL;
     }
+    if (flags & JENGA_ATTN_LP)   // the 8-wave LP pair experiment (bsattn4.hip)
+        return jenga_bsattn_lp2_launch(stream, q, k, vt, o, seqlens, pidx, pcnt, B, H, n_blocks, nq_img, q_sb, q_ss, q_sh,
+                                       k_sb, k_ss, k_sh, o_sb, o_ss, o_sh, sm_scale, text_amp, text_block_start, dtype,
+                                       flags);
     PairParams P;
     P.q = (const uint16_t*)q;
     P.k = (const uint16_t*)k;

@@ -89,6 +89,12 @@ int jenga_bsattn_lp_launch(void* stream, const void* q, const void* k, const voi
                            int64_t nq_img, int64_t q_sb, int64_t q_ss, int64_t q_sh, int64_t k_sb, int64_t k_ss,
                            int64_t k_sh, int64_t o_sb, int64_t o_ss, int64_t o_sh, float sm_scale, float text_amp,
                            int64_t text_block_start, int dtype, int flags);
+// bsattn4.hip: the launcher behind jenga_bsattn_pair_fwd(..., flags & JENGA_ATTN_LP); arguments already validated
+int jenga_bsattn_lp2_launch(void* stream, const void* q, const void* k, const void* vt, void* o, const int32_t* seqlens,
+                           const int32_t* pidx, const int32_t* pcnt, int64_t B, int64_t H, int64_t n_blocks,
+                           int64_t nq_img, int64_t q_sb, int64_t q_ss, int64_t q_sh, int64_t k_sb, int64_t k_ss,
+                           int64_t k_sh, int64_t o_sb, int64_t o_ss, int64_t o_sh, float sm_scale, float text_amp,
+                           int64_t text_block_start, int dtype, int flags);
 
 namespace jenga {
 

@@ -1,0 +1,334 @@
+// Shared device code of the LP attention kernels (bsattn3.hip: one query block per 4-wave workgroup; bsattn4.hip: two
+// query blocks per 8-wave workgroup sharing staged tiles): LDS tile geometry, LDS-DMA helpers, the per-wave softmax
+// state, the exact (max-first) path, the 16-slot pipelined basic block lp_bb and the unpipelined tail tile.
+// See the header of bsattn3.hip for the design.
+#pragma once
+#include "common.h"
+
+namespace jenga {
+namespace {
+
+constexpr int LP_TILE = 16384;
+constexpr int LP_K_RING = 0;               // 3 slots: tile t in slot t % 3
+constexpr int LP_V_RING = 3 * LP_TILE;     // 2 slots: tile t in slot t & 1
+constexpr int LP_LDS_BYTES = 5 * LP_TILE;  // 80 KiB: two workgroups per CU
+
+constexpr float LP_RAISE_SUM = 256.0f;
+template <typename T> __device__ __forceinline__ constexpr float lp_tiny();
+template <> __device__ __forceinline__ constexpr float lp_tiny<BF16>() { return 8.673617379884035e-19f; }   // 2^-60
+template <> __device__ __forceinline__ constexpr float lp_tiny<FP16>() { return 0.0625f; }                   // 2^-4
+
+// four 1-KiB LDS-DMA pieces of one tile (see bsattn2.hip: immediate offsets, piece i's lane offsets biased by -1024 i)
+__device__ __forceinline__ void lp_stage4(const void* base, unsigned lds, unsigned o0, unsigned o1, unsigned o2,
+                                          unsigned o3) {
+#ifdef JENGA_X_NODMA
+    return;
+#endif
+    asm volatile("s_mov_b32 m0, %0\n\t"
+                 "s_nop 0\n\t"
+                 "global_load_lds_dwordx4 %2, %1\n\t"
+                 "global_load_lds_dwordx4 %3, %1 offset:1024\n\t"
+                 "global_load_lds_dwordx4 %4, %1 offset:2048\n\t"
+                 "global_load_lds_dwordx4 %5, %1 offset:3072"
+                 :
+                 : "s"(lds), "s"(base), "v"(o0), "v"(o1), "v"(o2), "v"(o3)
+                 : "memory");
+}
+// one piece: in the unrolled main loop the four pieces of a stage go out in four MFMA slots of the block (1, 5, 9,
+// 13) instead of back to back in front of it -- less queueing in the vector-memory path, +2 % sustained
+// (JENGA_LP_NO_DMA_SPREAD restores the up-front form)
+struct LpDma {
+    const void* base;
+    unsigned lds;
+    unsigned o[4];
+};
+template <int I>
+__device__ __forceinline__ void lp_stage1(const LpDma& d) {
+#ifdef JENGA_X_NODMA
+    return;
+#endif
+    if (I == 0)
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %1" : : "s"(d.lds), "s"(d.base), "v"(d.o[0]) : "memory");
+    else if (I == 1)
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %1 offset:1024" : : "s"(d.lds), "s"(d.base), "v"(d.o[1]) : "memory");
+    else if (I == 2)
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %1 offset:2048" : : "s"(d.lds), "s"(d.base), "v"(d.o[2]) : "memory");
+    else
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %1 offset:3072" : : "s"(d.lds), "s"(d.base), "v"(d.o[3]) : "memory");
+}
+#define LP_WAIT_ALL() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#ifdef JENGA_X_NOWAIT
+#define LP_WAIT_KEEP4()
+#else
+#define LP_WAIT_KEEP4() asm volatile("s_waitcnt vmcnt(4)" ::: "memory")
+#endif
+
+struct LpState {
+    uint4 qf[8];
+    f32x16 o[4];
+    float l;       // whole-row running sum (identical in the two lanes that share a row)
+    float neg_m;   // -m~
+    f32x16 cinit;  // 16 copies of -m~: C operand of the first QK^T MFMA of an item (image rows), so that the scores
+                   // arrive as S - m~ and the softmax saves one VALU instruction per score
+};
+
+// exact (max-first) softmax of one 32-key item from its intact scores
+// `s`: raw scores (TEXT) or S - m~(old) (image rows).  `pend`: scores of the NEXT item, already produced against the
+// old m~ (or null).
+template <typename T, bool TEXT>
+__device__ __forceinline__ void lp_exact(LpState& st, const f32x16& s, uint4 (&pf)[2], float& psum, float qk_scale,
+                                         f32x16* pend) {
+    float v[16];
+    float tmax = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        v[r] = TEXT ? s[r] * qk_scale + st.neg_m : s[r];
+        tmax = fmaxf(tmax, v[r]);
+    }
+    tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+    const bool move = (tmax > 0.f) || (st.l + psum < lp_tiny<T>());
+    const float delta = (move && tmax > -1e30f) ? fmaxf(ceilf(tmax), -120.f) : 0.f;
+    const float f2 = __builtin_amdgcn_exp2f(-delta);
+    st.neg_m -= delta;
+    st.l *= f2;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) st.o[i][r] *= f2;
+    if (!TEXT) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) st.cinit[r] = st.neg_m;
+        if (pend) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) (*pend)[r] -= delta;
+        }
+    }
+    float e[16];
+    psum = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        e[r] = __builtin_amdgcn_exp2f(v[r] - delta);
+        psum += e[r];
+    }
+    psum += __shfl_xor(psum, 32);
+    pf[0] = make_uint4(pack2<T>(e[0], e[1]), pack2<T>(e[2], e[3]), pack2<T>(e[4], e[5]), pack2<T>(e[6], e[7]));
+    pf[1] = make_uint4(pack2<T>(e[8], e[9]), pack2<T>(e[10], e[11]), pack2<T>(e[12], e[13]), pack2<T>(e[14], e[15]));
+}
+
+// One basic block of the pipeline (see the header).  HALF: which 32-key half of the 64-key tiles kt (item i) and vt
+// (item i-2) this block works on.
+// KOFF / VOFF: byte offset of the ring slot inside the K / V^T ring when it is known at compile time (the unrolled
+// main loop) -- it then folds into the ds_read offset field together with the HALF / d-block offsets and the eight K
+// + two V^T per-item address adds disappear; -1: the slot is in the pointer (kt / vt = smem + slot * LP_TILE).
+// PRE: 1 = during its P.V MFMAs this (HALF 0) block also issues the K fragment reads of the NEXT block (HALF 1 of the
+// same tile, into frk, which lives in the caller), 2 = this block's K fragments were issued that way (no up-front
+// reads): the fragment pipeline then runs through the block boundary instead of draining and refilling there.
+template <typename T, bool TEXT, int HALF, bool DO_PV, bool DO_QK, bool DO_SM, int KOFF = -1, int VOFF = -1, int PRE = 0>
+__device__ __forceinline__ void lp_bb(LpState& st, const unsigned char* kt, const unsigned char* vt, f32x16& sn,
+                                      const f32x16& sp, const uint4 (&pf_old)[2], uint4 (&pf_new)[2],
+                                      const int (&k_addr)[8], const int (&v_addr)[4], float qk_scale,
+                                      uint4 (&frk)[8], const LpDma* dma = nullptr) {
+    constexpr int KO = KOFF < 0 ? 0 : KOFF, VO = VOFF < 0 ? 0 : VOFF;
+    static_assert(PRE == 0 || (DO_QK && DO_PV), "the cross-block fragment pipeline is for full blocks");
+    static_assert(PRE != 1 || HALF == 0, "only the first half prefetches (the next tile may still be in flight)");
+    f32x16 zero16;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) zero16[r] = 0.f;
+    uint4 frv[8];
+    float tt[16], xx[16];
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    float half_ = 0.f;
+    uint32_t ww[8];
+#ifdef JENGA_X_NOREADS      /* EXPERIMENT (wrong results): no fragment reads at all */
+#define LP_RD_ON(F_) false
+#elif defined(JENGA_X_HALFREADS)   /* EXPERIMENT (wrong results): every second fragment read skipped */
+#define LP_RD_ON(F_) (((F_) & 1) == 0)
+#else
+#define LP_RD_ON(F_) true
+#endif
+#define LP_READ(F_)                                                                                                   \
+    do {                                                                                                              \
+        if (!LP_RD_ON(F_)) {                                                                                          \
+            if ((F_) < 8) frk[(F_) & 7] = frk[((F_) & 7) ^ 1];                                                        \
+            else if ((F_) < 16) frv[(F_) & 7] = frv[((F_) & 7) ^ 1];                                                  \
+        } else if ((F_) < 8) {                                                                                        \
+            if (DO_QK) frk[(F_) & 7] = *reinterpret_cast<const uint4*>(kt + k_addr[(F_) & 7] + (HALF * 8192 + KO));   \
+        } else if ((F_) < 16) {                                                                                       \
+            if (DO_PV) frv[(F_) & 7] = *reinterpret_cast<const uint4*>(vt + v_addr[2 * HALF + (((F_) - 8) >> 2)] +    \
+                                                                       ((((F_) - 8) & 3) * 4096 + VO));               \
+        } else if ((F_) < 24 && PRE == 1) { /* K fragment (F_ - 16) of the next block: the other half of this tile */ \
+            frk[(F_) & 7] = *reinterpret_cast<const uint4*>(kt + k_addr[(F_) & 7] + (8192 + KO));                     \
+        }                                                                                                             \
+    } while (0)
+#ifdef JENGA_X_NOSM
+#define LP_SM_ON false
+#else
+#define LP_SM_ON true
+#endif
+    /* image rows: the scores are S - m~ already (C operand); TEXT rows: raw scores, scaled and shifted here.
+       Image rows: all 16 scores exist when the block starts, so element e is exponentiated in slot X(e) = e / 2 for
+       e < 4, e - 2 after that, added / packed one slot later, and the 4-way sum tree closes in slot 15: what is left
+       behind the last MFMA is the cross-half permlane and the ballot.  TEXT rows keep the three-stage form (their
+       scale-and-shift stage needs a slot of its own) that ends two slots later. */
+#define LP_SM_X(E_) ((E_) < 4 ? ((E_) >> 1) : (E_) - 2)
+#define LP_SM(M_)                                                                                                     \
+    do {                                                                                                              \
+        if (DO_SM && LP_SM_ON) {                                                                                      \
+            if (TEXT) {                                                                                               \
+                if ((M_) < 16) tt[(M_) & 15] = sp[(M_) & 15] * qk_scale + st.neg_m;                                   \
+                if ((M_) >= 1 && (M_) < 17) xx[((M_) - 1) & 15] = __builtin_amdgcn_exp2f(tt[((M_) - 1) & 15]);        \
+                if ((M_) >= 2 && (M_) < 18) {                                                                         \
+                    if ((M_) < 6) acc[((M_) - 2) & 3] = xx[((M_) - 2) & 15];                                          \
+                    else acc[((M_) - 2) & 3] += xx[((M_) - 2) & 15];                                                  \
+                    if (((M_) - 2) & 1) {                                                                             \
+                        ww[(((M_) - 2) & 15) >> 1] = pack2<T>(xx[((M_) - 3) & 15], xx[((M_) - 2) & 15]);              \
+                        asm volatile("" : "+v"(ww[(((M_) - 2) & 15) >> 1]));   /* stay in this slot */                \
+                    }                                                                                                 \
+                }                                                                                                     \
+                if ((M_) == 17) half_ = (acc[0] + acc[1]) + (acc[2] + acc[3]);                                        \
+            } else {                                                                                                  \
+                _Pragma("unroll") for (int e_ = 0; e_ < 16; ++e_) {                                                   \
+                    if (LP_SM_X(e_) + 1 == (M_)) {                                                                    \
+                        if (e_ < 4) acc[e_ & 3] = xx[e_]; else acc[e_ & 3] += xx[e_];                                 \
+                        if (e_ & 1) {                                                                                 \
+                            ww[e_ >> 1] = pack2<T>(xx[e_ - 1], xx[e_]);                                               \
+                            asm volatile("" : "+v"(ww[e_ >> 1]));   /* stay in this slot */                           \
+                        }                                                                                             \
+                    }                                                                                                 \
+                }                                                                                                     \
+                _Pragma("unroll") for (int e_ = 0; e_ < 16; ++e_)                                                     \
+                    if (LP_SM_X(e_) == (M_)) xx[e_] = __builtin_amdgcn_exp2f(sp[e_]);                                 \
+                if ((M_) == 15) half_ = (acc[0] + acc[1]) + (acc[2] + acc[3]);                                        \
+            }                                                                                                         \
+        }                                                                                                             \
+    } while (0)
+#ifdef JENGA_X_NOMFMA       /* EXPERIMENT (wrong results): MFMAs replaced by one cheap VALU op each */
+#define LP_MFMA(D_, A_, B_, C_) do { D_ = C_; D_[0] += __uint_as_float((A_).x ^ (B_).x); } while (0)
+#else
+#define LP_MFMA(D_, A_, B_, C_) D_ = mfma32<T>(A_, B_, C_)
+#endif
+    /* fragment reads go out two at a time, eight MFMAs ahead (slot m, m even, reads the fragments of MFMAs m+8 and
+       m+9), with ONE explicit counted s_waitcnt lgkmcnt per two MFMAs (the compiler would emit one per MFMA).
+       Before MFMA m (even) fragments m, m+1 must be there; the reads issued behind them are m+2 .. min(m+7, 15). */
+#define LP_LGKM(N_)                                                                                                   \
+    do {                                                                                                              \
+        if ((N_) == 0) __builtin_amdgcn_s_waitcnt(0xC07F);                                                            \
+        else if ((N_) == 2) __builtin_amdgcn_s_waitcnt(0xC27F);                                                       \
+        else if ((N_) == 4) __builtin_amdgcn_s_waitcnt(0xC47F);                                                       \
+        else if ((N_) == 6) __builtin_amdgcn_s_waitcnt(0xC67F);                                                       \
+        else if ((N_) == 8) __builtin_amdgcn_s_waitcnt(0xC87F);                                                       \
+        else __builtin_amdgcn_s_waitcnt(0xC07F);                                                                      \
+    } while (0)
+#define LP_SLOT(M_)                                                                                                   \
+    do {                                                                                                              \
+        if (!((M_) & 1) && (((M_) < 8 && DO_QK) || ((M_) >= 8 && DO_PV))) {                                           \
+            if (!DO_QK) LP_LGKM(14 - (M_) > 8 ? 0 : 14 - (M_));   /* drain forms: fragments 8..15 read up front */    \
+            else if (PRE == 1) LP_LGKM(6);   /* the next block's reads keep the queue at eight */                     \
+            else LP_LGKM((M_) <= 8 ? 6 : 14 - (M_));                                                                  \
+            __builtin_amdgcn_sched_barrier(0);   /* or hipcc moves the MFMA above the wait and adds its own */        \
+        }                                                                                                             \
+        if ((M_) < 8) {                                                                                               \
+            if (DO_QK) {                                                                                              \
+                if ((M_) == 0) { if (TEXT) LP_MFMA(sn, frk[(M_) & 7], st.qf[(M_) & 7], zero16); else LP_MFMA(sn, frk[(M_) & 7], st.qf[(M_) & 7], st.cinit); } \
+                else LP_MFMA(sn, frk[(M_) & 7], st.qf[(M_) & 7], sn);                                                 \
+            }                                                                                                         \
+        } else if (DO_PV) {                                                                                           \
+            LP_MFMA(st.o[((M_) - 8) & 3], frv[(M_) & 7], pf_old[((M_) - 8) >> 2], st.o[((M_) - 8) & 3]);              \
+        }                                                                                                             \
+        if (((M_) & 1) == 0) {                                                                                        \
+            LP_READ((M_) + 8); LP_READ((M_) + 9);                                                                     \
+        }                                                                                                             \
+        if (dma) {                                                                                                    \
+            if ((M_) == 1) lp_stage1<0>(*dma);                                                                        \
+            if ((M_) == 5) lp_stage1<1>(*dma);                                                                        \
+            if ((M_) == 9) lp_stage1<2>(*dma);                                                                        \
+            if ((M_) == 13) lp_stage1<3>(*dma);                                                                       \
+        }                                                                                                             \
+        LP_SM(M_);                                                                                                    \
+        __builtin_amdgcn_sched_barrier(0);                                                                            \
+    } while (0)
+    if (PRE != 2) {
+        LP_READ(0); LP_READ(1); LP_READ(2); LP_READ(3); LP_READ(4); LP_READ(5); LP_READ(6); LP_READ(7);
+    }
+    if (!DO_QK) {
+        LP_READ(8); LP_READ(9); LP_READ(10); LP_READ(11); LP_READ(12); LP_READ(13); LP_READ(14); LP_READ(15);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    LP_SLOT(0); LP_SLOT(1); LP_SLOT(2); LP_SLOT(3); LP_SLOT(4); LP_SLOT(5); LP_SLOT(6); LP_SLOT(7);
+    LP_SLOT(8); LP_SLOT(9); LP_SLOT(10); LP_SLOT(11); LP_SLOT(12); LP_SLOT(13); LP_SLOT(14); LP_SLOT(15);
+    LP_SM(16);
+    LP_SM(17);
+#undef LP_READ
+#undef LP_SM
+#undef LP_SM_X
+#undef LP_SLOT
+#undef LP_MFMA
+#undef LP_LGKM
+    if (DO_SM) {
+        const auto sw_ = __builtin_amdgcn_permlane32_swap(__float_as_uint(half_), __float_as_uint(half_), false, false);
+        float psum = __uint_as_float(sw_[0]) + __uint_as_float(sw_[1]);   // both half-lanes: the row's 32 keys
+        pf_new[0] = make_uint4(ww[0], ww[1], ww[2], ww[3]);
+        pf_new[1] = make_uint4(ww[4], ww[5], ww[6], ww[7]);
+#ifdef JENGA_X_NOSM
+        psum = 1.f + sp[0] * 1e-30f;
+        pf_new[0] = pf_new[1] = make_uint4(0x3c003c00u, 0x3c003c00u, 0x3c003c00u, 0x3c003c00u);
+#else
+        // two ballots straight off the compares (a ballot of an OR-ed condition goes through v_cndmask + v_cmp_ne)
+        if ((__builtin_amdgcn_ballot_w64(!(psum <= LP_RAISE_SUM)) |
+             __builtin_amdgcn_ballot_w64(st.l + psum < lp_tiny<T>())) != 0ull)
+            lp_exact<T, TEXT>(st, sp, pf_new, psum, qk_scale, DO_QK ? &sn : nullptr);
+#endif
+        st.l += psum;
+    }
+}
+
+// a whole 64-key tile, unpipelined, with the text_amp add and the kv-length mask (tail of the ascending lists)
+template <typename T>
+__device__ __forceinline__ void lp_slow_tile(LpState& st, const unsigned char* kt, const unsigned char* vt, int key0,
+                                             bool amp_on, float text_amp, int seqlen, int hi,
+                                             const int (&k_addr)[8], const int (&v_addr)[4]) {
+    if (key0 >= seqlen) return;   // contributes exp2(-inf) = 0
+    f32x16 zero16;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) zero16[r] = 0.f;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        f32x16 s;
+        {
+            uint4 ka[8];
+#pragma unroll
+            for (int ds = 0; ds < 8; ++ds) ka[ds] = *reinterpret_cast<const uint4*>(kt + k_addr[ds] + half * 8192);
+            s = mfma32<T>(ka[0], st.qf[0], st.cinit);   // S - m~
+#pragma unroll
+            for (int ds = 1; ds < 8; ++ds) s = mfma32<T>(ka[ds], st.qf[ds], s);
+        }
+        if (amp_on) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[r] += text_amp;
+        }
+        if (key0 + 64 > seqlen) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int kk = key0 + half * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                if (kk >= seqlen) s[r] = -INFINITY;
+            }
+        }
+        uint4 pf[2];
+        float psum = 0.f;
+        lp_exact<T, false>(st, s, pf, psum, 0.f, nullptr);
+        st.l += psum;
+        uint4 va[2][4];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int db = 0; db < 4; ++db)
+                va[ks][db] = *reinterpret_cast<const uint4*>(vt + v_addr[2 * half + ks] + db * 4096);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int db = 0; db < 4; ++db) st.o[db] = mfma32<T>(va[ks][db], pf[ks], st.o[db]);
+    }
+}
+
+}  // namespace
+}  // namespace jenga
