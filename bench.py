@@ -5,6 +5,7 @@ at Jenga-Base settings, on N GPUs of one node (Ulysses sequence parallelism over
     python bench.py --gpus 1 --steps 6 --warmup 1
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N ...        (no launcher: re-executes itself under torch.distributed.run, same thing)
 
 A "step" is one scheduler step of the 50-step loop = one call of the (synthetic-weight, full-size) DiT with the
 Jenga forward: Hilbert gather -> 20 double + 40 single blocks (QKV GEMMs, fused RMSNorm+RoPE, block selection,
@@ -30,6 +31,7 @@ sys.path.insert(0, ROOT)
 
 MFMA_PEAK_TFLOPS = 2500.0  # dense bf16, /opt/skills/guides/MI355X_MICROARCH.md
 FLOPS_PER_PAIR = 4 * 128 ** 3  # one 128x128 query block against one 128-key block, head_dim 128: QK^T + PV
+PMC_FILE = "r02_pmc_bsattn_lp.json"   # the counter passes `roofline.traffic` is derived from (profiles/)
 
 
 PRESETS = {   # scripts/hyvideo_jenga_{base,turbo,flash,3stage}.sh and scripts/hyvideo_multigpu_jenga_*.sh
@@ -43,6 +45,9 @@ PRESETS = {   # scripts/hyvideo_jenga_{base,turbo,flash,3stage}.sh and scripts/h
     "turbo-mgpu": dict(res=[0.75, 1.0], steps=[0.5, 1.0], rates=[0.75, 0.85], shifts=[7, 9], p=0.3),
     "flash-mgpu": dict(res=[0.75, 1.0], steps=[0.5, 1.0], rates=[0.8, 0.95], shifts=[7, 9], p=0.5),
     "3stage-mgpu": dict(res=[0.5, 0.75, 1.0], steps=[0.3, 0.5, 1.0], rates=[0.75, 0.85, 0.85], shifts=[7, 9, 11], p=0.3),
+    # the un-accelerated model (README.md:80-82 "HunyuanVideo" row, 1625 s on one H800): sa-drop 0 takes the dense
+    # branch of the blocks (models_mul...:254-258), no step skipping (enable_skip is a Jenga switch): 50 computed steps
+    "dense": dict(res=[1.0, 1.0], steps=[0.5, 1.0], rates=[0.0, 0.0], shifts=[7, 7], p=0.3, skip=False),
 }
 
 
@@ -70,6 +75,13 @@ def parse():
                     help="HunyuanVideo-I2V flavour: token_replace modulation of the first latent frame, 512 text tokens "
                          "(4 text blocks) -- BASELINE.json configs[4] with --preset 3stage")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-dense-ref", action="store_true",
+                    help="skip the ONE dense (sa-drop 0) computed step that is run after the timed region to report "
+                         "speedup_vs_dense (the reference's own headline: 1625 s -> 310 s, README.md:80-82)")
+    ap.add_argument("--coherent", type=float, default=0.0, metavar="SMOOTH",
+                    help="> 0: spatially smooth synthetic latents (white noise at 1/SMOOTH of the latent resolution, "
+                         "upsampled trilinearly, + 10 %% white noise) instead of iid noise: Hilbert-adjacent query blocks "
+                         "then see similar keys and keep similar block lists, as a trained model's do (SURVEY.md 8(d))")
     ap.add_argument("--simulate-ranks", type=int, default=0,
                     help="diagnostic, single process: run rank 0's share of an N-rank Ulysses job (per-rank shapes, "
                          "pack / unpack kernels, 24/N heads) with the exchanges replaced by local copies -- the "
@@ -77,6 +89,17 @@ def parse():
     return ap.parse_args()
 
 
+
+
+def launch_command(n_gpus, argv, port=None):
+    """The command `python bench.py --gpus N` re-executes itself as when no launcher set WORLD_SIZE."""
+    if port is None:
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}",
+            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
 
 
 def stage_of(i, split):
@@ -158,9 +181,16 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # called bare (`python bench.py --gpus 8 ...`): become the launcher -- one rank per GPU under
+        # torch.distributed.run, rendezvous on 127.0.0.1 (the reference's scripts/hyvideo_multigpu_jenga_base.sh:7 uses
+        # torchrun the same way).  Under an external torchrun WORLD_SIZE is set and this branch is not taken.
+        cmd = launch_command(a.gpus, sys.argv[1:])
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        sys.stdout.flush()
+        os.execv(cmd[0], cmd)
     if a.gpus != world:
-        if world == 1 and a.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run for --gpus > 1")
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch one rank per GPU")
     assert torch.cuda.is_available(), "bench.py needs a GPU"
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
@@ -245,15 +275,27 @@ def main():
     shapes, split = prores.stage_plan((T, Hh, W), 50, preset["res"], preset["steps"])
     g = torch.Generator(device=dev).manual_seed(42)
     stages = []
+    amps = prores.stage_text_amps(shapes)   # stage 0 carries the amplifier, every later stage 0.0 (:577, :755)
+
+    def synth_latents(shp):
+        if a.coherent > 0:
+            lo = [max(2, int(round(d / a.coherent))) for d in shp]
+            base_ = torch.randn(1, 16, *lo, generator=g, device=dev, dtype=torch.float32)
+            x_ = torch.nn.functional.interpolate(base_, size=list(shp), mode="trilinear", align_corners=False)
+            x_ = x_ / x_.std() + 0.1 * torch.randn(1, 16, *shp, generator=g, device=dev, dtype=torch.float32)
+            return x_.to(torch.bfloat16)
+        return torch.randn(1, 16, *shp, generator=g, device=dev, dtype=torch.bfloat16)
+
     for k, shp in enumerate(shapes):      # static geometry + synthetic latents per resolution stage
         cos_k, sin_k = model.set_stage(shp, dev)
         stages.append(dict(shape=shp, cos=cos_k, sin=sin_k, curve=model.curve_sel, l2h=model.linear_to_hilbert,
                            h2l=model.hilbert_order,
-                           latents=torch.randn(1, 16, *shp, generator=g, device=dev, dtype=torch.bfloat16),
-                           text_amp=prores.stage_text_amp(shp, shapes[-1]) if preset["res"][k] != 1.0 else 0.0))
+                           latents=synth_latents(shp),
+                           text_amp=amps[k]))
     # steps forced to compute by `start_stage` right after a resolution switch (:755)
     forced = {split[k] + 1 for k in range(len(split) - 1) if preset["res"][k] != 1.0}
-    computed_steps = sorted(set(NON_SKIP_STEPS) | forced)
+    do_skip = preset.get("skip", True)
+    computed_steps = sorted(set(NON_SKIP_STEPS) | forced) if do_skip else list(range(50))
     sched = prores.FlowMatchSchedule(50, shift=preset["shifts"][0])
     g2 = torch.Generator(device=dev).manual_seed(43)
     n_txt = 512 if a.i2v else 256
@@ -266,7 +308,7 @@ def main():
     model.i2v_condition_type = "token_replace" if a.i2v else None
     model.text_amp = 0.0
     model.num_steps = 50
-    model.enable_skip = True
+    model.enable_skip = do_skip
 
     def run_step(i):
         k = stage_of(i, split)
@@ -330,6 +372,30 @@ def main():
         elapsed = float(tt.item())
     finite = bool(torch.isfinite(out.float()).all().item())
 
+    # ---- the un-accelerated model beside it (NOT in the timed region): ONE computed step with sa-drop 0 at the final
+    #      resolution, no skipping; its loop is 50 such steps (README.md:80-82: 1625 s dense vs 310 s Jenga-Base)
+    dense_ms = None
+    if not a.no_dense_ref and a.preset != "dense":
+        from jenga_amd.modules import attention as _att
+        st = stages[-1]
+        if world == 1 and sim <= 1:
+            _att._dense_lists(dev, 1, model.heads_num, (st["h2l"].numel() + n_txt) // 128)   # built once, outside the timing
+        model.curve_sel, model.linear_to_hilbert, model.hilbert_order = st["curve"], st["l2h"], st["h2l"]
+        model.cnt, model.sa_drop_rate, model.text_amp, model.start_stage, model.enable_skip = 0, 0.0, 0.0, False, False
+        barrier()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        model(st["latents"], sched.timesteps[0:1].to(dev), text_states=text, text_mask=text_mask, text_states_2=text2,
+              freqs_cos=st["cos"], freqs_sin=st["sin"], guidance=guidance, return_dict=False)
+        e1.record()
+        barrier()
+        dense_ms = e0.elapsed_time(e1)
+        if world > 1:
+            tt = torch.tensor([dense_ms], device=dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dense_ms = float(tt.item())
+        model.enable_skip = do_skip
+
     cls = {}
     for i, e0, e1 in evs:
         cls.setdefault(klass(i), []).append(e0.elapsed_time(e1))
@@ -354,12 +420,23 @@ def main():
         sec_per_video = elapsed * 50.0 / len(plan)
         unsampled = []
     ps = prof.summary()
-    traffic = None
-    try:   # HBM-side bytes per launch from the committed PMC passes (profiles/), scaled by this run's kept pairs
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_bsattn_lp.json")))
-        traffic = int(pmc["derived"]["traffic_bytes_per_kept_pair"] * ps["pairs"] / max(ps["launches"], 1))
-    except Exception:
-        pass
+    # HBM-side bytes per launch: the per-kept-pair figure of the committed PMC passes (profiles/, separate rocprofv3
+    # --pmc runs of this kernel on this workload; recipe tools/pmc_attn2.sh) x this run's kept pairs per launch
+    traffic = traffic_tbps = None
+    pmc_rel = os.path.join("profiles", PMC_FILE)
+    try:
+        pmc = json.load(open(os.path.join(ROOT, pmc_rel)))
+    except FileNotFoundError:
+        pmc = None
+        print(f"bench.py: {pmc_rel} not found: roofline.traffic stays null", file=sys.stderr)
+    if pmc is not None and ps["launches"] > 0:
+        d_ = pmc["derived"]
+        per_pair = d_.get("traffic_bytes_per_kept_pair")
+        if per_pair is None:      # older records carry the per-launch total and the pair count of the PMC run
+            per_pair = d_["traffic_bytes_per_launch"] / d_["kept_block_pairs_per_launch"]
+        traffic = int(per_pair * ps["pairs"] / ps["launches"])
+        if ps["total_ms"] > 0:
+            traffic_tbps = round(traffic / (ps["total_ms"] / ps["launches"] * 1e-3) / 1e12, 3)
     flops = ps["pairs"] * FLOPS_PER_PAIR
     ach = flops / (ps["total_ms"] * 1e-3) / 1e12 if ps["total_ms"] > 0 else 0.0
     res = {
@@ -376,6 +453,8 @@ def main():
                    "stage_tokens": [(sh[0] * (sh[1] // 2) * (sh[2] // 2)) for sh in shapes],
                    "sa_drop_rates": a.rates, "p_remain_rates": a.p_remain, "valid_text_tokens": a.valid_text,
                    "qk_norm_gain": a.peaky if a.peaky > 0 else 1.0,
+                   "latents": (f"smooth field (white noise at 1/{a.coherent:g} resolution, trilinear, + 10 % white noise)"
+                               if a.coherent > 0 else "iid N(0,1)"),
                    "schedule": "full 50-step loop" if not sampled else
                    f"sampled steps {plan}; sec/video = sum over (stage, computed|skipped) classes of "
                    f"count x mean step time, counts {dict((f'{k[0]}{k[1]}', n) for k, n in counts.items())}",
@@ -387,14 +466,23 @@ def main():
                    "weights": "random init N(0,0.02), seed 0", "finite_output": finite},
         "roofline": {"kernel": "jenga::bsattn_lp_kernel<bf16>" if (_capi.ATTN_DEFAULT_FLAGS & 8) else "jenga::bsattn_fwd_kernel<bf16>", "bound": "mfma", "achieved": round(ach, 1),
                      "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_PEAK_TFLOPS, 4),
-                     "traffic": traffic,
-                     "traffic_source": "profiles/r02_pmc_bsattn_lp.json: (2*FETCH_SIZE + WRITE_SIZE) per kept block pair "
-                                       "from separate rocprofv3 --pmc passes, x this run's pairs per launch",
+                     "traffic": traffic, "traffic_TBps": traffic_tbps,
+                     "traffic_source": f"{pmc_rel}: memory-side bytes per kept block pair from separate rocprofv3 --pmc "
+                                       "passes (FETCH_SIZE / WRITE_SIZE with the guide's gfx950 corrections), x this "
+                                       "run's pairs per launch; traffic_TBps = traffic / avg_launch_ms (the fabric "
+                                       "roof beside the MFMA one: ~8 TB/s)",
                      "launches": ps["launches"],
                      "avg_launch_ms": round(ps["total_ms"] / max(ps["launches"], 1), 3),
                      "kept_block_pairs_per_launch": ps["pairs"] // max(ps["launches"], 1),
                      "algorithmic_flops": "4*128^3 per kept (128-query, 128-key) block pair, realised masks"},
     }
+    if dense_ms is not None:
+        res["dense_reference"] = {
+            "s_per_video": round(50 * dense_ms / 1e3, 2), "ms_per_dense_step": round(dense_ms, 1),
+            "speedup_vs_dense": round(50 * dense_ms / 1e3 / max(sec_per_video, 1e-9), 3),
+            "note": "one computed step at sa-drop 0.0 (dense branch of the blocks, same kernels, every kv block kept), "
+                    "final resolution, measured after the timed region; the dense loop computes all 50 steps "
+                    "(no step skipping).  The reference's own ratio on H800: 1625 s / 310 s = 5.24 (README.md:80-82)"}
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         cb = cpu_baseline(a.rates, a.p_remain)
         layers = len(model.double_blocks) + len(model.single_blocks)

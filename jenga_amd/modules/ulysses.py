@@ -28,6 +28,7 @@ tests can drive N simulated ranks in one process on one GPU with an exchange tha
 (tests/test_gpu_ulysses.py), and the world_size-2 gloo test exercises the collectives themselves.
 """
 import os
+import threading
 
 import torch
 import torch.distributed as dist
@@ -36,6 +37,7 @@ from .. import _capi
 from . import attention_block_sparse as _op
 
 _SP_GROUP = None
+_TLS = threading.local()
 
 
 class _SPGroup:
@@ -44,8 +46,14 @@ class _SPGroup:
     def __init__(self, group):
         self.group = group
 
+    def size(self):
+        return dist.get_world_size(self.group) if dist.is_initialized() else 1
+
+    def rank(self):
+        return dist.get_rank(self.group) if dist.is_initialized() else 0
+
     def all_gather(self, x, dim=0):
-        n = dist.get_world_size(self.group)
+        n = self.size()
         if n == 1:
             return x
         x = x.contiguous()
@@ -60,18 +68,34 @@ def init_sequence_parallel(group=None):
     return _SP_GROUP
 
 
+def set_thread_sp_group(group_like):
+    """Per-thread override of the sequence-parallel group: an object with .size(), .rank(), .all_gather(x, dim).
+    tests/test_gpu_sp_dit.py runs N simulated ranks as N threads of one process, each with its own in-process group;
+    None removes the override.  Production code never calls this."""
+    _TLS.group = group_like
+
+
 def get_sp_group():
+    g = getattr(_TLS, "group", None)
+    if g is not None:
+        return g
     if _SP_GROUP is None:
         raise RuntimeError("call jenga_amd.modules.ulysses.init_sequence_parallel() first")
     return _SP_GROUP
 
 
 def get_sequence_parallel_world_size():
-    return dist.get_world_size(get_sp_group().group) if (_SP_GROUP and dist.is_initialized()) else 1
+    g = getattr(_TLS, "group", None)
+    if g is not None:
+        return g.size()
+    return _SP_GROUP.size() if _SP_GROUP else 1
 
 
 def get_sequence_parallel_rank():
-    return dist.get_rank(get_sp_group().group) if (_SP_GROUP and dist.is_initialized()) else 0
+    g = getattr(_TLS, "group", None)
+    if g is not None:
+        return g.rank()
+    return _SP_GROUP.rank() if _SP_GROUP else 0
 
 
 def _pack_heads(t, N):

@@ -63,6 +63,12 @@ def stage_text_amp(stage_shape, final_shape, scale_txt_amp=1.0):
     return -1 * math.log(math.sqrt(tok / tok_f), 2) * scale_txt_amp
 
 
+def stage_text_amps(shapes, scale_txt_amp=1.0):
+    """text_amp per stage: only stage 0 carries the amplifier (:577, 594); the pipeline sets text_amp = 0.0 after ANY
+    stage switch (:755), so every later stage runs with 0.0 whatever its resolution."""
+    return [stage_text_amp(shapes[0], shapes[-1], scale_txt_amp)] + [0.0] * (len(shapes) - 1)
+
+
 def switch_stage(sched, noise_pred, i, latents, new_shape, new_shift, noise):
     """The re-noising hop at a stage boundary (:724-739): re-shift the schedule, predict x0 from x_t, upsample
     trilinearly to the next stage's latent size, add the fresh noise at sigma_{i+1}.  Returns fp32 latents."""

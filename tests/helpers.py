@@ -1,6 +1,85 @@
 """Shared test helpers (conversion between torch low-precision tensors and the oracle's fp32 arrays)."""
+import threading
+
 import numpy as np
 import torch
+
+
+class SimWorld:
+    """Shared state of N simulated ranks (threads of one process, one GPU)."""
+
+    def __init__(self, N):
+        self.N = N
+        self.barrier = threading.Barrier(N)
+        self.slots = {}
+        self.lock = threading.Lock()
+
+
+class _SimParty:
+    def __init__(self, world, rank, tag):
+        self.w, self.r, self.calls, self.tag = world, rank, 0, tag
+
+    def size(self):
+        return self.w.N
+
+    def rank(self):
+        return self.r
+
+    def _swap(self, payload):
+        key = (self.tag, self.calls)
+        self.calls += 1
+        with self.w.lock:
+            self.w.slots[(key, self.r)] = payload
+        self.w.barrier.wait()
+        peers = [self.w.slots[(key, p)] for p in range(self.w.N)]
+        return key, peers
+
+    def _done(self, key):
+        self.w.barrier.wait()            # everybody has copied: the send buffers may go
+        with self.w.lock:
+            self.w.slots.pop((key, self.r), None)
+
+
+class _Waited:
+    def wait(self):
+        return True
+
+
+class SimExchange(_SimParty):
+    """In-process stand-in for jenga_amd.modules.ulysses.DistExchange: same methods, the chunks REALLY change ranks
+    (recv[r][p] = send[p][r], what all_to_all_single / the grouped send-recv do)."""
+
+    def __init__(self, world, rank):
+        super().__init__(world, rank, "x")
+
+    def all_to_all(self, recvs, sends):
+        key, peers = self._swap(sends)
+        for i, rc in enumerate(recvs):
+            for p in range(self.w.N):
+                rc[p].copy_(peers[p][i][self.r])       # chunk r of rank p's send buffer -> chunk p of my receive buffer
+        self._done(key)
+        return [_Waited()]
+
+    def all_gather(self, out, x):
+        key, peers = self._swap(x)
+        for p in range(self.w.N):
+            out[p].copy_(peers[p])
+        self._done(key)
+        return _Waited()
+
+
+class SimGroup(_SimParty):
+    """In-process stand-in for the sequence-parallel group object (ulysses._SPGroup): .all_gather(x, dim) concatenates
+    the ranks' tensors in rank order along `dim` (jenga_hyvideo_multigpu.py:193)."""
+
+    def __init__(self, world, rank):
+        super().__init__(world, rank, "g")
+
+    def all_gather(self, x, dim=0):
+        key, peers = self._swap(x)
+        out = torch.cat(list(peers), dim=dim)   # (all threads share the device's default stream: ordered)
+        self._done(key)
+        return out
 
 
 def to_np(t):

@@ -1,0 +1,38 @@
+"""CPU: bench.py's launcher-independent --gpus N (VERDICT r2 missing #5) and the evidence chain of roofline.traffic
+(the PMC record bench.py reads must carry what it reads)."""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_bare_gpus_n_relaunches_under_torch_distributed_run():
+    import bench
+    cmd = bench.launch_command(8, ["--gpus", "8", "--steps", "6", "--warmup", "1"], port=29511)
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"]
+    assert "--nnodes=1" in cmd and "--nproc-per-node=8" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[cmd.index("--master-port") + 1] == "29511"
+    i = cmd.index(os.path.join(ROOT, "bench.py"))
+    assert cmd[i + 1:] == ["--gpus", "8", "--steps", "6", "--warmup", "1"]
+    # a free port is picked when none is given
+    assert int(bench.launch_command(2, [])[bench.launch_command(2, []).index("--master-port") + 1]) > 0
+
+
+def test_pmc_record_carries_the_per_pair_traffic_bench_reads():
+    import bench
+    d = json.load(open(os.path.join(ROOT, "profiles", bench.PMC_FILE)))["derived"]
+    per_pair = d.get("traffic_bytes_per_kept_pair")
+    if per_pair is None:
+        per_pair = d["traffic_bytes_per_launch"] / d["kept_block_pairs_per_launch"]
+    # one kept pair stages a 64 KiB K/V block pair at most once: the figure must be of that order
+    assert 8e3 < per_pair <= 70e3
+
+
+def test_presets_cover_the_reference_scripts_and_dense():
+    import bench
+    for name in ("base", "turbo", "flash", "3stage", "base-mgpu", "turbo-mgpu", "flash-mgpu", "3stage-mgpu", "dense"):
+        p = bench.PRESETS[name]
+        assert len(p["res"]) == len(p["steps"]) == len(p["rates"]) == len(p["shifts"])
+    assert bench.PRESETS["dense"]["rates"] == [0.0, 0.0] and bench.PRESETS["dense"]["skip"] is False
+    assert bench.stage_of(25, [25, 50]) == 0 and bench.stage_of(26, [25, 50]) == 1

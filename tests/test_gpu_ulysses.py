@@ -15,7 +15,7 @@ import pytest
 import torch
 
 import inputs
-from helpers import to_np
+from helpers import SimExchange, SimWorld, to_np
 
 pytestmark = pytest.mark.gpu
 
@@ -49,66 +49,6 @@ def test_pack_unpack_heads_vs_oracle(dev, N):
         assert torch.equal(_capi.ulysses_pack_heads(y.to(dev), N).cpu(), ou.pack_heads(y, N))
 
 
-class _SimWorld:
-    """Shared state of N simulated ranks (threads)."""
-
-    def __init__(self, N):
-        self.N = N
-        self.barrier = threading.Barrier(N)
-        self.slots = {}
-        self.lock = threading.Lock()
-
-
-class SimExchange:
-    """In-process stand-in for DistExchange: same methods, the chunks really change ranks."""
-
-    def __init__(self, world, rank):
-        self.w, self.r, self.calls = world, rank, 0
-
-    def size(self):
-        return self.w.N
-
-    def rank(self):
-        return self.r
-
-    def _swap(self, payload):
-        key = self.calls
-        self.calls += 1
-        with self.w.lock:
-            self.w.slots[(key, self.r)] = payload
-        self.w.barrier.wait()
-        peers = [self.w.slots[(key, p)] for p in range(self.w.N)]
-        return key, peers
-
-    def _done(self, key):
-        self.w.barrier.wait()            # everybody has copied: the send buffers may go
-        with self.w.lock:
-            self.w.slots.pop((key, self.r), None)
-
-    def all_to_all(self, recvs, sends):
-        key, peers = self._swap(sends)
-        for i, rc in enumerate(recvs):
-            for p in range(self.w.N):
-                rc[p].copy_(peers[p][i][self.r])       # chunk r of rank p's send buffer -> chunk p of my receive buffer
-        self._done(key)
-
-        class W:
-            def wait(self_inner):
-                return True
-        return [W()]
-
-    def all_gather(self, out, x):
-        key, peers = self._swap(x)
-        for p in range(self.w.N):
-            out[p].copy_(peers[p])
-        self._done(key)
-
-        class W:
-            def wait(self_inner):
-                return True
-        return W()
-
-
 @pytest.mark.parametrize("N", [2, 8])
 def test_simulated_ranks_forward_equals_single_rank_op(dev, N):
     from jenga_amd.modules import ulysses
@@ -131,7 +71,7 @@ def test_simulated_ranks_forward_equals_single_rank_op(dev, N):
     qd, kd, vd = q.to(dev), k.to(dev), v.to(dev)
     nb_dev = torch.from_numpy(nbm).to(dev)
 
-    world = _SimWorld(N)
+    world = SimWorld(N)
     results, errors = [None] * N, []
 
     def run(rank):

@@ -30,6 +30,11 @@ def test_stage_plan_and_text_amp():
     shapes3, split3 = prores.stage_plan((32, 90, 160), 50, [0.5, 0.75, 1.0], [0.3, 0.5, 1.0])
     assert shapes3[0] == (32, 44, 80) and split3 == [15, 25, 50]
     assert 32 * 22 * 40 == 28160
+    # only stage 0 carries the amplifier: the pipeline zeroes text_amp after ANY switch (pipeline...prores.py:755),
+    # so the 0.75-resolution middle stage of the 3-stage presets runs with 0.0
+    amps3 = prores.stage_text_amps(shapes3)
+    assert amps3[1:] == [0.0, 0.0] and abs(amps3[0] - 1.0162107388461887) < 1e-12     # -log2(sqrt(880/3600))
+    assert [abs(v) for v in prores.stage_text_amps(prores.stage_plan((32, 90, 160), 50, [1.0, 1.0], [0.5, 1.0])[0])] == [0.0, 0.0]
 
 
 def test_switch_stage_composes_the_three_steps():

@@ -117,6 +117,7 @@ def main():
     kept = int(cnt.sum().item())
     pairs = kept + H * tb * nb
     flops = 4 * 128 ** 3 * pairs
+    res["pairs"] = pairs
     res["kept_mean"] = kept / (H * nimg)
     res["kept_min_max"] = [int(cnt.min()), int(cnt.max())]
     ms, o = timed(lambda: _capi.bsattn_fwd(q, k, vt, seqlens, idx, cnt, nimg, 128 ** -0.5, 0.0, nimg,

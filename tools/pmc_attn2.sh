@@ -43,7 +43,7 @@ for db in sorted(glob.glob(out + "/*/*.db")):
 for line in open(out + "/trace.log"):
     if line.startswith("{"):
         d = json.loads(line)
-        res["bench"] = {k: d[k] for k in ("attn_ms", "attn_TFLOPs", "kept_mean") if k in d}
+        res["bench"] = {k: d[k] for k in ("attn_ms", "attn_TFLOPs", "kept_mean", "pairs", "adjacent_shared_frac") if k in d}
         res["shape"] = d.get("shape")
 c = res["counters_per_launch"]
 der = {}
@@ -51,6 +51,9 @@ if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
     der["traffic_bytes_per_launch"] = (2 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024
     der["traffic_note"] = ("(2*FETCH_SIZE + WRITE_SIZE) KB: FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 tallies "
                            "128-B requests at 64 B); memory-side L2 requests, Infinity-Cache hits included")
+    if res.get("bench", {}).get("pairs"):
+        der["kept_block_pairs_per_launch"] = res["bench"]["pairs"]
+        der["traffic_bytes_per_kept_pair"] = der["traffic_bytes_per_launch"] / res["bench"]["pairs"]
 if "TCC_HIT_sum" in c:
     der["l2_hit_rate"] = c["TCC_HIT_sum"] / (c["TCC_HIT_sum"] + c["TCC_MISS_sum"])
 if "GRBM_GUI_ACTIVE" in c and "SQ_VALU_MFMA_BUSY_CYCLES" in c:
