@@ -129,6 +129,23 @@ int jenga_qk_norm_rope_pool(void* stream, const void* xq, const void* xk, void* 
                             int64_t o_ss, int64_t o_sh, int64_t s_rope, int64_t pool_block0, int64_t nq_pool,
                             int64_t nk_pool, float eps, int dtype);
 
+/* jenga_sp_qkv_prologue (SURVEY.md §8 f-2 on the sequence-parallel path): the local half of the reference's chain
+ * "RMSNorm(q), RMSNorm(k), apply_rotary_emb (models_mul_block_gc_ha_multigpu.py:196-214) -> SeqAllToAll4D's
+ * scatter-heads permute of q, k and v (xdit_ring_atten.py:118-131)" in ONE pass: jenga_rmsnorm_rope of Q and K plus
+ * jenga_ulysses_pack_heads of Q, K and V.  xq, xk, xv [B, S, H, 128] share one set of strides (the three slices of a
+ * QKV GEMM output); any S.  Heads [head0, head0 + n_heads) are processed; head h is written to
+ *     o + (h / heads_per_peer) * o_sp + b * o_sb + s * o_ss + (h % heads_per_peer) * o_sh        (elements)
+ * for each of oq, ok (normalised, RoPE on tokens < s_rope) and ov (copied).
+ *   peer-major send buffers [N][B][S][H/N][128]: head0 = 0, n_heads = H, o_sp = B*S*(H/N)*128;
+ *   a rank's own head slice of the replicated text rows, written straight behind the gathered image rows of the
+ *   attention inputs (xdit_ring_atten.py:159-175 slices them the same way): head0 = rank*H/N, n_heads = H/N, o_sp = 0.
+ * Bit-identical to the unfused kernels. */
+int jenga_sp_qkv_prologue(void* stream, const void* xq, const void* xk, const void* xv, void* oq, void* ok, void* ov,
+                          const void* wq, const void* wk, const float* cosT, const float* sinT, int64_t B, int64_t S,
+                          int64_t H, int64_t head0, int64_t n_heads, int64_t heads_per_peer, int64_t x_sb,
+                          int64_t x_ss, int64_t x_sh, int64_t o_sp, int64_t o_sb, int64_t o_ss, int64_t o_sh,
+                          int64_t s_rope, float eps, int dtype);
+
 /* ---------------------------------------------------------------------------------------------------
  * Block selection.  Replaces _build_block_index_with_importance_optimized
  * (hyvideo/modules/attention_block_triton_diffres.py:198-295; Wan first_frame_blocks rule

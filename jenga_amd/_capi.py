@@ -35,6 +35,7 @@ SIGNATURES = {
     "jenga_wan_ln_modulate": (_i32, [_vp] * 7 + [_i64] * 4 + [_f32, _i32, _i32]),
     "jenga_wan_gate_residual": (_i32, [_vp] * 5 + [_i64] * 5 + [_i32]),
     "jenga_qk_norm_rope_pool": (_i32, [_vp] * 11 + [_i64] * 13 + [_f32, _i32]),
+    "jenga_sp_qkv_prologue": (_i32, [_vp] * 11 + [_i64] * 14 + [_f32, _i32]),
     "jenga_block_pool": (_i32, [_vp, _vp, _vp] + [_i64] * 6 + [_i32]),
     "jenga_block_select": (_i32, [_vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp] + [_i64] * 6 + [_f32, _i64, _i32]),
     "jenga_pack_v_bytes": (ctypes.c_size_t, [_i64, _i64, _i64]),
@@ -233,6 +234,58 @@ def qk_norm_rope_pool(xq, xk, wq, wk, cos, sin, out_q, out_k, s_rope=None, qpool
                                              *_bshd_strides(xq), *_bshd_strides(out_q), int(s_rope), int(pool_block0),
                                              nq, nk, float(eps), dtype_code(xq.dtype)), "jenga_qk_norm_rope_pool")
     return out_q, out_k
+
+
+def sp_qkv_prologue(xq, xk, xv, wq, wk, cos, sin, out_q, out_k, out_v, heads_per_peer, head0=0, n_heads=None,
+                    s_rope=None, eps=1e-6):
+    """Sequence-parallel prologue: per-head RMSNorm + RoPE of Q and K and the Ulysses head scatter of Q, K, V in one
+    launch.  xq, xk, xv [B,S,H,128] with the SAME strides (any S).  Outputs, all three of one shape and stride set:
+      peer-major send buffers [N,B,S,H/N,128] (contiguous; head0 = 0, all heads), or
+      [B,S,n_heads,128] views (any strides) receiving the head window [head0, head0 + n_heads) -- a rank's own slice
+      of the replicated text rows, written in place behind the gathered image rows."""
+    _need_gpu(xq, "sp_qkv_prologue")
+    B, S, H, D = xq.shape
+    if D != 128 or xk.shape != xq.shape or xv.shape != xq.shape:
+        raise ValueError("sp_qkv_prologue: q / k / v must be [B, S, H, 128] of one shape")
+    if not (_bshd_strides(xq) == _bshd_strides(xk) == _bshd_strides(xv)):
+        raise ValueError("sp_qkv_prologue: q, k and v must share their strides")
+    if n_heads is None:
+        n_heads = H - head0
+    Hn = int(heads_per_peer)
+    if out_q.dim() == 5:
+        N = out_q.shape[0]
+        if head0 != 0 or n_heads != H or tuple(out_q.shape) != (N, B, S, Hn, 128) or N * Hn != H \
+                or not out_q.is_contiguous():
+            raise ValueError("sp_qkv_prologue: peer-major outputs must be contiguous [N, B, S, H/N, 128]")
+        o_sp, o_sb, o_ss, o_sh = out_q.stride(0), out_q.stride(1), out_q.stride(2), out_q.stride(3)
+    else:
+        if tuple(out_q.shape) != (B, S, n_heads, 128) or n_heads > Hn or head0 % Hn + n_heads > Hn:
+            raise ValueError("sp_qkv_prologue: head-window outputs must be [B, S, n_heads, 128] inside one peer's heads")
+        o_sp = 0
+        o_sb, o_ss, o_sh = _bshd_strides(out_q)
+        if head0 % Hn:      # the kernel writes head h at local index h % Hn: shift the base so that head0 lands on 0
+            raise ValueError("sp_qkv_prologue: head0 must be a multiple of heads_per_peer")
+    for t in (out_k, out_v):
+        if t.shape != out_q.shape or t.stride() != out_q.stride() or t.dtype != xq.dtype:
+            raise ValueError("sp_qkv_prologue: the three outputs must share shape, strides and dtype")
+    wq = None if wq is None else wq.to(device=xq.device, dtype=xq.dtype).contiguous()
+    wk = None if wk is None else wk.to(device=xq.device, dtype=xq.dtype).contiguous()
+    if cos is not None:
+        if cos.dtype != torch.float32 or sin.dtype != torch.float32 or cos.shape[-1] != 128:
+            raise ValueError("cos/sin must be float32 [S,128]")
+        cos, sin = cos.contiguous(), sin.contiguous()
+        if s_rope is None:
+            s_rope = cos.shape[0]
+        if s_rope > cos.shape[0] or s_rope > S:
+            raise ValueError("s_rope exceeds the table / sequence length")
+    else:
+        s_rope = 0
+    with torch.cuda.device(xq.device):
+        _check(lib().jenga_sp_qkv_prologue(_stream(xq.device), _p(xq), _p(xk), _p(xv), _p(out_q), _p(out_k), _p(out_v),
+                                           _p(wq), _p(wk), _p(cos), _p(sin), B, S, H, int(head0), int(n_heads), Hn,
+                                           *_bshd_strides(xq), int(o_sp), int(o_sb), int(o_ss), int(o_sh),
+                                           int(s_rope), float(eps), dtype_code(xq.dtype)), "jenga_sp_qkv_prologue")
+    return out_q, out_k, out_v
 
 
 def rmsnorm_rows(x, weight, eps):

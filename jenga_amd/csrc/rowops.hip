@@ -197,6 +197,55 @@ __global__ void __launch_bounds__(128) qk_norm_rope_pool_kernel(const uint16_t* 
     }
 }
 
+// ------------------------------------------------------------------------------------------------ SP prologue
+// SURVEY.md §8 f-2 on the sequence-parallel path (models_mul_block_gc_ha_multigpu.py:196-214 feeding
+// xdit_ring_atten.py:118-131): ONE pass over the local shard's Q, K and V slices of the QKV GEMM output does the
+// per-head RMSNorm + RoPE of Q and K and writes all three straight into the PEER-MAJOR send buffers of the Ulysses
+// exchange (head h goes to peer h / Hn as its local head h % Hn) -- what used to be rmsnorm_rope x 2 +
+// ulysses_pack_heads x 3.  Any row count (no 128-token blocking: pooling happens after the exchange, on the gathered
+// sequence).  With o_sp = 0 and a head window [head0, head0 + n_heads) the same kernel writes a rank's OWN head slice
+// of the replicated text rows directly behind the gathered image rows of the attention inputs.
+// Arithmetic of the norm and the rotation: norm_rope_row (= rmsnorm_rope_kernel's, bit for bit).
+template <typename T>
+__global__ void __launch_bounds__(256) sp_qkv_prologue_kernel(
+    const uint16_t* __restrict__ xq, const uint16_t* __restrict__ xk, const uint16_t* __restrict__ xv,
+    uint16_t* __restrict__ oq, uint16_t* __restrict__ ok, uint16_t* __restrict__ ov, const uint16_t* __restrict__ wq,
+    const uint16_t* __restrict__ wk, const float* __restrict__ cosT, const float* __restrict__ sinT, long long B,
+    long long S, long long head0, long long n_heads, long long Hn, long long x_sb, long long x_ss, long long x_sh,
+    long long o_sp, long long o_sb, long long o_ss, long long o_sh, long long s_rope, float eps) {
+    const int sub = threadIdx.x & 15, rig = threadIdx.x >> 4;
+    const long long rows = B * S * n_heads;
+    float wqv[8], wkv[8];
+    if (wq) unpack8<T>(*reinterpret_cast<const uint4*>(wq + sub * 8), wqv);
+    if (wk) unpack8<T>(*reinterpret_cast<const uint4*>(wk + sub * 8), wkv);
+    for (long long row = (long long)blockIdx.x * 16 + rig; row < rows; row += (long long)gridDim.x * 16) {
+        const long long hw = row % n_heads, s = (row / n_heads) % S, b = row / (n_heads * S);
+        const long long h = head0 + hw;
+        const long long xo = b * x_sb + s * x_ss + h * x_sh + sub * 8;
+        const uint4 rq = *reinterpret_cast<const uint4*>(xq + xo);
+        const uint4 rk = *reinterpret_cast<const uint4*>(xk + xo);
+        const uint4 rv = *reinterpret_cast<const uint4*>(xv + xo);
+        float fq[8], fk[8];
+        unpack8<T>(rq, fq);
+        unpack8<T>(rk, fk);
+        const bool rope = cosT && s < s_rope;
+        float c[8], sn[8];
+        if (rope) {
+            const float4* cp = reinterpret_cast<const float4*>(cosT + s * 128 + sub * 8);
+            const float4* sp = reinterpret_cast<const float4*>(sinT + s * 128 + sub * 8);
+            const float4 c0 = cp[0], c1 = cp[1], s0 = sp[0], s1 = sp[1];
+            c[0] = c0.x; c[1] = c0.y; c[2] = c0.z; c[3] = c0.w; c[4] = c1.x; c[5] = c1.y; c[6] = c1.z; c[7] = c1.w;
+            sn[0] = s0.x; sn[1] = s0.y; sn[2] = s0.z; sn[3] = s0.w; sn[4] = s1.x; sn[5] = s1.y; sn[6] = s1.z; sn[7] = s1.w;
+        }
+        norm_rope_row<T>(fq, wqv, wq != nullptr, eps, rope, c, sn);
+        norm_rope_row<T>(fk, wkv, wk != nullptr, eps, rope, c, sn);
+        const long long oo = (h / Hn) * o_sp + b * o_sb + s * o_ss + (h % Hn) * o_sh + sub * 8;
+        *reinterpret_cast<uint4*>(oq + oo) = pack8<T>(fq);
+        *reinterpret_cast<uint4*>(ok + oo) = pack8<T>(fk);
+        *reinterpret_cast<uint4*>(ov + oo) = rv;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ block pooling
 // One workgroup per (b, h, block): 128 tokens x 128 dims.  thread -> (token group tg = t/16, slice = t%16);
 // each thread sums 8 tokens in fp32, LDS tree over the 16 groups, one rounding of mean to dtype.
@@ -471,6 +520,41 @@ extern "C" int jenga_qk_norm_rope_pool(void* stream, const void* xq, const void*
     if (dtype == JENGA_BF16) LAUNCH_QKP(BF16); else LAUNCH_QKP(FP16);
 #undef LAUNCH_QKP
     JENGA_CHECK_LAUNCH("jenga_qk_norm_rope_pool");
+    return JENGA_OK;
+}
+
+extern "C" int jenga_sp_qkv_prologue(void* stream, const void* xq, const void* xk, const void* xv, void* oq, void* ok,
+                                     void* ov, const void* wq, const void* wk, const float* cosT, const float* sinT,
+                                     int64_t B, int64_t S, int64_t H, int64_t head0, int64_t n_heads,
+                                     int64_t heads_per_peer, int64_t x_sb, int64_t x_ss, int64_t x_sh, int64_t o_sp,
+                                     int64_t o_sb, int64_t o_ss, int64_t o_sh, int64_t s_rope, float eps, int dtype) {
+    if (!xq || !xk || !xv || !oq || !ok || !ov || B < 0 || S < 0 || H <= 0 || head0 < 0 || n_heads < 0 ||
+        head0 + n_heads > H || heads_per_peer <= 0 || !strides_ok(x_sb, x_ss, x_sh) || !strides_ok(o_sb, o_ss, o_sh) ||
+        (o_sp & 7) || o_sp < 0 || ((uintptr_t)xq & 15) || ((uintptr_t)xk & 15) || ((uintptr_t)xv & 15) ||
+        ((uintptr_t)oq & 15) || ((uintptr_t)ok & 15) || ((uintptr_t)ov & 15) ||
+        ((cosT == nullptr) != (sinT == nullptr)) || s_rope < 0) {
+        set_error("jenga_sp_qkv_prologue: bad arguments (head window [%lld, %lld) of %lld heads, %lld heads per peer; "
+                  "strides multiples of 8 elements, pointers 16-B aligned)",
+                  (long long)head0, (long long)(head0 + n_heads), (long long)H, (long long)heads_per_peer);
+        return JENGA_EINVAL;
+    }
+    if (dtype != JENGA_BF16 && dtype != JENGA_FP16) {
+        set_error("jenga_sp_qkv_prologue: dtype must be bf16 or fp16");
+        return JENGA_EUNSUPPORTED;
+    }
+    const long long rows = (long long)B * S * n_heads;
+    if (rows == 0) return JENGA_OK;
+    const int grid = grid_for((rows + 15) / 16, 65536);
+#define LAUNCH_SPP(T)                                                                                              \
+    hipLaunchKernelGGL(sp_qkv_prologue_kernel<T>, dim3(grid), dim3(256), 0, (hipStream_t)stream,                   \
+                       (const uint16_t*)xq, (const uint16_t*)xk, (const uint16_t*)xv, (uint16_t*)oq, (uint16_t*)ok, \
+                       (uint16_t*)ov, (const uint16_t*)wq, (const uint16_t*)wk, cosT, sinT, (long long)B,          \
+                       (long long)S, (long long)head0, (long long)n_heads, (long long)heads_per_peer,              \
+                       (long long)x_sb, (long long)x_ss, (long long)x_sh, (long long)o_sp, (long long)o_sb,        \
+                       (long long)o_ss, (long long)o_sh, (long long)s_rope, eps)
+    if (dtype == JENGA_BF16) LAUNCH_SPP(BF16); else LAUNCH_SPP(FP16);
+#undef LAUNCH_SPP
+    JENGA_CHECK_LAUNCH("jenga_sp_qkv_prologue");
     return JENGA_OK;
 }
 

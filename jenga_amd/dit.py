@@ -113,41 +113,22 @@ class MMDoubleStreamBlock(nn.Module):
         self.txt_mlp = MLP(hidden_size, mlp_hidden, **fk)
         self.hybrid_seq_parallel_attn = None
 
-    @torch.no_grad()   # inference only, like the reference (hyvideo/inference.py:195 disables grad globally)
-    def forward(self, img, txt, vec, cu_seqlens_q=None, cu_seqlens_kv=None, max_seqlen_q=None, max_seqlen_kv=None,
-                freqs_cis: tuple = None, sa_drop_rate: float = 0.0, txt_amp: float = 1.0, curve_sel: list = None,
-                p_remain_rates: float = 0.5, txt_block_num: int = 2, per_block_token: int = 128,
-                token_replace_vec=None, first_frame_mask=None):
-        """token_replace_vec / first_frame_mask: the I2V "token_replace" conditioning (hyvideo_i2v/modules/
-        models_mul.py:136-320): image tokens with first_frame_mask set are modulated / gated by a second vector."""
+    def _attention_unfused(self, img_qkv, txt_qkv, cos, sin, sa_drop_rate, top_k, txt_amp, txt_block_num,
+                           p_remain_rates, block_neighbor_list, cu_seqlens_q, cu_seqlens_kv):
+        """Single GPU (and a sequence-parallel module that only offers the reference's forward signature)."""
         H = self.heads_num
-        B, S_img, C = img.shape
-        S_txt = txt.shape[1]
-        (img_mod1_shift, img_mod1_scale, img_mod1_gate, img_mod2_shift, img_mod2_scale,
-         img_mod2_gate) = self.img_mod(vec).chunk(6, dim=-1)
-        (txt_mod1_shift, txt_mod1_scale, txt_mod1_gate, txt_mod2_shift, txt_mod2_scale,
-         txt_mod2_gate) = self.txt_mod(vec).chunk(6, dim=-1)
-        tr = [None] * 6
-        if token_replace_vec is not None:
-            tr = self.img_mod(token_replace_vec).chunk(6, dim=-1)
-        fm = first_frame_mask if token_replace_vec is not None else None
-        # LayerNorm + adaLN modulation fused (one pass over HBM instead of three)
-        img_qkv = self.img_attn_qkv(_capi.ln_modulate(img, img_mod1_shift, img_mod1_scale, shift2=tr[0], scale2=tr[1],
-                                                      mask=fm)).view(B, S_img, 3, H, 128)
-        txt_qkv = self.txt_attn_qkv(_capi.ln_modulate(txt, txt_mod1_shift, txt_mod1_scale)).view(B, S_txt, 3, H, 128)
-        block_neighbor_list = curve_sel[0][2] if curve_sel is not None else None
-        top_k = _select_top_k(sa_drop_rate, S_img // per_block_token)
-        cos, sin = freqs_cis
+        B, S_img = img_qkv.shape[:2]
+        S_txt = txt_qkv.shape[1]
         # QK-norm + RoPE (+ the block means the selection needs) fused: one kernel per stream handles Q and K, writes
         # straight into the concatenated (image | text) buffers and fills the pooled tensors
-        q = torch.empty((B, S_img + S_txt, H, 128), dtype=img.dtype, device=img.device)
+        q = torch.empty((B, S_img + S_txt, H, 128), dtype=img_qkv.dtype, device=img_qkv.device)
         k = torch.empty_like(q)
         sparse = (not self.hybrid_seq_parallel_attn) and sa_drop_rate != 0.0 and S_img % 128 == 0 and S_txt % 128 == 0
         pooled = None
         if sparse:      # (sequence parallel: pooling happens after the exchange, on the gathered sequence)
             nimg_, nb_ = S_img // 128, (S_img + S_txt) // 128
-            pooled = (torch.empty((B, H, nimg_, 128), dtype=img.dtype, device=img.device),
-                      torch.empty((B, H, nb_, 128), dtype=img.dtype, device=img.device))
+            pooled = (torch.empty((B, H, nimg_, 128), dtype=img_qkv.dtype, device=img_qkv.device),
+                      torch.empty((B, H, nb_, 128), dtype=img_qkv.dtype, device=img_qkv.device))
         if S_img % 128 == 0 and S_txt % 128 == 0:
             qp, kp = pooled if pooled else (None, None)
             _capi.qk_norm_rope_pool(img_qkv[:, :, 0], img_qkv[:, :, 1], self.img_attn_q_norm.weight,
@@ -179,6 +160,49 @@ class MMDoubleStreamBlock(nn.Module):
             seqlens = cu_seqlens_q[1:2]
             attn = op.attencarve_packed(q, k, vt, top_k, seqlens, txt_block_num, txt_amp, p_remain_rates,
                                         block_neighbor_list, pooled=pooled).view(B, S_img + S_txt, H * 128)
+        return attn
+
+    @torch.no_grad()   # inference only, like the reference (hyvideo/inference.py:195 disables grad globally)
+    def forward(self, img, txt, vec, cu_seqlens_q=None, cu_seqlens_kv=None, max_seqlen_q=None, max_seqlen_kv=None,
+                freqs_cis: tuple = None, sa_drop_rate: float = 0.0, txt_amp: float = 1.0, curve_sel: list = None,
+                p_remain_rates: float = 0.5, txt_block_num: int = 2, per_block_token: int = 128,
+                token_replace_vec=None, first_frame_mask=None):
+        """token_replace_vec / first_frame_mask: the I2V "token_replace" conditioning (hyvideo_i2v/modules/
+        models_mul.py:136-320): image tokens with first_frame_mask set are modulated / gated by a second vector."""
+        H = self.heads_num
+        B, S_img, C = img.shape
+        S_txt = txt.shape[1]
+        (img_mod1_shift, img_mod1_scale, img_mod1_gate, img_mod2_shift, img_mod2_scale,
+         img_mod2_gate) = self.img_mod(vec).chunk(6, dim=-1)
+        (txt_mod1_shift, txt_mod1_scale, txt_mod1_gate, txt_mod2_shift, txt_mod2_scale,
+         txt_mod2_gate) = self.txt_mod(vec).chunk(6, dim=-1)
+        tr = [None] * 6
+        if token_replace_vec is not None:
+            tr = self.img_mod(token_replace_vec).chunk(6, dim=-1)
+        fm = first_frame_mask if token_replace_vec is not None else None
+        # LayerNorm + adaLN modulation fused (one pass over HBM instead of three)
+        img_qkv = self.img_attn_qkv(_capi.ln_modulate(img, img_mod1_shift, img_mod1_scale, shift2=tr[0], scale2=tr[1],
+                                                      mask=fm)).view(B, S_img, 3, H, 128)
+        txt_qkv = self.txt_attn_qkv(_capi.ln_modulate(txt, txt_mod1_shift, txt_mod1_scale)).view(B, S_txt, 3, H, 128)
+        block_neighbor_list = curve_sel[0][2] if curve_sel is not None else None
+        top_k = _select_top_k(sa_drop_rate, S_img // per_block_token)
+        cos, sin = freqs_cis
+        sp = self.hybrid_seq_parallel_attn
+        if sp and hasattr(sp, "forward_qkv"):
+            # sequence parallel, fused prologue: RMSNorm + RoPE of Q, K and the peer-major pack of Q, K, V in ONE kernel
+            # per stream straight from the GEMM outputs (any shard length: 14400 tokens at N = 8 is not a multiple of
+            # 128); pooling happens after the exchange, on the gathered sequence
+            attn = sp.forward_qkv(
+                (img_qkv[:, :, 0], img_qkv[:, :, 1], img_qkv[:, :, 2]),
+                (txt_qkv[:, :, 0], txt_qkv[:, :, 1], txt_qkv[:, :, 2]),
+                (self.img_attn_q_norm.weight, self.img_attn_k_norm.weight),
+                (self.txt_attn_q_norm.weight, self.txt_attn_k_norm.weight), (cos, sin),
+                top_k=ulysses.get_sequence_parallel_world_size() * top_k, text_amp=txt_amp,
+                block_neighbor_list=block_neighbor_list, p_remain_rates=p_remain_rates,
+                cu_seqlens_q=cu_seqlens_q).reshape(B, S_img + S_txt, -1)
+        else:
+            attn = self._attention_unfused(img_qkv, txt_qkv, cos, sin, sa_drop_rate, top_k, txt_amp, txt_block_num,
+                                           p_remain_rates, block_neighbor_list, cu_seqlens_q, cu_seqlens_kv)
         img_attn, txt_attn = attn[:, :S_img], attn[:, S_img:]
         # gated residual adds fused; the MLP input is again LayerNorm + modulate in one pass
         img = _capi.gate_residual(img, self.img_attn_proj(img_attn), img_mod1_gate, gate2=tr[2], mask=fm)
@@ -207,6 +231,37 @@ class MMSingleStreamBlock(nn.Module):
         self.modulation = ModulateDiT(hidden_size, 3, **fk)
         self.hybrid_seq_parallel_attn = None
 
+    def _attention_unfused(self, qkv, S_img, cos, sin, sa_drop_rate, top_k, txt_amp, txt_block_num, p_remain_rates,
+                           block_neighbor_list, cu_seqlens_q, cu_seqlens_kv, cat, attn_out):
+        H, C = self.heads_num, self.hidden_size
+        B, S = qkv.shape[:2]
+        sparse = (not self.hybrid_seq_parallel_attn) and sa_drop_rate != 0.0 and S % 128 == 0 and S_img % 128 == 0
+        pooled = None
+        if S % 128 == 0:   # Q and K in one kernel (RoPE on image tokens only), block means for the selection on the way
+            q = torch.empty((B, S, H, 128), dtype=qkv.dtype, device=qkv.device)
+            k = torch.empty_like(q)
+            if sparse:
+                pooled = (torch.empty((B, H, S_img // 128, 128), dtype=qkv.dtype, device=qkv.device),
+                          torch.empty((B, H, S // 128, 128), dtype=qkv.dtype, device=qkv.device))
+            _capi.qk_norm_rope_pool(qkv[:, :, 0], qkv[:, :, 1], self.q_norm.weight, self.k_norm.weight, cos, sin, q, k,
+                                    s_rope=S_img, qpool=pooled[0] if pooled else None,
+                                    kpool=pooled[1] if pooled else None)
+        else:
+            q = _capi.rmsnorm_rope(qkv[:, :, 0], self.q_norm.weight, cos, sin, s_rope=S_img)
+            k = _capi.rmsnorm_rope(qkv[:, :, 1], self.k_norm.weight, cos, sin, s_rope=S_img)
+        if self.hybrid_seq_parallel_attn:
+            attn = my_parallel_attention(self.hybrid_seq_parallel_attn, q, k, qkv[:, :, 2], img_q_len=S_img,
+                                         img_kv_len=S_img, cu_seqlens_q=cu_seqlens_q, cu_seqlens_kv=cu_seqlens_kv,
+                                         top_k=ulysses.get_sequence_parallel_world_size() * top_k, text_amp=txt_amp,
+                                         block_neighbor_list=block_neighbor_list, p_remain_rates=p_remain_rates)
+            cat[..., :C] = attn
+        elif sa_drop_rate == 0.0:
+            cat[..., :C] = dense_attention(q, k, qkv[:, :, 2], cu_seqlens_q=cu_seqlens_q, cu_seqlens_kv=cu_seqlens_kv)
+        else:
+            vt = _capi.pack_v(qkv[:, :, 2], S // 128)
+            op.attencarve_packed(q, k, vt, top_k, cu_seqlens_q[1:2], txt_block_num, txt_amp, p_remain_rates,
+                                 block_neighbor_list, out=attn_out, pooled=pooled)
+
     @torch.no_grad()
     def forward(self, x, vec, txt_len, cu_seqlens_q=None, cu_seqlens_kv=None, max_seqlen_q=None, max_seqlen_kv=None,
                 freqs_cis: Tuple[torch.Tensor, torch.Tensor] = None, sa_drop_rate: float = 0.0, txt_amp: float = 1.0,
@@ -225,36 +280,23 @@ class MMSingleStreamBlock(nn.Module):
         qkv = lin1[..., : 3 * C].unflatten(-1, (3, H, 128))                        # strided views, no copies
         mlp = lin1[..., 3 * C:]
         cos, sin = freqs_cis
-        sparse = (not self.hybrid_seq_parallel_attn) and sa_drop_rate != 0.0 and S % 128 == 0 and S_img % 128 == 0
-        pooled = None
-        if S % 128 == 0:   # Q and K in one kernel (RoPE on image tokens only), block means for the selection on the way
-            q = torch.empty((B, S, H, 128), dtype=x.dtype, device=x.device)
-            k = torch.empty_like(q)
-            if sparse:
-                pooled = (torch.empty((B, H, S_img // 128, 128), dtype=x.dtype, device=x.device),
-                          torch.empty((B, H, S // 128, 128), dtype=x.dtype, device=x.device))
-            _capi.qk_norm_rope_pool(qkv[:, :, 0], qkv[:, :, 1], self.q_norm.weight, self.k_norm.weight, cos, sin, q, k,
-                                    s_rope=S_img, qpool=pooled[0] if pooled else None,
-                                    kpool=pooled[1] if pooled else None)
-        else:
-            q = _capi.rmsnorm_rope(qkv[:, :, 0], self.q_norm.weight, cos, sin, s_rope=S_img)
-            k = _capi.rmsnorm_rope(qkv[:, :, 1], self.k_norm.weight, cos, sin, s_rope=S_img)
         block_neighbor_list = curve_sel[0][2] if curve_sel is not None else None
         top_k = _select_top_k(sa_drop_rate, S_img // per_block_token)
         # concat buffer for linear2: attention writes its [B,S,H*128] output straight into the left part
         cat = torch.empty((B, S, C + self.mlp_hidden_dim), dtype=x.dtype, device=x.device)
-        if self.hybrid_seq_parallel_attn:
-            attn = my_parallel_attention(self.hybrid_seq_parallel_attn, q, k, qkv[:, :, 2], img_q_len=S_img,
-                                         img_kv_len=S_img, cu_seqlens_q=cu_seqlens_q, cu_seqlens_kv=cu_seqlens_kv,
-                                         top_k=ulysses.get_sequence_parallel_world_size() * top_k, text_amp=txt_amp,
-                                         block_neighbor_list=block_neighbor_list, p_remain_rates=p_remain_rates)
-            cat[..., :C] = attn
-        elif sa_drop_rate == 0.0:
-            cat[..., :C] = dense_attention(q, k, qkv[:, :, 2], cu_seqlens_q=cu_seqlens_q, cu_seqlens_kv=cu_seqlens_kv)
+        attn_out = cat[..., :C].unflatten(-1, (H, 128))
+        sp = self.hybrid_seq_parallel_attn
+        if sp and hasattr(sp, "forward_qkv"):
+            # fused sequence-parallel prologue (see MMDoubleStreamBlock): image rows -> peer-major send buffers, this
+            # rank's head slice of the text rows -> in place; the unpack kernels write into the concat buffer
+            w = (self.q_norm.weight, self.k_norm.weight)
+            sp.forward_qkv(tuple(qkv[:, :S_img, i] for i in range(3)), tuple(qkv[:, S_img:, i] for i in range(3)), w, w,
+                           (cos, sin), top_k=ulysses.get_sequence_parallel_world_size() * top_k, text_amp=txt_amp,
+                           block_neighbor_list=block_neighbor_list, p_remain_rates=p_remain_rates,
+                           cu_seqlens_q=cu_seqlens_q, out=attn_out)
         else:
-            vt = _capi.pack_v(qkv[:, :, 2], S // 128)
-            op.attencarve_packed(q, k, vt, top_k, cu_seqlens_q[1:2], txt_block_num, txt_amp, p_remain_rates,
-                                 block_neighbor_list, out=cat[..., :C].unflatten(-1, (H, 128)), pooled=pooled)
+            self._attention_unfused(qkv, S_img, cos, sin, sa_drop_rate, top_k, txt_amp, txt_block_num, p_remain_rates,
+                                    block_neighbor_list, cu_seqlens_q, cu_seqlens_kv, cat, attn_out)
         _capi.gelu_tanh(mlp, out=cat[..., C:])
         return _capi.gate_residual(x, self.linear2(cat), mod_gate, gate2=tr[2], mask=fm)
 

@@ -178,24 +178,39 @@ def _wait_all(works):
         w.wait()
 
 
+def _hip_prologue(xq, xk, xv, wq, wk, cos, sin, outs, Hn, head0, n_heads, s_rope):
+    """RMSNorm + RoPE of Q, K and the head scatter of Q, K, V in one HIP launch (jenga_sp_qkv_prologue)."""
+    _capi.sp_qkv_prologue(xq, xk, xv, wq, wk, cos, sin, outs[0], outs[1], outs[2], Hn, head0=head0, n_heads=n_heads,
+                          s_rope=s_rope)
+
+
 class UlyssesAttenCarve(torch.nn.Module):
     """Callable with the signature of xFuserLongContextAttention.forward (xdit_ring_atten.py:61-85); assign an
     instance to `block.hybrid_seq_parallel_attn` exactly as jenga_hyvideo_multigpu.py:181-182 does.
+
+    Two entry points:
+      forward(...)      the reference's signature: already normalised / rotated q, k, v of the local shard
+      forward_qkv(...)  (jenga_amd.dit's blocks) the RAW q / k / v slices of the QKV GEMM outputs: per-head RMSNorm,
+                        RoPE and the peer-major pack of all three happen in ONE kernel per stream (image | text),
+                        the text call writing this rank's head slice straight into the attention inputs
 
     The local steps are injectable so that the world_size > 1 exchange logic can be exercised on CPU tensors over gloo
     against the oracle (tests/test_ulysses_gloo.py supplies oracle stand-ins); the defaults are the HIP kernels and
     raise on CPU tensors -- there is no CPU path in the product:
       select_fn(q_all, k_all, top_k, text_blocks, p, neighbors) -> (idx, cnt)
       attend_fn(q_all, k_all, v_all, idx, cnt, seqlens, text_blocks, text_amp) -> [1,S,H/N,D]
-      pack_fn(t [B,S_loc,H,D], N) -> [N,B,S_loc,H/N,D];  unpack_fn(recv [N,B,S_loc,H/N,D], N, out [B,S_loc,H,D])"""
+      pack_fn(t [B,S_loc,H,D], N) -> [N,B,S_loc,H/N,D];  unpack_fn(recv [N,B,S_loc,H/N,D], N, out [B,S_loc,H,D])
+      prologue_fn(xq, xk, xv, wq, wk, cos, sin, (oq, ok, ov), H/N, head0, n_heads, s_rope)"""
 
-    def __init__(self, group=None, select_fn=None, attend_fn=None, pack_fn=None, unpack_fn=None, exchange=None):
+    def __init__(self, group=None, select_fn=None, attend_fn=None, pack_fn=None, unpack_fn=None, exchange=None,
+                 prologue_fn=None):
         super().__init__()
         self.group = group
         self.select_fn = select_fn or _hip_select
         self.attend_fn = attend_fn or _hip_attend
         self.pack_fn = pack_fn or _pack_heads
         self.unpack_fn = unpack_fn or _unpack_heads
+        self.prologue_fn = prologue_fn or _hip_prologue
         self._exchange = exchange
 
     def exchange(self):
@@ -220,13 +235,66 @@ class UlyssesAttenCarve(torch.nn.Module):
             recvs.append(full[0, :S_img].view(N, S_loc, Hn, D))
         return sends, fulls, recvs
 
-    def stage_out(self, o_recv, txt_all, N, S_loc, S_txt, dtype, device):
-        """o_recv [N,S_loc,Hn,D] (chunk p = my tokens, rank p's heads), txt_all [N,1,S_txt,Hn,D] -> [1,S_loc+S_txt,H,D]."""
+    def stage_in_fused(self, img, txt, w_img, w_txt, cos, sin, N, r):
+        """img / txt: (q, k, v) raw slices [1,S_loc,H,D] / [1,S_txt,H,D] of the QKV GEMM outputs; w_*: (wq, wk) RMSNorm
+        weights.  Same return value as stage_in, produced by two launches of the fused prologue."""
+        B, S_loc, H, D = img[0].shape
+        Hn = H // N
+        S_txt = txt[0].shape[1]
+        S_img = S_loc * N
+        dt, dev = img[0].dtype, img[0].device
+        sends = [torch.empty((N, B, S_loc, Hn, D), dtype=dt, device=dev) for _ in range(3)]
+        fulls = [torch.empty((B, S_img + S_txt, Hn, D), dtype=dt, device=dev) for _ in range(3)]
+        self.prologue_fn(img[0], img[1], img[2], w_img[0], w_img[1], cos, sin, sends, Hn, 0, H, S_loc)
+        self.prologue_fn(txt[0], txt[1], txt[2], w_txt[0], w_txt[1], None, None, [f[:, S_img:] for f in fulls], Hn,
+                         r * Hn, Hn, 0)
+        recvs = [f[0, :S_img].view(N, S_loc, Hn, D) for f in fulls]
+        return [s_.view(N, S_loc, Hn, D) for s_ in sends], fulls, recvs
+
+    def stage_out(self, o_recv, txt_all, N, S_loc, S_txt, dtype, device, out=None):
+        """o_recv [N,S_loc,Hn,D] (chunk p = my tokens, rank p's heads), txt_all [N,1,S_txt,Hn,D] -> [1,S_loc+S_txt,H,D]
+        (written into `out` when given: may be a strided view, e.g. the left part of linear2's concat buffer)."""
         Hn, D = o_recv.shape[-2:]
-        result = torch.empty((1, S_loc + S_txt, N * Hn, D), dtype=dtype, device=device)
+        result = out if out is not None else torch.empty((1, S_loc + S_txt, N * Hn, D), dtype=dtype, device=device)
         self.unpack_fn(o_recv.view(N, 1, S_loc, Hn, D), N, result[:, :S_loc])
         self.unpack_fn(txt_all, N, result[:, S_loc:])
         return result
+
+    def _run(self, ex, N, sends, fulls, recvs, S_loc, S_txt, top_k, text_amp, block_neighbor_list, p_remain_rates,
+             cu_seqlens_q, out=None):
+        q_all, k_all, v_all = fulls
+        S_img = S_loc * N
+        B, _, Hn, D = q_all.shape
+        dev, dt = q_all.device, q_all.dtype
+        # ---- exchange in: scatter heads / gather sequence; Q+K first, V behind them on the communication stream
+        w_qk = ex.all_to_all(recvs[:2], sends[:2])
+        w_v = ex.all_to_all(recvs[2:], sends[2:])
+        # cu_seqlens = [0, n_valid_text + S_img, S] (xdit_ring_atten.py:105,183-184) -- stays on the device
+        seqlens = (cu_seqlens_q[1:2].to(torch.int64) - S_loc + S_img).to(device=dev, dtype=torch.int32)
+        _wait_all(w_qk)
+        idx, cnt = self.select_fn(q_all, k_all, top_k, S_txt // 128, p_remain_rates, block_neighbor_list)
+        _wait_all(w_v)                                         # the V transfer overlapped pooling + selection
+        o = self.attend_fn(q_all, k_all, v_all, idx, cnt, seqlens, S_txt // 128, text_amp)
+        # ---- exchange out: image rows (already peer-major: chunk p = rank p's tokens) back to sequence shards;
+        #      text rows gathered over heads (the reference repeats them N times and all-to-alls, :206-217)
+        o_img = o[0, :S_img].reshape(N, S_loc, Hn, D)
+        if not o_img.is_contiguous():
+            o_img = o_img.contiguous()
+        o_recv = torch.empty((N, S_loc, Hn, D), dtype=dt, device=dev)
+        txt_all = torch.empty((N, B, S_txt, Hn, D), dtype=dt, device=dev)
+        w_o = ex.all_to_all([o_recv], [o_img])
+        w_t = ex.all_gather(txt_all, o[:, S_img:])
+        _wait_all(w_o)
+        w_t.wait()
+        return self.stage_out(o_recv, txt_all, N, S_loc, S_txt, dt, dev, out=out)
+
+    def _check(self, B, S_loc, H, S_txt, N):
+        if B != 1:
+            raise ValueError("jenga_amd Ulysses: batch must be 1")
+        if H % N:
+            raise ValueError(f"heads ({H}) must be divisible by the sequence-parallel degree ({N})")
+        if (S_loc * N) % 128 or S_txt % 128:
+            raise ValueError("gathered image length and text length must be multiples of 128")
 
     @torch.no_grad()
     def forward(self, attn, query, key, value, *, joint_tensor_query=None, joint_tensor_key=None,
@@ -239,39 +307,29 @@ class UlyssesAttenCarve(torch.nn.Module):
         ex = self.exchange()
         N, r = ex.size(), ex.rank()
         B, S_loc, H, D = query.shape
-        if B != 1:
-            raise ValueError("jenga_amd Ulysses: batch must be 1")
-        if H % N:
-            raise ValueError(f"heads ({H}) must be divisible by the sequence-parallel degree ({N})")
-        Hn = H // N
         S_txt = joint_tensor_query.shape[1]
-        S_img = S_loc * N
-        if S_img % 128 or S_txt % 128:
-            raise ValueError("gathered image length and text length must be multiples of 128")
-        dev, dt = query.device, query.dtype
-        # ---- exchange in: scatter heads / gather sequence; Q+K first, V behind them on the communication stream
-        sends, (q_all, k_all, v_all), recvs = self.stage_in(query, key, value, joint_tensor_query, joint_tensor_key,
-                                                            joint_tensor_value, N, r)
-        w_qk = ex.all_to_all(recvs[:2], sends[:2])
-        w_v = ex.all_to_all(recvs[2:], sends[2:])
-        # cu_seqlens = [0, n_valid_text + S_img, S] (xdit_ring_atten.py:105,183-184) -- stays on the device
-        seqlens = (cu_seqlens_q[1:2].to(torch.int64) - S_loc + S_img).to(device=dev, dtype=torch.int32)
-        _wait_all(w_qk)
-        idx, cnt = self.select_fn(q_all, k_all, top_k, S_txt // 128, p_remain_rates, block_neighbor_list)
-        _wait_all(w_v)                                         # the V transfer overlapped pooling + selection
-        out = self.attend_fn(q_all, k_all, v_all, idx, cnt, seqlens, S_txt // 128, text_amp)
-        # ---- exchange out: image rows (already peer-major: chunk p = rank p's tokens) back to sequence shards;
-        #      text rows gathered over heads (the reference repeats them N times and all-to-alls, :206-217)
-        o_img = out[0, :S_img].reshape(N, S_loc, Hn, D)
-        if not o_img.is_contiguous():
-            o_img = o_img.contiguous()
-        o_recv = torch.empty((N, S_loc, Hn, D), dtype=dt, device=dev)
-        txt_all = torch.empty((N, B, S_txt, Hn, D), dtype=dt, device=dev)
-        w_o = ex.all_to_all([o_recv], [o_img])
-        w_t = ex.all_gather(txt_all, out[:, S_img:])
-        _wait_all(w_o)
-        w_t.wait()
-        return self.stage_out(o_recv, txt_all, N, S_loc, S_txt, dt, dev)
+        self._check(B, S_loc, H, S_txt, N)
+        sends, fulls, recvs = self.stage_in(query, key, value, joint_tensor_query, joint_tensor_key,
+                                            joint_tensor_value, N, r)
+        return self._run(ex, N, sends, fulls, recvs, S_loc, S_txt, top_k, text_amp, block_neighbor_list,
+                         p_remain_rates, cu_seqlens_q)
+
+    @torch.no_grad()
+    def forward_qkv(self, img_qkv, txt_qkv, img_norm_w, txt_norm_w, freqs_cis, *, top_k=0, text_amp=0.0,
+                    block_neighbor_list=None, p_remain_rates=0.0, cu_seqlens_q=None, out=None):
+        """The fused entry (jenga_amd.dit): img_qkv / txt_qkv = (q, k, v) RAW slices of the QKV GEMM outputs of the
+        local image shard [1,S_loc,H,D] and of the (replicated) text rows [1,S_txt,H,D]; *_norm_w = (q_norm.weight,
+        k_norm.weight); freqs_cis = (cos, sin) rows of the local shard.  Same result as forward() on the
+        normalised / rotated tensors, bit for bit; returns [1, S_loc + S_txt, H, D] (in `out` when given)."""
+        ex = self.exchange()
+        N, r = ex.size(), ex.rank()
+        B, S_loc, H, D = img_qkv[0].shape
+        S_txt = txt_qkv[0].shape[1]
+        self._check(B, S_loc, H, S_txt, N)
+        cos, sin = freqs_cis
+        sends, fulls, recvs = self.stage_in_fused(img_qkv, txt_qkv, img_norm_w, txt_norm_w, cos, sin, N, r)
+        return self._run(ex, N, sends, fulls, recvs, S_loc, S_txt, top_k, text_amp, block_neighbor_list,
+                         p_remain_rates, cu_seqlens_q, out=out)
 
 
 # name the reference uses (jenga_hyvideo_multigpu.py:181)

@@ -58,3 +58,27 @@ def unpack_heads(recv, n_ranks, out):
     out.copy_(recv.permute(1, 2, 0, 3, 4).reshape(B, S, Np * Hn, D))
     return out
 
+
+
+def qkv_prologue(xq, xk, xv, wq, wk, cos, sin, outs, heads_per_peer, head0, n_heads, s_rope, dtype="bfloat16"):
+    """Stand-in for jenga_sp_qkv_prologue on CPU tensors (tests only): per-head RMSNorm of q, k
+    (norm_layers.py:56-59), RoPE on tokens < s_rope (posemb_layers.py:181-229), then head h of q, k, v goes to
+    outs[i][h // heads_per_peer, ..., h % heads_per_peer, :] (peer-major outputs [N,B,S,Hn,D]) or to
+    outs[i][..., h - head0, :] (head-window outputs [B,S,n_heads,D]) -- xdit_ring_atten.py:118-131 / :159-175."""
+    import torch
+
+    from . import norm_rope as onr
+    tn = lambda t: t.detach().float().numpy()
+    res = []
+    for x, w in ((xq, wq), (xk, wk)):
+        y = onr.rmsnorm(tn(x), None if w is None else tn(w), dtype)
+        if cos is not None and s_rope > 0:
+            y[:, :s_rope] = onr.apply_rotary_emb(y[:, :s_rope], tn(cos)[:s_rope], tn(sin)[:s_rope], dtype)
+        res.append(torch.from_numpy(y).to(xq.dtype))
+    res.append(xv)
+    for o, y in zip(outs, res):
+        y = y[:, :, head0:head0 + n_heads]
+        if o.dim() == 5:
+            o.copy_(pack_heads(y, o.shape[0]))
+        else:
+            o.copy_(y)

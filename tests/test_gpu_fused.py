@@ -70,3 +70,64 @@ def test_qk_norm_rope_pool_rejects_bad_arguments(dev):
         _capi.qk_norm_rope_pool(x, x.transpose(1, 2).contiguous().transpose(1, 2), None, None, None, None, o, o)
     with pytest.raises(ValueError):
         _capi.qk_norm_rope_pool(x, x, None, None, None, None, o, o, qpool=torch.zeros(1, 2, 2, 64, device=dev))
+
+
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("N,H,S_loc,S_txt", [(8, 24, 400, 256), (2, 8, 256, 256), (4, 8, 72, 512)])
+def test_sp_qkv_prologue_equals_norm_rope_plus_pack(dev, dt, N, H, S_loc, S_txt):
+    """jenga_sp_qkv_prologue (one launch: RMSNorm + RoPE of Q, K and the peer-major pack of Q, K, V; any shard length)
+    against the five launches it replaces -- jenga_rmsnorm_rope x 2 + jenga_ulysses_pack_heads x 3 -- bit for bit, and
+    the head-window form (a rank's own slice of the replicated text rows, written in place) against norm + slice."""
+    from jenga_amd import _capi
+    g = torch.Generator(device=dev).manual_seed(N * 1000 + S_loc)
+    Hn = H // N
+    S = S_loc + S_txt
+    lin = (torch.randn(1, S, 3 * H * 128 + 64, generator=g, device=dev) * 1.7).to(dt)     # linear1's layout: qkv | mlp
+    qkv = lin[..., : 3 * H * 128].unflatten(-1, (3, H, 128))
+    wq = (1 + 0.1 * torch.randn(128, generator=g, device=dev)).to(dt)
+    wk = (1 + 0.1 * torch.randn(128, generator=g, device=dev)).to(dt)
+    cos = torch.randn(S_loc, 128, generator=g, device=dev)
+    sin = torch.randn(S_loc, 128, generator=g, device=dev)
+    img = [qkv[:, :S_loc, i] for i in range(3)]
+    txt = [qkv[:, S_loc:, i] for i in range(3)]
+    # ---- image rows -> peer-major send buffers
+    sends = [torch.full((N, 1, S_loc, Hn, 128), 7.0, dtype=dt, device=dev) for _ in range(3)]
+    _capi.sp_qkv_prologue(img[0], img[1], img[2], wq, wk, cos, sin, sends[0], sends[1], sends[2], Hn, s_rope=S_loc)
+    q_ref = _capi.ulysses_pack_heads(_capi.rmsnorm_rope(img[0], wq, cos, sin, s_rope=S_loc), N)
+    k_ref = _capi.ulysses_pack_heads(_capi.rmsnorm_rope(img[1], wk, cos, sin, s_rope=S_loc), N)
+    v_ref = _capi.ulysses_pack_heads(img[2], N)
+    torch.cuda.synchronize()
+    assert torch.equal(sends[0], q_ref) and torch.equal(sends[1], k_ref) and torch.equal(sends[2], v_ref)
+    # ---- text rows: rank r's head slice straight into the tail of the gathered attention inputs
+    S_img = S_loc * N
+    for r in (0, N - 1):
+        fulls = [torch.zeros(1, S_img + S_txt, Hn, 128, dtype=dt, device=dev) for _ in range(3)]
+        _capi.sp_qkv_prologue(txt[0], txt[1], txt[2], wq, wk, None, None, fulls[0][:, S_img:], fulls[1][:, S_img:],
+                              fulls[2][:, S_img:], Hn, head0=r * Hn, n_heads=Hn)
+        hs = slice(r * Hn, (r + 1) * Hn)
+        tq = _capi.rmsnorm_rope(txt[0], wq, None, None)[:, :, hs]
+        tk = _capi.rmsnorm_rope(txt[1], wk, None, None)[:, :, hs]
+        torch.cuda.synchronize()
+        assert torch.equal(fulls[0][:, S_img:], tq) and torch.equal(fulls[1][:, S_img:], tk)
+        assert torch.equal(fulls[2][:, S_img:], txt[2][:, :, hs])
+        assert not any(f[:, :S_img].any() for f in fulls)
+
+
+def test_sp_qkv_prologue_rejects_bad_arguments(dev):
+    from jenga_amd import _capi
+    x = torch.zeros(1, 40, 8, 128, dtype=torch.bfloat16, device=dev)
+    o = [torch.empty(4, 1, 40, 2, 128, dtype=torch.bfloat16, device=dev) for _ in range(3)]
+    with pytest.raises(ValueError):      # q / k / v strides differ
+        _capi.sp_qkv_prologue(x, x, x.transpose(1, 2).contiguous().transpose(1, 2), None, None, None, None, *o, 2)
+    with pytest.raises(ValueError):      # N * Hn != H
+        _capi.sp_qkv_prologue(x, x, x, None, None, None, None, *o, 4)
+    with pytest.raises(ValueError):      # head window not on a peer boundary
+        w = [torch.empty(1, 40, 2, 128, dtype=torch.bfloat16, device=dev) for _ in range(3)]
+        _capi.sp_qkv_prologue(x, x, x, None, None, None, None, *w, 2, head0=1, n_heads=2)
+    with pytest.raises(_capi.JengaError):   # the C ABI's own check (head window outside H)
+        w = [torch.empty(1, 40, 2, 128, dtype=torch.bfloat16, device=dev) for _ in range(3)]
+        _capi.lib()
+        _capi._check(_capi.lib().jenga_sp_qkv_prologue(None, _capi._p(x), _capi._p(x), _capi._p(x), _capi._p(w[0]),
+                                                       _capi._p(w[1]), _capi._p(w[2]), None, None, None, None, 1, 40, 8,
+                                                       8, 2, 2, *_capi._bshd_strides(x), 0, *_capi._bshd_strides(w[0]),
+                                                       0, 1e-6, 0), "jenga_sp_qkv_prologue")

@@ -57,16 +57,30 @@ def _record(name, rec):
         pass
 
 
-# (N, latent T H W, text tokens, i2v): image tokens = T * H/2 * W/2
+class _ReferenceSignatureOnly(torch.nn.Module):
+    """A sequence-parallel module that only offers xFuserLongContextAttention's forward (no forward_qkv): the blocks
+    then take the unfused path (norm / RoPE kernels, then the reference-signature call)."""
+
+    def __init__(self, inner):
+        super().__init__()
+        self.inner = inner
+
+    def forward(self, *a, **kw):
+        return self.inner(*a, **kw)
+
+
+# (N, latent T H W, text tokens, i2v, fused prologue): image tokens = T * H/2 * W/2
 CASES = [
-    (2, (4, 16, 32), 256, False),     # 512 tokens: S_loc = 256 (a multiple of 128)
-    (8, (4, 40, 80), 256, False),     # 3200 tokens = 25 blocks: S_loc = 400 (NOT a multiple of 128), top_k 8 vs 12
-    (4, (3, 24, 64), 512, True),      # I2V token_replace: 1152 tokens = 9 blocks, S_loc = 288, 4 text blocks
+    (2, (4, 16, 32), 256, False, True),     # 512 tokens: S_loc = 256 (a multiple of 128)
+    (8, (4, 40, 80), 256, False, True),     # 3200 tokens = 25 blocks: S_loc = 400 (NOT a multiple of 128), top_k 8 vs 12
+    (4, (3, 24, 64), 512, True, True),      # I2V token_replace: 1152 tokens = 9 blocks, S_loc = 288, 4 text blocks
+    (8, (4, 40, 80), 256, False, False),    # the reference-signature path (separate norm / RoPE / pack kernels)
+    (2, (3, 24, 64), 512, True, False),
 ]
 
 
-@pytest.mark.parametrize("N,latent,n_txt,i2v", CASES)
-def test_sp_forward_n_ranks_equals_single_rank(dev, N, latent, n_txt, i2v):
+@pytest.mark.parametrize("N,latent,n_txt,i2v,fused", CASES)
+def test_sp_forward_n_ranks_equals_single_rank(dev, N, latent, n_txt, i2v, fused):
     from jenga_amd import dit
     from jenga_amd.modules import ulysses
     base = _model(dev)
@@ -120,8 +134,10 @@ def test_sp_forward_n_ranks_equals_single_rank(dev, N, latent, n_txt, i2v):
             torch.cuda.set_device(dev)
             m = models[rank]
             ulysses.set_thread_sp_group(SimGroup(world, rank))
+            ex = SimExchange(world, rank)      # ONE exchange per rank: its call counter orders the collectives
             for blk in list(m.double_blocks) + list(m.single_blocks):
-                blk.hybrid_seq_parallel_attn = ulysses.UlyssesAttenCarve(exchange=SimExchange(world, rank))
+                sp = ulysses.UlyssesAttenCarve(exchange=ex)
+                blk.hybrid_seq_parallel_attn = sp if fused else _ReferenceSignatureOnly(sp)
             c, s = configure(m)
             results[rank] = run_steps(m, c, s)
         except Exception as e:                                 # noqa: BLE001 - surfaced below
@@ -139,7 +155,7 @@ def test_sp_forward_n_ranks_equals_single_rank(dev, N, latent, n_txt, i2v):
     assert not errors, errors
     torch.cuda.synchronize()
 
-    rec = {"N": N, "latent": list(latent), "S_loc": S_img // N, "i2v": i2v, "steps": []}
+    rec = {"N": N, "latent": list(latent), "S_loc": S_img // N, "i2v": i2v, "fused_prologue": fused, "steps": []}
     for si, (cnt, _) in enumerate(steps):
         # the gathered output is assembled from all ranks' shards, so every rank must hold the same tensor
         for r in range(1, N):
@@ -155,7 +171,7 @@ def test_sp_forward_n_ranks_equals_single_rank(dev, N, latent, n_txt, i2v):
     # the residual cache of a rank is its LOCAL shard (jenga_hyvideo_multigpu.py:296-305)
     for r in range(N):
         assert models[r].previous_residual.shape[1] == S_img // N
-    _record(f"N{N}_{'i2v' if i2v else 't2v'}", rec)
+    _record(f"N{N}_{'i2v' if i2v else 't2v'}_{'fused' if fused else 'unfused'}", rec)
 
 
 def test_first_frame_mask_on_a_chunked_order_matches_the_unchunked_mask(dev):

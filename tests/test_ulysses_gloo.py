@@ -76,6 +76,30 @@ def _worker(rank, world, port, ret, mode):
                                     cu_seqlens_kv=cu, top_k=world * top_k_local, text_amp=0.25,
                                     block_neighbor_list=torch.from_numpy(nbm), p_remain_rates=0.3)
         ret[rank] = out.float().numpy()
+        # the fused entry point the DiT blocks use (forward_qkv: RAW q / k / v, norm + RoPE + pack in one local step):
+        # must equal forward() on the separately normalised / rotated tensors, bit for bit
+        from oracle import norm_rope as onr
+        g2 = torch.Generator().manual_seed(5)
+        H = q.shape[2]
+        raw = [torch.randn(1, S_loc + tb * 128, H, 128, generator=g2).to(torch.bfloat16) for _ in range(3)]
+        wq = (1 + 0.1 * torch.randn(128, generator=g2)).to(torch.bfloat16)
+        wk = (1 + 0.1 * torch.randn(128, generator=g2)).to(torch.bfloat16)
+        cos, sin = (torch.randn(S_loc, 128, generator=g2) for _ in range(2))
+        sp2 = ulysses.UlyssesAttenCarve(select_fn=_oracle_select, attend_fn=_oracle_attend, pack_fn=ou.pack_heads,
+                                        unpack_fn=ou.unpack_heads, prologue_fn=ou.qkv_prologue,
+                                        exchange=ulysses.DistExchange(ulysses.get_sp_group().group, mode=mode))
+        kw = dict(top_k=world * top_k_local, text_amp=0.25, block_neighbor_list=torch.from_numpy(nbm),
+                  p_remain_rates=0.3, cu_seqlens_q=cu)
+        fused = sp2.forward_qkv(tuple(t[:, :S_loc] for t in raw), tuple(t[:, S_loc:] for t in raw), (wq, wk), (wq, wk),
+                                (cos, sin), **kw)
+        nrm = []
+        for t, w in ((raw[0], wq), (raw[1], wk)):
+            y = onr.rmsnorm(to_np(t), to_np(w), "bfloat16")
+            y[:, :S_loc] = onr.apply_rotary_emb(y[:, :S_loc], cos.numpy(), sin.numpy(), "bfloat16")
+            nrm.append(torch.from_numpy(y).to(torch.bfloat16))
+        unfused = my_parallel_attention(sp2, nrm[0], nrm[1], raw[2], img_q_len=S_loc, img_kv_len=S_loc,
+                                        cu_seqlens_kv=cu, **kw).reshape(fused.shape)
+        assert torch.equal(fused, unfused), "forward_qkv differs from forward on the normalised tensors"
         # the all_gather used by the driver (jenga_hyvideo_multigpu.py:193)
         g = ulysses.get_sp_group().all_gather(torch.full((1, 2, 3), float(rank)), dim=1)
         assert g.shape == (1, 2 * world, 3) and g[0, 2 * rank, 0] == rank
