@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define JENGA_ABI_VERSION 1
+#define JENGA_ABI_VERSION 2   /* 2: jenga_block_select(flags), jenga_bsattn_fwd(order), jenga_sp_qkv_prologue, jenga_order_by_count */
 
 enum { JENGA_OK = 0, JENGA_EINVAL = 1, JENGA_ELAUNCH = 2, JENGA_EUNSUPPORTED = 3 };
 enum { JENGA_BF16 = 0, JENGA_FP16 = 1 };
@@ -172,11 +172,19 @@ int jenga_block_pool(void* stream, const void* x, void* pooled, int64_t B, int64
  *   neighbors: uint8 [nb_rows, nb_cols] row-major (row stride nb_cols) or NULL
  * Outputs (either may be NULL):
  *   mask  uint8 [B,H,nq,nk_all]            the reference's one-hot layout (for parity checks)
- *   idx   int32 [B,H,nq,nk_all], cnt int32 [B,H,nq]   ascending kept-column lists for jenga_bsattn_fwd */
+ *   idx   int32 [B,H,nq,nk_all], cnt int32 [B,H,nq]   ascending kept-column lists for jenga_bsattn_fwd
+ * flags: JENGA_SELECT_DEVICE_SCAN replaces the cumulative sum by what torch.cumsum computes for a 16-bit tensor ON THE
+ *   DEVICE (the reference as shipped runs :241-250 on a CUDA bf16 tensor): ATen's blocked scan
+ *   (ATen/native/cuda/ScanUtils.cuh, torch 2.10: tensor_kernel_scan_innermost_dim_impl) restated -- chunks of
+ *   2 * 2^l columns, l = get_log_num_threads_x_inner_scan(B*H*nq, nk_img) (16 columns x 2 at the production shapes), a
+ *   Sklansky network per chunk with EVERY add rounded to the 16-bit dtype, the chunk total carried in the 16-bit dtype;
+ *   all columns with cumsum <= p are counted.  tests/test_gpu_select.py checks the kept counts against torch.cumsum on
+ *   the device bit for bit.  Default (0): the CPU semantics above. */
+#define JENGA_SELECT_DEVICE_SCAN 1
 int jenga_block_select(void* stream, const void* qpool, const void* kpool, const uint8_t* neighbors,
                        int64_t nb_rows, int64_t nb_cols, uint8_t* mask, int32_t* idx, int32_t* cnt,
                        int64_t B, int64_t H, int64_t nq, int64_t nk_img, int64_t text_blocks, int64_t top_k,
-                       float p, int64_t first_frame_blocks, int dtype);
+                       float p, int64_t first_frame_blocks, int dtype, int flags);
 
 /* ---------------------------------------------------------------------------------------------------
  * Block-sparse attention forward.  Replaces _triton_block_sparse_attn_fwd_kernel_onehot + launcher
@@ -200,32 +208,44 @@ size_t jenga_pack_v_bytes(int64_t B, int64_t H, int64_t n_blocks);
 int jenga_pack_v(void* stream, const void* v, void* vt, int64_t B, int64_t H, int64_t n_blocks, int64_t v_sb,
                  int64_t v_ss, int64_t v_sh, int64_t dst_block0, int64_t dst_blocks_total, int dtype);
 int jenga_bsattn_fwd(void* stream, const void* q, const void* k, const void* vt, void* o,
-                     const int32_t* seqlens, const int32_t* idx, const int32_t* cnt, int64_t B, int64_t H,
-                     int64_t n_blocks, int64_t nq_img, int64_t q_sb, int64_t q_ss, int64_t q_sh, int64_t k_sb,
-                     int64_t k_ss, int64_t k_sh, int64_t o_sb, int64_t o_ss, int64_t o_sh, float sm_scale,
-                     float text_amp, int64_t text_block_start, int dtype, int flags);
-/* flags: which of the three parity-equivalent kernels runs (DESIGN.md section 3 has the measurements)
+                     const int32_t* seqlens, const int32_t* idx, const int32_t* cnt, const int32_t* order, int64_t B,
+                     int64_t H, int64_t n_blocks, int64_t nq_img, int64_t q_sb, int64_t q_ss, int64_t q_sh,
+                     int64_t k_sb, int64_t k_ss, int64_t k_sh, int64_t o_sb, int64_t o_ss, int64_t o_sh,
+                     float sm_scale, float text_amp, int64_t text_block_start, int dtype, int flags);
+/* flags: launch order and which of the parity-equivalent kernels runs (DESIGN.md section 3 has the measurements)
  *   neither PINGPONG nor LP: the round-1 kernel (csrc/bsattn.hip), 4-wave workgroup per 128-row query block */
 #define JENGA_ATTN_XCD_REMAP 1 /* contiguous q-block ranges per XCD (L2 locality); 0 = plain head-major order */
-#define JENGA_ATTN_PINGPONG 2  /* 8-wave workgroups, MFMA / softmax phases of the two waves per SIMD in anti-phase */
+#define JENGA_ATTN_PINGPONG 2  /* EXPERIMENT (libraries built with JENGA_EXPERIMENTS only; else JENGA_EUNSUPPORTED):
+                                  8-wave workgroups, MFMA / softmax phases of the two waves per SIMD in anti-phase */
 #define JENGA_ATTN_LP 8        /* same decomposition, in-wave software pipeline (softmax inside the MFMA stream):
                                   csrc/bsattn3.hip, the default of the Python modules (XCD_REMAP | LP) */
+/* order (may be NULL): int32 [B,H,nq_img], launch position -> image query block, a permutation per (b, h) -- a
+ *   scheduling hint only (every query block is computed exactly once either way, results are bit-identical).
+ *   jenga_order_by_count fills it from cnt: inside every segment of `segment` consecutive query blocks the blocks are
+ *   ordered by DESCENDING kept count (ties: lower block first), so that the longest lists of a range start first and
+ *   the short ones fill the tail (reference grid: attention_block_triton_diffres.py:165 launches in plain order).
+ *   With JENGA_ATTN_XCD_REMAP use segment = ceil(nq_img / 8) (= one XCD's contiguous range); without it
+ *   segment = nq_img.  The LP kernel honours it; the round-1 kernel ignores it. */
+int jenga_order_by_count(void* stream, const int32_t* cnt, int64_t BH, int64_t nq_img, int64_t segment,
+                         int32_t* order);
 
-/* Step 2, pair variant (a measured alternative, not the default: it halves the staged bytes of shared kv blocks but
- * even with 85 % of the blocks shared it ran 1017 TFLOP/s against 1044-1056 for jenga_bsattn_fwd on the same lists,
- * DESIGN.md section 3): two Hilbert-adjacent query blocks per
- * workgroup, kv blocks kept by BOTH staged once for 256 query rows, one wave per SIMD with the softmax of one
- * (32-row, 64-key) item interleaved into the MFMA stream of its neighbours (csrc/bsattn2.hip).
+#ifdef JENGA_EXPERIMENTS
+/* ---- measured alternatives, NOT part of the product library (python -m jenga_amd.build --experiments builds
+ * libjenga_amd_exp.so = the product sources + csrc/experiments/ with -DJENGA_EXPERIMENTS) ------------------------------
+ * Pair variant: it halves the staged bytes of shared kv blocks but even with 85 % of the blocks shared it ran
+ * 1017 TFLOP/s against 1044-1056 for jenga_bsattn_fwd on the same lists: two Hilbert-adjacent
+ * query blocks per workgroup, kv blocks kept by BOTH staged once for 256 query rows, one wave per SIMD with the softmax
+ * of one (32-row, 64-key) item interleaved into the MFMA stream of its neighbours (csrc/experiments/bsattn2.hip).
  *   jenga_pair_merge: idx/cnt of jenga_block_select ->
  *       pidx int32 [B,H,ceil(nq_img/2),n_blocks]: per query-block pair (2j, 2j+1) the kv blocks both rows keep, then
  *            those only row 2j keeps, then those only row 2j+1 keeps -- each part ascending;
  *       pcnt int32 [B,H,ceil(nq_img/2),4]: the three part lengths, 0.   (odd nq_img: the last pair has one row)
  *   jenga_bsattn_pair_fwd: same arguments and semantics as jenga_bsattn_fwd with (pidx, pcnt) in place of (idx, cnt).
  *       The kv blocks of a row are visited in the order (only-this-row, shared) instead of ascending; online softmax
- *       is order independent up to fp32 rounding and every rescale stays an exact power of two. */
-/*   flags of jenga_bsattn_pair_fwd: JENGA_ATTN_XCD_REMAP; with JENGA_ATTN_LP the 8-wave "LP pair" experiment runs
- *   instead (csrc/bsattn4.hip: two query blocks per 512-thread workgroup, shared kv blocks staged once for both;
- *   restriction: no masked image block in an unshared list, i.e. seqlens >= the image length). */
+ *       is order independent up to fp32 rounding and every rescale stays an exact power of two.
+ *   flags of jenga_bsattn_pair_fwd: JENGA_ATTN_XCD_REMAP; with JENGA_ATTN_LP the 8-wave "LP pair" experiment runs
+ *   instead (csrc/experiments/bsattn4.hip: two query blocks per 512-thread workgroup, shared kv blocks staged once for
+ *   both; restriction: no masked image block in an unshared list, i.e. seqlens >= the image length). */
 int jenga_pair_merge(void* stream, const int32_t* idx, const int32_t* cnt, int64_t B, int64_t H, int64_t nq_img,
                      int64_t n_blocks, int32_t* pidx, int32_t* pcnt);
 int jenga_bsattn_pair_fwd(void* stream, const void* q, const void* k, const void* vt, void* o,
@@ -233,6 +253,7 @@ int jenga_bsattn_pair_fwd(void* stream, const void* q, const void* k, const void
                           int64_t n_blocks, int64_t nq_img, int64_t q_sb, int64_t q_ss, int64_t q_sh, int64_t k_sb,
                           int64_t k_ss, int64_t k_sh, int64_t o_sb, int64_t o_ss, int64_t o_sh, float sm_scale,
                           float text_amp, int64_t text_block_start, int dtype, int flags);
+#endif /* JENGA_EXPERIMENTS */
 
 /* ---------------------------------------------------------------------------------------------------
  * Ulysses head pack/unpack: the local halves of xFuserLongContextAttention.forward's SeqAllToAll4D calls

@@ -10,12 +10,17 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("JENGA_LIB", os.path.join(_HERE, "libjenga_amd.so"))
 
 JENGA_BF16, JENGA_FP16 = 0, 1
+# jenga_bsattn_fwd flags (include/jenga_amd.h).  No kernel bit = the round-1 kernel, exactly as in the C header.
 ATTN_XCD_REMAP = 1
-ATTN_PINGPONG = 2
-ATTN_LEGACY = 4      # (Python-side switch) the round-1 kernel: one 128-row query block per 4-wave workgroup
-ATTN_LP = 8          # round-1 decomposition + in-wave software pipeline (csrc/bsattn3.hip)
-ATTN_PAIR = 64       # (Python-side switch) with ATTN_LP: the 8-wave LP pair experiment (csrc/bsattn4.hip)
-ATTN_DEFAULT_FLAGS = int(os.environ.get("JENGA_ATTN_FLAGS", str(ATTN_XCD_REMAP | 8)))   # LP kernel (csrc/bsattn3.hip)
+ATTN_PINGPONG = 2    # experiment: needs libjenga_amd_exp.so (python -m jenga_amd.build --experiments; JENGA_LIB=...)
+ATTN_LEGACY = 0      # (readability alias) no kernel bit: the round-1 kernel, one query block per 4-wave workgroup
+ATTN_LP = 8          # round-1 decomposition + in-wave software pipeline (csrc/bsattn3.hip): the default
+ATTN_SORTED = 16     # (Python-side) kept-count-aware launch order: jenga_order_by_count feeds jenga_bsattn_fwd's `order`
+ATTN_PAIR = 64       # (Python-side, experiment) route to jenga_bsattn_pair_fwd: the pair kernel; with ATTN_LP the 8-wave
+#                      LP pair (csrc/experiments/); needs libjenga_amd_exp.so
+ATTN_DEFAULT_FLAGS = int(os.environ.get("JENGA_ATTN_FLAGS", str(ATTN_XCD_REMAP | ATTN_LP)))
+SELECT_DEVICE_SCAN = 1   # jenga_block_select flags: torch's DEVICE cumsum semantics for the kept-count rule
+SELECT_DEFAULT_FLAGS = int(os.environ.get("JENGA_SELECT_FLAGS", "0"))
 
 _vp, _i64, _i32, _f32 = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_float
 
@@ -37,14 +42,19 @@ SIGNATURES = {
     "jenga_qk_norm_rope_pool": (_i32, [_vp] * 11 + [_i64] * 13 + [_f32, _i32]),
     "jenga_sp_qkv_prologue": (_i32, [_vp] * 11 + [_i64] * 14 + [_f32, _i32]),
     "jenga_block_pool": (_i32, [_vp, _vp, _vp] + [_i64] * 6 + [_i32]),
-    "jenga_block_select": (_i32, [_vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp] + [_i64] * 6 + [_f32, _i64, _i32]),
+    "jenga_block_select": (_i32, [_vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp] + [_i64] * 6 + [_f32, _i64, _i32, _i32]),
+    "jenga_order_by_count": (_i32, [_vp, _vp, _i64, _i64, _i64, _vp]),
     "jenga_pack_v_bytes": (ctypes.c_size_t, [_i64, _i64, _i64]),
     "jenga_pack_v": (_i32, [_vp, _vp, _vp] + [_i64] * 8 + [_i32]),
-    "jenga_bsattn_fwd": (_i32, [_vp] * 8 + [_i64] * 13 + [_f32, _f32, _i64, _i32, _i32]),
-    "jenga_pair_merge": (_i32, [_vp, _vp, _vp] + [_i64] * 4 + [_vp, _vp]),
-    "jenga_bsattn_pair_fwd": (_i32, [_vp] * 8 + [_i64] * 13 + [_f32, _f32, _i64, _i32, _i32]),
+    "jenga_bsattn_fwd": (_i32, [_vp] * 9 + [_i64] * 13 + [_f32, _f32, _i64, _i32, _i32]),
     "jenga_ulysses_pack_heads": (_i32, [_vp, _vp, _vp] + [_i64] * 7),
     "jenga_ulysses_unpack_heads": (_i32, [_vp, _vp, _vp] + [_i64] * 7),
+}
+
+# the experiments library (libjenga_amd_exp.so, include/jenga_amd.h under JENGA_EXPERIMENTS) adds these
+EXPERIMENT_SIGNATURES = {
+    "jenga_pair_merge": (_i32, [_vp, _vp, _vp] + [_i64] * 4 + [_vp, _vp]),
+    "jenga_bsattn_pair_fwd": (_i32, [_vp] * 8 + [_i64] * 13 + [_f32, _f32, _i64, _i32, _i32]),
 }
 
 _lib = None
@@ -83,10 +93,19 @@ def lib():
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)
             fn.restype, fn.argtypes = res, args
-        if L.jenga_abi_version() != 1:
+        for name, (res, args) in EXPERIMENT_SIGNATURES.items():
+            if hasattr(L, name):
+                fn = getattr(L, name)
+                fn.restype, fn.argtypes = res, args
+        if L.jenga_abi_version() != 2:
             raise JengaError("libjenga_amd.so ABI version mismatch; rebuild")
         _lib = L
     return _lib
+
+
+def has_experiments():
+    """True when the loaded library was built with JENGA_EXPERIMENTS (pair / LP-pair / ping-pong kernels)."""
+    return hasattr(lib(), "jenga_bsattn_pair_fwd")
 
 
 def _check(rc, what):
@@ -430,8 +449,10 @@ def block_pool(x, n_blocks):
 
 
 def block_select(qpool, kpool, neighbors, nk_img, text_blocks, top_k, p, first_frame_blocks=0, want_mask=False,
-                 want_lists=True):
-    """-> (mask uint8 [B,H,nq,nk_all] | None, idx int32 [B,H,nq,nk_all] | None, cnt int32 [B,H,nq] | None)."""
+                 want_lists=True, flags=None):
+    """-> (mask uint8 [B,H,nq,nk_all] | None, idx int32 [B,H,nq,nk_all] | None, cnt int32 [B,H,nq] | None).
+    flags: SELECT_DEVICE_SCAN = the kept-count rule with torch's DEVICE cumsum semantics (default: CPU semantics, or
+    the JENGA_SELECT_FLAGS environment variable)."""
     _need_gpu(qpool, "block_select")
     B, H, nq, _ = qpool.shape
     nk_all = nk_img + text_blocks
@@ -450,7 +471,8 @@ def block_select(qpool, kpool, neighbors, nk_img, text_blocks, top_k, p, first_f
     with torch.cuda.device(dev):
         _check(lib().jenga_block_select(_stream(dev), _p(qpool.contiguous()), _p(kpool.contiguous()), _p(neighbors),
                                         nbr, nbc, _p(mask), _p(idx), _p(cnt), B, H, nq, nk_img, text_blocks,
-                                        int(top_k), float(p), int(first_frame_blocks), dtype_code(qpool.dtype)),
+                                        int(top_k), float(p), int(first_frame_blocks), dtype_code(qpool.dtype),
+                                        int(SELECT_DEFAULT_FLAGS if flags is None else flags)),
                "jenga_block_select")
     return mask, idx, cnt
 
@@ -475,8 +497,9 @@ def pack_v(v, n_blocks=None, out=None, dst_block0=0, dst_blocks_total=None):
 
 
 def bsattn_fwd(q, k, vt, seqlens, idx, cnt, nq_img, sm_scale, text_amp, text_block_start, out=None, xcd_remap=True,
-               flags=None):
-    """q,k [B,S,H,128]; vt from pack_v; seqlens int32 [B] device; idx/cnt from block_select -> o [B,S,H,128]."""
+               flags=None, order=None):
+    """q,k [B,S,H,128]; vt from pack_v; seqlens int32 [B] device; idx/cnt from block_select -> o [B,S,H,128].
+    order: optional launch-order hint (order_by_count); flags & ATTN_SORTED builds it from cnt."""
     _need_gpu(q, "bsattn_fwd")
     B, S, H, D = q.shape
     if D != 128 or S % 128:
@@ -503,23 +526,39 @@ def bsattn_fwd(q, k, vt, seqlens, idx, cnt, nq_img, sm_scale, text_amp, text_blo
     fl = ATTN_DEFAULT_FLAGS if flags is None else flags
     if not xcd_remap:
         fl &= ~ATTN_XCD_REMAP
-    legacy = bool(fl & (ATTN_LEGACY | ATTN_PINGPONG | ATTN_LP)) and not (fl & ATTN_PAIR)
+    pair = bool(fl & ATTN_PAIR)
+    if (pair or (fl & ATTN_PINGPONG)) and not has_experiments():
+        raise JengaError("the pair / ping-pong attention kernels are experiments: build libjenga_amd_exp.so with "
+                         "`python -m jenga_amd.build --experiments` and set JENGA_LIB to it")
+    if pair and (fl & ATTN_LP) and n_blocks == nq_img:
+        # the 8-wave LP pair takes no masked image block in an unshared list (csrc/experiments/bsattn4.hip): without
+        # text blocks the padded last image block can be one
+        raise JengaError("ATTN_LP | ATTN_PAIR needs text blocks behind the image blocks (masked image blocks in an "
+                         "unshared list are not handled by that experiment)")
     prof = ATTN_PROFILE
     with torch.cuda.device(q.device):
-        pidx = pcnt = None
-        if not legacy and nq_img > 0:
+        pidx = pcnt = order_t = None
+        if pair and nq_img > 0:
             pidx, pcnt = pair_merge(idx, cnt, n_blocks)
+        if order is not None:
+            order_t = order
+        elif (fl & ATTN_SORTED) and nq_img > 0 and (fl & ATTN_LP) and not pair:
+            order_t = order_by_count(cnt, (nq_img + 7) // 8 if ((fl & ATTN_XCD_REMAP) and nq_img >= 64) else nq_img)
+        if order_t is not None and (tuple(order_t.shape) != (B, H, nq_img) or order_t.dtype != torch.int32
+                                    or not order_t.is_contiguous() or order_t.device != q.device):
+            raise ValueError("bsattn_fwd: order must be a contiguous int32 [B,H,nq_img] tensor on the device")
         if prof is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
         common = (B, H, n_blocks, nq_img, *_bshd_strides(q), *_bshd_strides(k), *_bshd_strides(out), float(sm_scale),
                   float(text_amp), int(text_block_start), dtype_code(q.dtype))
-        if legacy:
+        cflags = fl & (ATTN_XCD_REMAP | ATTN_PINGPONG | ATTN_LP)
+        if not pair:
             _check(lib().jenga_bsattn_fwd(_stream(q.device), _p(q), _p(k), _p(vt), _p(out), _p(seqlens), _p(idx),
-                                          _p(cnt), *common, fl & ~ATTN_LEGACY), "jenga_bsattn_fwd")
+                                          _p(cnt), _p(order_t), *common, cflags), "jenga_bsattn_fwd")
         else:
             _check(lib().jenga_bsattn_pair_fwd(_stream(q.device), _p(q), _p(k), _p(vt), _p(out), _p(seqlens),
-                                               _p(pidx), _p(pcnt), *common, fl & ~(ATTN_PAIR | ATTN_LEGACY)),
+                                               _p(pidx), _p(pcnt), *common, cflags & ~ATTN_PINGPONG),
                    "jenga_bsattn_pair_fwd")
         if prof is not None:
             e1.record()
@@ -531,10 +570,27 @@ def bsattn_fwd(q, k, vt, seqlens, idx, cnt, nq_img, sm_scale, text_amp, text_blo
     return out
 
 
+def order_by_count(cnt, segment):
+    """cnt int32 [B,H,nq] -> order int32 [B,H,nq]: inside every run of `segment` consecutive query blocks, the blocks by
+    descending kept count (the launch-order hint of jenga_bsattn_fwd)."""
+    _need_gpu(cnt, "order_by_count")
+    if cnt.dim() != 3 or cnt.dtype != torch.int32 or not cnt.is_contiguous():
+        raise ValueError("order_by_count: cnt must be a contiguous int32 [B,H,nq] tensor")
+    B, H, nq = cnt.shape
+    order = torch.empty_like(cnt)
+    with torch.cuda.device(cnt.device):
+        _check(lib().jenga_order_by_count(_stream(cnt.device), _p(cnt), B * H, nq, int(segment), _p(order)),
+               "jenga_order_by_count")
+    return order
+
+
 def pair_merge(idx, cnt, n_blocks):
-    """idx int32 [B,H,nq,n_blocks], cnt int32 [B,H,nq] (jenga_block_select) -> (pidx [B,H,ceil(nq/2),n_blocks],
-    pcnt [B,H,ceil(nq/2),4]): per query-block pair the kv blocks both keep | only the even row | only the odd row."""
+    """(experiments library) idx int32 [B,H,nq,n_blocks], cnt int32 [B,H,nq] (jenga_block_select) -> (pidx
+    [B,H,ceil(nq/2),n_blocks], pcnt [B,H,ceil(nq/2),4]): per query-block pair the kv blocks both keep | only the even
+    row | only the odd row."""
     _need_gpu(idx, "pair_merge")
+    if not has_experiments():
+        raise JengaError("pair_merge is part of the experiments library (python -m jenga_amd.build --experiments)")
     B, H, nq, nb = idx.shape
     if nb != n_blocks or tuple(cnt.shape) != (B, H, nq) or idx.dtype != torch.int32 or cnt.dtype != torch.int32:
         raise ValueError("pair_merge: idx / cnt must be int32 [B,H,nq,n_blocks] / [B,H,nq]")

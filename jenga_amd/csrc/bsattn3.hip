@@ -44,6 +44,7 @@ struct LpParams {
     const int32_t* seqlens;
     const int32_t* idx;
     const int32_t* cnt;
+    const int32_t* order;   // optional launch-order hint: position -> query block, per (b, h) (jenga_order_by_count)
     long long q_sb, q_ss, q_sh, k_sb, k_ss, k_sh, o_sb, o_ss, o_sh;
     int B, H, n_blocks, nq_img;
     int text_block_start;
@@ -58,16 +59,7 @@ template <typename T, bool TEXT>
 __device__ __forceinline__ void attn_block_lp(const LpParams& P, unsigned char* smem, int b, int h, int m) {
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-#ifdef JENGA_LP_LOADERS
-    // EXPERIMENT (timing of the "idle waves stage the tiles" idea): 8 waves; waves 0-3 compute and never issue a DMA,
-    // waves 4-7 issue all of it (8 pieces of K + 8 of V^T per tile each ... i.e. both halves of this wave's share)
-    const int wave_all = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const bool is_loader = wave_all >= 4;
-    const int wave_u = wave_all & 3;
-#else
     const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const bool is_loader = false;
-#endif
     const int lq = lane & 31, hi = lane >> 5;
     const int seqlen = P.seqlens ? __builtin_amdgcn_readfirstlane(P.seqlens[b]) : P.n_blocks * 128;
 
@@ -147,9 +139,6 @@ __device__ __forceinline__ void attn_block_lp(const LpParams& P, unsigned char* 
     };
     // tile t = half (t & 1) of kept block t >> 1
     auto issue_k_at = [&](int t, int slot) {
-#ifdef JENGA_LP_LOADERS
-        if (!is_loader) return;
-#endif
         const int tc = t < 2 * nkept ? t : 2 * nkept - 1;
         const int blk = blk_at(tc >> 1);
         // byte offset = row * (k_ss * 2): one 32 x 32 -> 64 bit scalar multiply (launcher: k_ss * 2 < 2^32)
@@ -158,9 +147,6 @@ __device__ __forceinline__ void attn_block_lp(const LpParams& P, unsigned char* 
                   smem_base + LP_K_RING + slot * LP_TILE + wave_u * 4096, k_src0, k_src1, k_src2, k_src3);
     };
     auto issue_v_at = [&](int t, int slot) {
-#ifdef JENGA_LP_LOADERS
-        if (!is_loader) return;
-#endif
         const int tc = t < 2 * nkept ? t : 2 * nkept - 1;
         const int blk = blk_at(tc >> 1);
         lp_stage4(reinterpret_cast<const unsigned char*>(vbh) +
@@ -227,13 +213,8 @@ __device__ __forceinline__ void attn_block_lp(const LpParams& P, unsigned char* 
     f32x16 sA, sB;
     uint4 pfA[2], pfB[2];
     uint4 frk[8];   // K fragments of the item in flight (lp_bb, PRE)
-#ifdef JENGA_LP_NO_PREFETCH
-#define LP_PRE0 0
-#define LP_PRE1 0
-#else
 #define LP_PRE0 1
 #define LP_PRE1 2
-#endif
 #pragma unroll
     for (int r = 0; r < 16; ++r) sA[r] = sB[r] = 0.f;
     pfA[0] = pfA[1] = pfB[0] = pfB[1] = make_uint4(0u, 0u, 0u, 0u);
@@ -258,20 +239,7 @@ __device__ __forceinline__ void attn_block_lp(const LpParams& P, unsigned char* 
         LP_WAIT_KEEP4();                                                                                              \
         __syncthreads();                                                                                              \
     } while (0)
-#ifdef JENGA_LP_LOADERS
-    if (is_loader) {
-        for (int t = 0; t < t_all; ++t) {
-            issue_v(t);
-            issue_k(t + 2);
-            if (t < t_fast) { LP_WAIT_KEEP4(); __syncthreads(); }
-            else { LP_WAIT_ALL(); __syncthreads(); __syncthreads(); }
-        }
-        LP_WAIT_ALL();
-        return;
-    }
-#endif
     // step t0 + J of the unrolled loop, t0 = 1 (mod 6): every ring slot is a compile-time constant
-#ifndef JENGA_LP_NO_DMA_SPREAD
 #define LP_STEP_C(T0_, J_)                                                                                            \
     do {                                                                                                              \
         {                                                                                                             \
@@ -287,30 +255,15 @@ __device__ __forceinline__ void attn_block_lp(const LpParams& P, unsigned char* 
         LP_WAIT_KEEP4();                                                                                              \
         __syncthreads();                                                                                              \
     } while (0)
-#else
-#define LP_STEP_C(T0_, J_)                                                                                            \
-    do {                                                                                                              \
-        issue_v_at((T0_) + (J_), (1 + (J_)) & 1);                                                                     \
-        lp_bb<T, TEXT, 0, true, true, true, ((1 + (J_)) % 3) * LP_TILE, ((J_) & 1) * LP_TILE, LP_PRE0>(               \
-            st, smem, smem, sA, sB, pfA, pfB, k_addr, v_addr, P.qk_scale, frk);                                       \
-        issue_k_at((T0_) + (J_) + 2, (J_) % 3);                                                                       \
-        lp_bb<T, TEXT, 1, true, true, true, ((1 + (J_)) % 3) * LP_TILE, ((J_) & 1) * LP_TILE, LP_PRE1>(               \
-            st, smem, smem, sB, sA, pfB, pfA, k_addr, v_addr, P.qk_scale, frk);                                       \
-        LP_WAIT_KEEP4();                                                                                              \
-        __syncthreads();                                                                                              \
-    } while (0)
-#endif
     if (t_fast > 0) {
         LP_STEP(0, false, false);
         int t = 1;
-#ifndef JENGA_LP_NO_UNROLL
         if (!TEXT) {
             for (; t + 6 <= t_fast; t += 6) {
                 lp_window(t);
                 LP_STEP_C(t, 0); LP_STEP_C(t, 1); LP_STEP_C(t, 2); LP_STEP_C(t, 3); LP_STEP_C(t, 4); LP_STEP_C(t, 5);
             }
         }
-#endif
         for (; t < t_fast; ++t) LP_STEP(t, true, true);
         // drain: softmax of the last item, P.V of the last tile
         lp_bb<T, TEXT, 0, true, false, true>(st, nullptr, vslot(t_fast - 1), sA, sB, pfA, pfB, k_addr, v_addr,
@@ -352,11 +305,7 @@ __device__ __forceinline__ void attn_block_lp(const LpParams& P, unsigned char* 
     }
 }
 
-#ifdef JENGA_LP_LOADERS
-#define LP_THREADS 512
-#else
 #define LP_THREADS 256
-#endif
 template <typename T>
 __global__ void __launch_bounds__(LP_THREADS, 2) bsattn_lp_kernel(LpParams P) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -379,6 +328,7 @@ __global__ void __launch_bounds__(LP_THREADS, 2) bsattn_lp_kernel(LpParams P) {
     } else {
         m = r;
     }
+    if (P.order) m = P.order[(long long)bh * P.nq_img + m];   // kept-count-aware order inside the XCD's range
     attn_block_lp<T, false>(P, smem, bh / P.H, bh % P.H, m);
 }
 
@@ -389,10 +339,10 @@ using namespace jenga;
 
 // same arguments as jenga_bsattn_fwd (bsattn.hip); reached through it with JENGA_ATTN_LP
 int jenga_bsattn_lp_launch(void* stream, const void* q, const void* k, const void* vt, void* o, const int32_t* seqlens,
-                           const int32_t* idx, const int32_t* cnt, int64_t B, int64_t H, int64_t n_blocks,
-                           int64_t nq_img, int64_t q_sb, int64_t q_ss, int64_t q_sh, int64_t k_sb, int64_t k_ss,
-                           int64_t k_sh, int64_t o_sb, int64_t o_ss, int64_t o_sh, float sm_scale, float text_amp,
-                           int64_t text_block_start, int dtype, int flags) {
+                           const int32_t* idx, const int32_t* cnt, const int32_t* order, int64_t B, int64_t H,
+                           int64_t n_blocks, int64_t nq_img, int64_t q_sb, int64_t q_ss, int64_t q_sh, int64_t k_sb,
+                           int64_t k_ss, int64_t k_sh, int64_t o_sb, int64_t o_ss, int64_t o_sh, float sm_scale,
+                           float text_amp, int64_t text_block_start, int dtype, int flags) {
     LpParams P;
     P.q = (const uint16_t*)q;
     P.k = (const uint16_t*)k;
@@ -401,6 +351,7 @@ int jenga_bsattn_lp_launch(void* stream, const void* q, const void* k, const voi
     P.seqlens = seqlens;
     P.idx = idx;
     P.cnt = cnt;
+    P.order = order;
     P.q_sb = q_sb; P.q_ss = q_ss; P.q_sh = q_sh;
     P.k_sb = k_sb; P.k_ss = k_ss; P.k_sh = k_sh;
     P.o_sb = o_sb; P.o_ss = o_ss; P.o_sh = o_sh;

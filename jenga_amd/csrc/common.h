@@ -85,17 +85,15 @@ void set_error(const char* fmt, ...);
 
 // bsattn3.hip: the launcher behind jenga_bsattn_fwd(..., flags & JENGA_ATTN_LP); arguments already validated
 int jenga_bsattn_lp_launch(void* stream, const void* q, const void* k, const void* vt, void* o, const int32_t* seqlens,
-                           const int32_t* idx, const int32_t* cnt, int64_t B, int64_t H, int64_t n_blocks,
-                           int64_t nq_img, int64_t q_sb, int64_t q_ss, int64_t q_sh, int64_t k_sb, int64_t k_ss,
-                           int64_t k_sh, int64_t o_sb, int64_t o_ss, int64_t o_sh, float sm_scale, float text_amp,
-                           int64_t text_block_start, int dtype, int flags);
-// bsattn4.hip: the launcher behind jenga_bsattn_pair_fwd(..., flags & JENGA_ATTN_LP); arguments already validated
+                           const int32_t* idx, const int32_t* cnt, const int32_t* order, int64_t B, int64_t H,
+                           int64_t n_blocks, int64_t nq_img, int64_t q_sb, int64_t q_ss, int64_t q_sh, int64_t k_sb,
+                           int64_t k_ss, int64_t k_sh, int64_t o_sb, int64_t o_ss, int64_t o_sh, float sm_scale,
+                           float text_amp, int64_t text_block_start, int dtype, int flags);
+#ifdef JENGA_EXPERIMENTS
+// experiments/bsattn4.hip: the launcher behind jenga_bsattn_pair_fwd(..., flags & JENGA_ATTN_LP)
 int jenga_bsattn_lp2_launch(void* stream, const void* q, const void* k, const void* vt, void* o, const int32_t* seqlens,
                            const int32_t* pidx, const int32_t* pcnt, int64_t B, int64_t H, int64_t n_blocks,
                            int64_t nq_img, int64_t q_sb, int64_t q_ss, int64_t q_sh, int64_t k_sb, int64_t k_ss,
                            int64_t k_sh, int64_t o_sb, int64_t o_ss, int64_t o_sh, float sm_scale, float text_amp,
                            int64_t text_block_start, int dtype, int flags);
-
-namespace jenga {
-
-}  // namespace jenga
+#endif

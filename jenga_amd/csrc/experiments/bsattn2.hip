@@ -26,7 +26,7 @@
 //
 // MFMA formulation, LDS tile images, V pre-tiling, numerics: identical to bsattn.hip (see its header); reference
 // semantics attention_block_triton_diffres.py:38-136 (image rows) and :371-380 (text rows, TEXT=true).
-#include "common.h"
+#include "../common.h"
 
 #ifndef JENGA_PIN_Q
 #define JENGA_PIN_Q 3   // bit 0 / 1: keep the Q fragments of sub-block A / B in the accumulator registers
@@ -115,7 +115,7 @@ __device__ __forceinline__ void stage4(const void* base, unsigned lds, unsigned 
                  "global_load_lds_dwordx4 %6, %2 offset:3072" DMA_M0_RESTORE
                  : "=&s"(keep)
                  : "s"(lds), "s"(base), "v"(o0), "v"(o1), "v"(o2), "v"(o3)
-                 : "memory");
+                 : "memory", "m0");
 }
 // piece I (0..3) of a tile, placed into an MFMA gap by item_bb
 template <int I>
@@ -130,7 +130,7 @@ __device__ __forceinline__ void stage1(const void* base, unsigned lds, unsigned 
                  "global_load_lds_dwordx4 %3, %2 offset:%4" DMA_M0_RESTORE
                  : "=&s"(keep)
                  : "s"(lds), "s"(base), "v"(off), "i"(I * 1024)
-                 : "memory");
+                 : "memory", "m0");
 }
 #define DMA_WAIT_ALL() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
 #define DMA_WAIT_KEEP8() asm volatile("s_waitcnt vmcnt(8)" ::: "memory")

@@ -14,7 +14,7 @@
 // RESTRICTION of this experiment: no block of an UNSHARED list may need the slow path, i.e. seqlen >= the end of the
 // last unshared image block (true for the HunyuanVideo flavour, whose image blocks are never masked); the Python host
 // does not route here by default.
-#include "lp_core.h"
+#include "../lp_core.h"
 
 namespace jenga {
 namespace {
@@ -51,7 +51,7 @@ __device__ __forceinline__ void lp_stage2(const void* base, unsigned lds, unsign
                  "global_load_lds_dwordx4 %3, %1 offset:1024"
                  :
                  : "s"(lds), "s"(base), "v"(o0), "v"(o1)
-                 : "memory");
+                 : "memory", "m0");
 }
 
 template <typename T, bool TEXT>

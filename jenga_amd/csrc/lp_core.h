@@ -21,9 +21,6 @@ template <> __device__ __forceinline__ constexpr float lp_tiny<FP16>() { return 
 // four 1-KiB LDS-DMA pieces of one tile (see bsattn2.hip: immediate offsets, piece i's lane offsets biased by -1024 i)
 __device__ __forceinline__ void lp_stage4(const void* base, unsigned lds, unsigned o0, unsigned o1, unsigned o2,
                                           unsigned o3) {
-#ifdef JENGA_X_NODMA
-    return;
-#endif
     asm volatile("s_mov_b32 m0, %0\n\t"
                  "s_nop 0\n\t"
                  "global_load_lds_dwordx4 %2, %1\n\t"
@@ -32,11 +29,10 @@ __device__ __forceinline__ void lp_stage4(const void* base, unsigned lds, unsign
                  "global_load_lds_dwordx4 %5, %1 offset:3072"
                  :
                  : "s"(lds), "s"(base), "v"(o0), "v"(o1), "v"(o2), "v"(o3)
-                 : "memory");
+                 : "memory", "m0");   // M0 = LDS base of the DMA: the compiler must not assume it survives
 }
 // one piece: in the unrolled main loop the four pieces of a stage go out in four MFMA slots of the block (1, 5, 9,
 // 13) instead of back to back in front of it -- less queueing in the vector-memory path, +2 % sustained
-// (JENGA_LP_NO_DMA_SPREAD restores the up-front form)
 struct LpDma {
     const void* base;
     unsigned lds;
@@ -44,24 +40,17 @@ struct LpDma {
 };
 template <int I>
 __device__ __forceinline__ void lp_stage1(const LpDma& d) {
-#ifdef JENGA_X_NODMA
-    return;
-#endif
     if (I == 0)
-        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %1" : : "s"(d.lds), "s"(d.base), "v"(d.o[0]) : "memory");
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %1" : : "s"(d.lds), "s"(d.base), "v"(d.o[0]) : "memory", "m0");
     else if (I == 1)
-        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %1 offset:1024" : : "s"(d.lds), "s"(d.base), "v"(d.o[1]) : "memory");
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %1 offset:1024" : : "s"(d.lds), "s"(d.base), "v"(d.o[1]) : "memory", "m0");
     else if (I == 2)
-        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %1 offset:2048" : : "s"(d.lds), "s"(d.base), "v"(d.o[2]) : "memory");
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %1 offset:2048" : : "s"(d.lds), "s"(d.base), "v"(d.o[2]) : "memory", "m0");
     else
-        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %1 offset:3072" : : "s"(d.lds), "s"(d.base), "v"(d.o[3]) : "memory");
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %1 offset:3072" : : "s"(d.lds), "s"(d.base), "v"(d.o[3]) : "memory", "m0");
 }
 #define LP_WAIT_ALL() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
-#ifdef JENGA_X_NOWAIT
-#define LP_WAIT_KEEP4()
-#else
 #define LP_WAIT_KEEP4() asm volatile("s_waitcnt vmcnt(4)" ::: "memory")
-#endif
 
 struct LpState {
     uint4 qf[8];
@@ -139,19 +128,9 @@ __device__ __forceinline__ void lp_bb(LpState& st, const unsigned char* kt, cons
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
     float half_ = 0.f;
     uint32_t ww[8];
-#ifdef JENGA_X_NOREADS      /* EXPERIMENT (wrong results): no fragment reads at all */
-#define LP_RD_ON(F_) false
-#elif defined(JENGA_X_HALFREADS)   /* EXPERIMENT (wrong results): every second fragment read skipped */
-#define LP_RD_ON(F_) (((F_) & 1) == 0)
-#else
-#define LP_RD_ON(F_) true
-#endif
 #define LP_READ(F_)                                                                                                   \
     do {                                                                                                              \
-        if (!LP_RD_ON(F_)) {                                                                                          \
-            if ((F_) < 8) frk[(F_) & 7] = frk[((F_) & 7) ^ 1];                                                        \
-            else if ((F_) < 16) frv[(F_) & 7] = frv[((F_) & 7) ^ 1];                                                  \
-        } else if ((F_) < 8) {                                                                                        \
+        if ((F_) < 8) {                                                                                               \
             if (DO_QK) frk[(F_) & 7] = *reinterpret_cast<const uint4*>(kt + k_addr[(F_) & 7] + (HALF * 8192 + KO));   \
         } else if ((F_) < 16) {                                                                                       \
             if (DO_PV) frv[(F_) & 7] = *reinterpret_cast<const uint4*>(vt + v_addr[2 * HALF + (((F_) - 8) >> 2)] +    \
@@ -160,11 +139,6 @@ __device__ __forceinline__ void lp_bb(LpState& st, const unsigned char* kt, cons
             frk[(F_) & 7] = *reinterpret_cast<const uint4*>(kt + k_addr[(F_) & 7] + (8192 + KO));                     \
         }                                                                                                             \
     } while (0)
-#ifdef JENGA_X_NOSM
-#define LP_SM_ON false
-#else
-#define LP_SM_ON true
-#endif
     /* image rows: the scores are S - m~ already (C operand); TEXT rows: raw scores, scaled and shifted here.
        Image rows: all 16 scores exist when the block starts, so element e is exponentiated in slot X(e) = e / 2 for
        e < 4, e - 2 after that, added / packed one slot later, and the 4-way sum tree closes in slot 15: what is left
@@ -173,7 +147,7 @@ __device__ __forceinline__ void lp_bb(LpState& st, const unsigned char* kt, cons
 #define LP_SM_X(E_) ((E_) < 4 ? ((E_) >> 1) : (E_) - 2)
 #define LP_SM(M_)                                                                                                     \
     do {                                                                                                              \
-        if (DO_SM && LP_SM_ON) {                                                                                      \
+        if (DO_SM) {                                                                                      \
             if (TEXT) {                                                                                               \
                 if ((M_) < 16) tt[(M_) & 15] = sp[(M_) & 15] * qk_scale + st.neg_m;                                   \
                 if ((M_) >= 1 && (M_) < 17) xx[((M_) - 1) & 15] = __builtin_amdgcn_exp2f(tt[((M_) - 1) & 15]);        \
@@ -202,11 +176,7 @@ __device__ __forceinline__ void lp_bb(LpState& st, const unsigned char* kt, cons
             }                                                                                                         \
         }                                                                                                             \
     } while (0)
-#ifdef JENGA_X_NOMFMA       /* EXPERIMENT (wrong results): MFMAs replaced by one cheap VALU op each */
-#define LP_MFMA(D_, A_, B_, C_) do { D_ = C_; D_[0] += __uint_as_float((A_).x ^ (B_).x); } while (0)
-#else
 #define LP_MFMA(D_, A_, B_, C_) D_ = mfma32<T>(A_, B_, C_)
-#endif
     /* fragment reads go out two at a time, eight MFMAs ahead (slot m, m even, reads the fragments of MFMAs m+8 and
        m+9), with ONE explicit counted s_waitcnt lgkmcnt per two MFMAs (the compiler would emit one per MFMA).
        Before MFMA m (even) fragments m, m+1 must be there; the reads issued behind them are m+2 .. min(m+7, 15). */
@@ -269,15 +239,10 @@ __device__ __forceinline__ void lp_bb(LpState& st, const unsigned char* kt, cons
         float psum = __uint_as_float(sw_[0]) + __uint_as_float(sw_[1]);   // both half-lanes: the row's 32 keys
         pf_new[0] = make_uint4(ww[0], ww[1], ww[2], ww[3]);
         pf_new[1] = make_uint4(ww[4], ww[5], ww[6], ww[7]);
-#ifdef JENGA_X_NOSM
-        psum = 1.f + sp[0] * 1e-30f;
-        pf_new[0] = pf_new[1] = make_uint4(0x3c003c00u, 0x3c003c00u, 0x3c003c00u, 0x3c003c00u);
-#else
         // two ballots straight off the compares (a ballot of an OR-ed condition goes through v_cndmask + v_cmp_ne)
         if ((__builtin_amdgcn_ballot_w64(!(psum <= LP_RAISE_SUM)) |
              __builtin_amdgcn_ballot_w64(st.l + psum < lp_tiny<T>())) != 0ull)
             lp_exact<T, TEXT>(st, sp, pf_new, psum, qk_scale, DO_QK ? &sn : nullptr);
-#endif
         st.l += psum;
     }
 }

@@ -91,7 +91,7 @@ __global__ void __launch_bounds__(256)
 block_select_kernel(const uint16_t* __restrict__ qpool, const uint16_t* __restrict__ kpool,
                     const uint8_t* __restrict__ neighbors, int nb_rows, int nb_cols, uint8_t* __restrict__ mask,
                     int32_t* __restrict__ idx, int32_t* __restrict__ cnt, int /*H*/, int nq, int nk_img, int text_blocks,
-                    int top_k, float p_thr, int first_frame_blocks, int npow2) {
+                    int top_k, float p_thr, int first_frame_blocks, int npow2, int scan_log_nx) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t* keys = reinterpret_cast<uint32_t*>(smem);                 // [npow2]
     float* qrow = reinterpret_cast<float*>(keys + npow2);               // [128]
@@ -99,6 +99,7 @@ block_select_kernel(const uint16_t* __restrict__ qpool, const uint16_t* __restri
     uint32_t* wpre = bits + 80;                                         // [80] exclusive popcount prefix
     float* scratch = reinterpret_cast<float*>(wpre + 80);               // [8]
     int* n_sh = reinterpret_cast<int*>(scratch + 8);                    // [1]
+    float* sbuf = reinterpret_cast<float*>(n_sh + 4);                   // [2 << scan_log_nx] (device-scan mode, W > 64)
 
     const int nk_all = nk_img + text_blocks;
     const long long row = blockIdx.x;  // (b*H + h)*nq + m
@@ -176,18 +177,82 @@ block_select_kernel(const uint16_t* __restrict__ qpool, const uint16_t* __restri
             __syncthreads();
         }
     }
-    // ---- n = max(#(cumsum <= p) + 1, top_k): sequential fp32 accumulation, each partial rounded to dtype ----
-    if (tid == 0) {
-        float acc = 0.f;
-        int count = 0;
-        for (int i = 0; i < nk_img; ++i) {
-            acc = acc + to_f32<T>((uint16_t)(keys[i] >> 16));
-            if (round_to<T>(acc) <= p_thr)
-                ++count;
-            else
-                break;  // partial sums are non-decreasing
+    // ---- n = max(#(cumsum <= p) + 1, top_k) ----
+    if (scan_log_nx < 0) {
+        // default contract = torch.cumsum of a 16-bit tensor on the CPU (what the reference's goldens were generated
+        // with): sequential fp32 accumulation, each partial rounded to dtype
+        if (tid == 0) {
+            float acc = 0.f;
+            int count = 0;
+            for (int i = 0; i < nk_img; ++i) {
+                acc = acc + to_f32<T>((uint16_t)(keys[i] >> 16));
+                if (round_to<T>(acc) <= p_thr)
+                    ++count;
+                else
+                    break;  // partial sums are non-decreasing
+            }
+            *n_sh = count;
         }
-        int n = count + 1;
+    } else {
+        // JENGA_SELECT_DEVICE_SCAN: torch.cumsum of a 16-bit tensor on the DEVICE, restated (ATen/native/cuda/
+        // ScanUtils.cuh, tensor_kernel_scan_innermost_dim_impl, torch 2.10): the row is scanned in chunks of
+        // W = 2 * nx columns (nx = 2^scan_log_nx threads, chosen by get_log_num_threads_x_inner_scan from the number
+        // of rows and the row length); inside a chunk a Sklansky network, EVERY add rounded to the 16-bit dtype
+        // (row_buf is scalar_t); the chunk's last element (also 16-bit) is added to the next chunk's first one.
+        // Partials are not monotonic, so ALL columns with cumsum <= p are counted ((cumsum <= p).sum(), :244-245).
+        const int nx = 1 << scan_log_nx, W = 2 * nx;
+        if (tid == 0) *n_sh = 0;
+        __syncthreads();
+        if (W <= 64) {
+            if (tid < 64) {     // one wave, the chunk in registers, Sklansky steps as wave shuffles
+                float total = 0.f;
+                int count = 0;
+                for (int c0 = 0; c0 < nk_img; c0 += W) {
+                    const int col = c0 + tid;
+                    float v = (tid < W && col < nk_img) ? to_f32<T>((uint16_t)(keys[col] >> 16)) : 0.f;
+                    if (tid == 0) v = round_to<T>(v + total);
+                    for (int m = 0; m <= scan_log_nx; ++m) {
+                        const int sft = 1 << m;
+                        const int src = (tid & ~(2 * sft - 1)) + sft - 1;
+                        const float o = __shfl(v, src & 63);
+                        if (tid & sft) v = round_to<T>(v + o);
+                    }
+                    if (tid < W && col < nk_img && v <= p_thr) ++count;
+                    total = __shfl(v, W - 1);
+                }
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) count += __shfl_xor(count, o);
+                if (tid == 0) *n_sh = count;
+            }
+        } else {
+            float total = 0.f;
+            int count = 0;
+            for (int c0 = 0; c0 < nk_img; c0 += W) {
+                for (int e = tid; e < W; e += 256)
+                    sbuf[e] = (c0 + e < nk_img) ? to_f32<T>((uint16_t)(keys[c0 + e] >> 16)) : 0.f;
+                __syncthreads();
+                if (tid == 0) sbuf[0] = round_to<T>(sbuf[0] + total);
+                __syncthreads();
+                for (int m = 0; m <= scan_log_nx; ++m) {
+                    const int sft = 1 << m;
+                    for (int t = tid; t < nx; t += 256) {
+                        const int a = ((t >> m) << (m + 1)) | sft;
+                        const int ti = a + (t & (sft - 1)), si = a - 1;
+                        sbuf[ti] = round_to<T>(sbuf[ti] + sbuf[si]);
+                    }
+                    __syncthreads();
+                }
+                for (int e = tid; e < W; e += 256)
+                    if (c0 + e < nk_img && sbuf[e] <= p_thr) ++count;
+                total = sbuf[W - 1];
+                __syncthreads();
+            }
+            if (count) atomicAdd(n_sh, count);
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int n = *n_sh + 1;
         if (n < top_k) n = top_k;
         if (n > nk_img) n = nk_img;
         *n_sh = n;
@@ -227,6 +292,32 @@ block_select_kernel(const uint16_t* __restrict__ qpool, const uint16_t* __restri
     }
 }
 
+
+// ---- kept-count-aware launch order (SURVEY.md §7 "load imbalance -> work queue sorted by kept count") ------------
+// order[bh][s * seg + j] = the query block of segment s (blocks [s * seg, (s+1) * seg)) with the j-th LARGEST kept
+// count (ties: lower block first).  The attention kernel maps launch position -> query block through it, so that
+// inside every XCD's contiguous range the long lists start first and the short ones fill the tail.
+// Rank by counting: n <= 2048 per segment, one workgroup per (bh, segment).
+__global__ void __launch_bounds__(256) order_by_count_kernel(const int32_t* __restrict__ cnt, int32_t* __restrict__ order,
+                                                             int nq, int seg) {
+    __shared__ int c_sh[2048];
+    const int nseg = (nq + seg - 1) / seg;
+    const long long bh = blockIdx.x / nseg;
+    const int s0 = (int)(blockIdx.x % nseg) * seg;
+    const int n = (s0 + seg <= nq) ? seg : nq - s0;
+    for (int i = threadIdx.x; i < n; i += 256) c_sh[i] = cnt[bh * nq + s0 + i];
+    __syncthreads();
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const int ci = c_sh[i];
+        int rank = 0;
+        for (int j = 0; j < n; ++j) {
+            const int cj = c_sh[j];
+            rank += (cj > ci) || (cj == ci && j < i);
+        }
+        order[bh * nq + s0 + rank] = s0 + i;
+    }
+}
+
 }  // namespace
 }  // namespace jenga
 
@@ -235,7 +326,7 @@ using namespace jenga;
 extern "C" int jenga_block_select(void* stream, const void* qpool, const void* kpool, const uint8_t* neighbors,
                                   int64_t nb_rows, int64_t nb_cols, uint8_t* mask, int32_t* idx, int32_t* cnt,
                                   int64_t B, int64_t H, int64_t nq, int64_t nk_img, int64_t text_blocks, int64_t top_k,
-                                  float p, int64_t first_frame_blocks, int dtype) {
+                                  float p, int64_t first_frame_blocks, int dtype, int flags) {
     if (!qpool || !kpool || B < 0 || H < 0 || nq < 0 || nk_img <= 0 || text_blocks < 0 || top_k < 0) {
         set_error("jenga_block_select: bad arguments");
         return JENGA_EINVAL;
@@ -253,7 +344,20 @@ extern "C" int jenga_block_select(void* stream, const void* qpool, const void* k
     if (rows == 0) return JENGA_OK;
     int npow2 = 2;
     while (npow2 < nk_img) npow2 <<= 1;
-    const size_t smem = (size_t)npow2 * 4 + 128 * 4 + 80 * 4 * 2 + 8 * 4 + 16;
+    // device-scan mode: the chunk width torch's launcher would pick for a [rows, nk_img] tensor
+    // (get_log_num_threads_x_inner_scan, ATen/native/cuda/ScanUtils.cuh:20-41)
+    int scan_log_nx = -1;
+    if (flags & JENGA_SELECT_DEVICE_SCAN) {
+        uint32_t lx = 0, ly = 0;      // (torch instantiates the helper with uint32_t: the wrap-around is part of it)
+        while ((1ULL << lx) < (unsigned long long)nk_img) ++lx;
+        while ((1ULL << ly) < (unsigned long long)rows) ++ly;
+        uint32_t l = ((uint32_t)9 + (lx - ly)) / (uint32_t)2;
+        if (l < 4u) l = 4u;
+        if (l > 9u) l = 9u;
+        scan_log_nx = (int)l;
+    }
+    const size_t smem = (size_t)npow2 * 4 + 128 * 4 + 80 * 4 * 2 + 8 * 4 + 16 +
+                       (scan_log_nx > 5 ? ((size_t)2 << scan_log_nx) * 4 : 0);
     // the reference compares the dtype cumsum with a Python float: the scalar is rounded to the tensor dtype
     float p_thr;
     if (dtype == JENGA_BF16) {
@@ -268,12 +372,35 @@ extern "C" int jenga_block_select(void* stream, const void* qpool, const void* k
     hipLaunchKernelGGL(block_select_kernel<T>, dim3((unsigned)rows), dim3(256), smem, (hipStream_t)stream,            \
                        (const uint16_t*)qpool, (const uint16_t*)kpool, neighbors, (int)nb_rows, (int)nb_cols, mask,   \
                        idx, cnt, (int)H, (int)nq, (int)nk_img, (int)text_blocks, (int)top_k, p_thr,                   \
-                       (int)first_frame_blocks, npow2)
+                       (int)first_frame_blocks, npow2, scan_log_nx)
     if (dtype == JENGA_BF16) LAUNCH_SEL(BF16); else LAUNCH_SEL(FP16);
 #undef LAUNCH_SEL
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         set_error("jenga_block_select: %s", hipGetErrorString(e));
+        return JENGA_ELAUNCH;
+    }
+    return JENGA_OK;
+}
+
+extern "C" int jenga_order_by_count(void* stream, const int32_t* cnt, int64_t BH, int64_t nq, int64_t segment,
+                                    int32_t* order) {
+    if (!cnt || !order || BH < 0 || nq < 0 || segment <= 0) {
+        set_error("jenga_order_by_count: bad arguments");
+        return JENGA_EINVAL;
+    }
+    if (segment > nq) segment = nq;
+    if (segment > 2048) {
+        set_error("jenga_order_by_count: at most 2048 query blocks per segment (got %lld)", (long long)segment);
+        return JENGA_EUNSUPPORTED;
+    }
+    if (BH * nq == 0) return JENGA_OK;
+    const long long nseg = (nq + segment - 1) / segment;
+    hipLaunchKernelGGL(order_by_count_kernel, dim3((unsigned)(BH * nseg)), dim3(256), 0, (hipStream_t)stream, cnt, order,
+                       (int)nq, (int)segment);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        set_error("jenga_order_by_count: %s", hipGetErrorString(e));
         return JENGA_ELAUNCH;
     }
     return JENGA_OK;

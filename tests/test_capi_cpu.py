@@ -15,17 +15,42 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def test_library_builds_and_loads():
     build.build()
     L = _capi.lib()
-    assert L.jenga_abi_version() == 1
+    assert L.jenga_abi_version() == 2
+
+
+def _declared():
+    """(product symbols, experiment symbols) declared by include/jenga_amd.h."""
+    header = open(os.path.join(ROOT, "include", "jenga_amd.h")).read()
+    m = re.search(r"#ifdef JENGA_EXPERIMENTS(.*?)#endif /\* JENGA_EXPERIMENTS \*/", header, re.S)
+    assert m, "experiments section not found"
+    exp = set(re.findall(r"\b(jenga_[a-z0-9_]+)\s*\(", m.group(1)))
+    prod = set(re.findall(r"\b(jenga_[a-z0-9_]+)\s*\(", header[:m.start()] + header[m.end():]))
+    return prod, exp - prod
+
+
+def _exported(path):
+    out = subprocess.check_output(["nm", "-D", "--defined-only", path]).decode()
+    return {ln.split()[-1] for ln in out.splitlines() if " T " in ln}
 
 
 def test_header_symbols_exported():
-    header = open(os.path.join(ROOT, "include", "jenga_amd.h")).read()
-    declared = set(re.findall(r"\b(jenga_[a-z0-9_]+)\s*\(", header))
-    out = subprocess.check_output(["nm", "-D", "--defined-only", _capi.LIB_PATH]).decode()
-    exported = {ln.split()[-1] for ln in out.splitlines() if " T " in ln}
+    declared, experiments = _declared()
+    exported = _exported(_capi.LIB_PATH)
     assert declared, "no declarations parsed"
     assert declared <= exported, f"missing: {declared - exported}"
     assert declared == set(_capi.SIGNATURES), "ctypes binding out of sync with the header"
+    assert experiments == set(_capi.EXPERIMENT_SIGNATURES)
+    if os.path.basename(_capi.LIB_PATH) == "libjenga_amd.so":
+        # the product library carries no experiment: measured-and-rejected kernels live in libjenga_amd_exp.so only
+        assert not (experiments & exported), experiments & exported
+        assert len(build.SOURCES) <= 6 and not any("experiments" in s for s, _ in build.SOURCES)
+
+
+def test_experiments_library_is_a_superset_when_built():
+    if not os.path.exists(build.LIB_EXP):
+        pytest.skip("libjenga_amd_exp.so not built (python -m jenga_amd.build --experiments)")
+    declared, experiments = _declared()
+    assert (declared | experiments) <= _exported(build.LIB_EXP)
 
 
 def test_no_cpu_fallback():

@@ -1,0 +1,61 @@
+"""GPU (-m gpu): the kept-count-aware launch order ("load imbalance -> work queue sorted by kept count";
+the reference launches its grid in plain order, attention_block_triton_diffres.py:165).  jenga_order_by_count builds a
+permutation per (batch, head): inside every segment of consecutive query blocks, descending kept count; jenga_bsattn_fwd
+(LP kernel) maps launch position -> query block through it.  A scheduling hint only: outputs are bit-identical."""
+import pytest
+import torch
+
+from test_gpu_pair import _rand_case, lists_from_mask
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    return torch.device("cuda:0")
+
+
+@pytest.mark.parametrize("nq,seg", [(900, 113), (200, 25), (200, 200), (7, 3), (2048, 2048), (64, 8)])
+def test_order_by_count_is_a_segmentwise_descending_permutation(dev, nq, seg):
+    from jenga_amd import _capi
+    g = torch.Generator(device=dev).manual_seed(nq + seg)
+    cnt = torch.randint(1, 40, (2, 3, nq), generator=g, device=dev, dtype=torch.int32)
+    order = _capi.order_by_count(cnt, seg)
+    torch.cuda.synchronize()
+    c, o = cnt.cpu(), order.cpu()
+    for b in range(2):
+        for h in range(3):
+            for s0 in range(0, nq, seg):
+                n = min(seg, nq - s0)
+                blocks = o[b, h, s0:s0 + n]
+                assert sorted(blocks.tolist()) == list(range(s0, s0 + n)), "not a permutation of the segment"
+                key = [(-int(c[b, h, m]), int(m)) for m in blocks.tolist()]
+                assert key == sorted(key), "not (descending count, ascending block)"
+
+
+@pytest.mark.parametrize("flags", [9, 8])
+def test_sorted_launch_order_is_bit_identical(dev, flags):
+    from jenga_amd import _capi
+    H, nq_img, tb = 3, 72, 2            # >= 64 query blocks: the XCD remap is on for flags 9 (segment = 9)
+    q, k, v, mask = _rand_case(77, H, nq_img, tb, "bfloat16", 0.3, 0.0)
+    g = torch.Generator().manual_seed(5)
+    thin = torch.rand(1, H, nq_img, nq_img + tb, generator=g) < 0.3
+    mask[:, :, ::2, :nq_img] &= thin[:, :, ::2, :nq_img]      # ragged kept counts
+    for m in range(nq_img):
+        mask[:, :, m, m] = True
+    nb = nq_img + tb
+    idx, cnt = lists_from_mask(mask, dev)
+    vt = _capi.pack_v(v.to(dev), nb)
+    seqlens = torch.tensor([nq_img * 128 + 70], dtype=torch.int32, device=dev)
+    run = lambda fl, order=None: _capi.bsattn_fwd(q.to(dev), k.to(dev), vt, seqlens, idx, cnt, nq_img, 128 ** -0.5, 0.3,
+                                                  nq_img, flags=fl, order=order)
+    plain = run(flags)
+    srt = run(flags | _capi.ATTN_SORTED)
+    # an arbitrary permutation handed in by the caller works the same way
+    perm = torch.stack([torch.randperm(nq_img, generator=g) for _ in range(H)]).view(1, H, nq_img).to(torch.int32).to(dev)
+    arb = run(flags, order=perm)
+    torch.cuda.synchronize()
+    assert torch.equal(plain, srt) and torch.equal(plain, arb)
+    with pytest.raises(ValueError):
+        run(flags, order=perm[:, :, :-1].contiguous())

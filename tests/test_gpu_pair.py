@@ -23,6 +23,9 @@ def lists_from_mask(mask_bool, device):
 
 @pytest.mark.parametrize("nq,nb,density", [(8, 10, 0.4), (9, 9, 0.3), (1, 5, 0.5), (21, 300, 0.3), (6, 2050, 0.25)])
 def test_pair_merge_vs_sets(dev, nq, nb, density):
+    from jenga_amd import _capi as _c
+    if not _c.has_experiments():
+        pytest.skip("jenga_pair_merge is part of the experiments library")
     from jenga_amd import _capi
     gen = torch.Generator().manual_seed(nq * 1000 + nb)
     B, H = 1, 3
@@ -92,8 +95,14 @@ CASES = [
 ]
 
 
-NEW_KERNELS = {"pair": 1, "lp": 9, "lp_pair": 1 | 8 | 64}   # flags: XCD remap | (0 = pair kernel, 8 = JENGA_ATTN_LP,
-#                                                              8 | 64 = the 8-wave LP pair experiment, bsattn4.hip)
+NEW_KERNELS = {"pair": 1 | 64, "lp": 9, "lp_pair": 1 | 8 | 64}   # flags: XCD remap | (8 = JENGA_ATTN_LP, the default
+#     kernel; 64 = the pair kernel, 8 | 64 = the 8-wave LP pair: experiments, libjenga_amd_exp.so only)
+
+
+def _need(kern):
+    from jenga_amd import _capi
+    if NEW_KERNELS[kern] & 64 and not _capi.has_experiments():
+        pytest.skip("experiment kernel: needs JENGA_LIB=libjenga_amd_exp.so (python -m jenga_amd.build --experiments)")
 
 
 @pytest.mark.parametrize("kern", list(NEW_KERNELS))
@@ -101,6 +110,7 @@ NEW_KERNELS = {"pair": 1, "lp": 9, "lp_pair": 1 | 8 | 64}   # flags: XCD remap |
 def test_pair_kernel_vs_oracle_and_legacy(dev, case, kern):
     """Every row of the output (image AND text rows) against the oracle, and the two kernels against each other: same
     arithmetic, different kv order per row, so they agree to fp32-summation noise, i.e. the odd last-place flip."""
+    _need(kern)
     from jenga_amd import _capi
     from oracle import attention as oa
     seed, H, nq_img, tb, dt, density, overlap, valid_text, amp = case
@@ -131,6 +141,7 @@ def test_pair_kernel_running_max_moves_both_ways(dev, dt, kern):
     """The lazy running max starts at 0 and has no first-tile special case: rows whose scores all sit far BELOW zero
     must pull m~ down (running sum < 2^-60 -> exact path), rows with a late spike must push it up, including spikes
     that sit in A-only, B-only and shared blocks and in either 64-key half."""
+    _need(kern)
     from oracle import attention as oa
     gen = torch.Generator().manual_seed(77)
     H, nq_img, tb = 2, 8, 2
@@ -186,6 +197,7 @@ def test_pair_kernel_running_max_moves_both_ways(dev, dt, kern):
 def test_pair_kernel_full_size_heads_subset(dev, kern):
     """HunyuanVideo 720p shape (900 + 2 blocks), 2 heads, random lists with the benchmark's density: finite output,
     softmax rows are convex combinations of V (|o| <= max |v|), and sampled rows against the oracle."""
+    _need(kern)
     from jenga_amd import _capi
     from oracle import attention as oa
     gen = torch.Generator().manual_seed(5)

@@ -202,13 +202,18 @@ def test_sparse_kernel_vs_triton_interpreter_golden(golden_dir, dev, index):
     assert (err > 2e-3).mean() < 2e-3
 
 
-@pytest.mark.parametrize("dt,flags", [("bfloat16", None), ("float16", None), ("bfloat16", 0), ("bfloat16", 5), ("float16", 4),
-                                      ("bfloat16", 3), ("float16", 2), ("bfloat16", 9), ("float16", 8), ("bfloat16", 1)])
+@pytest.mark.parametrize("dt,flags", [("bfloat16", None), ("float16", None), ("bfloat16", 9), ("float16", 8), ("bfloat16", 25),
+                                      ("bfloat16", 0), ("bfloat16", 1), ("float16", 1),
+                                      ("bfloat16", 3), ("float16", 2), ("bfloat16", 65), ("float16", 64)])
 def test_sparse_kernel_vs_oracle(dev, dt, flags):
-    """flags None = the default pair kernel (two query blocks per workgroup, XCD remap on), 0 = plain workgroup order;
-    4 / 5 = the round-1 kernel (JENGA_ATTN_LEGACY: one query block per 4-wave workgroup); 2 / 3 = the experimental 8-wave
-    ping-pong kernel (JENGA_ATTN_PINGPONG) -- both kept in-tree as measured alternatives and held to the same tolerance."""
+    """flags None = the default: the LP kernel (JENGA_ATTN_LP, csrc/bsattn3.hip) with the XCD remap = 9; 8 = LP in plain
+    workgroup order; 25 = LP with the kept-count-aware launch order (ATTN_SORTED); 0 / 1 = no kernel bit = the round-1
+    kernel (csrc/bsattn.hip), the second product kernel.  Experiments (libjenga_amd_exp.so only, skipped otherwise):
+    2 / 3 = the 8-wave ping-pong kernel, 64 / 65 = the pair kernel -- held to the same tolerance."""
+    from jenga_amd import _capi
     from oracle import attention as oa
+    if flags is not None and (flags & (_capi.ATTN_PINGPONG | _capi.ATTN_PAIR)) and not _capi.has_experiments():
+        pytest.skip("experiment kernel: needs JENGA_LIB=libjenga_amd_exp.so (python -m jenga_amd.build --experiments)")
     gen = torch.Generator().manual_seed(11)
     H, nb_img, tb = 3, 9, 2
     S = (nb_img + tb) * 128
@@ -566,8 +571,8 @@ def test_c_abi_rejects_bad_arguments_on_device(dev):
     idx = torch.zeros(1, 1, 2, 2, dtype=torch.int32, device=dev)
     cnt = torch.ones(1, 1, 2, dtype=torch.int32, device=dev)
     p = _capi._p
-    args = lambda qq=q, dtype=0, ss=128: (st, p(qq), p(q), p(vt), p(o), p(sl), p(idx), p(cnt), 1, 1, 2, 2, 256 * 128, ss, 128,
-                                          256 * 128, 128, 128, 256 * 128, 128, 128, 0.088, 0.0, 2, dtype, 1)
+    args = lambda qq=q, dtype=0, ss=128: (st, p(qq), p(q), p(vt), p(o), p(sl), p(idx), p(cnt), None, 1, 1, 2, 2, 256 * 128, ss,
+                                          128, 256 * 128, 128, 128, 256 * 128, 128, 128, 0.088, 0.0, 2, dtype, 1)
     assert L.jenga_bsattn_fwd(*args()) == 0
     torch.cuda.synchronize()
     assert L.jenga_bsattn_fwd(*args(dtype=7)) != 0 and b"dtype" in L.jenga_last_error()

@@ -33,6 +33,13 @@ def main():
     ap.add_argument("--drop", type=float, default=0.75)
     ap.add_argument("--p", type=float, default=0.3)
     ap.add_argument("--peaky", type=float, default=0.0, help=">0: clustered block means with this temperature")
+    ap.add_argument("--coherent", type=int, default=0, metavar="SMOOTH",
+                    help="SURVEY.md 8(d)'s second regime: K block means = centroid + noise with centroids smoothed SMOOTH "
+                         "times over the Hilbert block-neighbour graph (spatially smooth features); Q of block m drawn "
+                         "near the mean centroid of its Hilbert neighbours.  Adjacent query blocks then keep similar "
+                         "lists, as a trained model's do; --gain sets the temperature so that top_k decides n")
+    ap.add_argument("--gain", type=float, default=3.0, help="--coherent: centroid scale (pooled score ~ gain^2)")
+    ap.add_argument("--sorted", action="store_true", help="kept-count-aware launch order (ATTN_SORTED)")
     ap.add_argument("--iters", type=int, default=5)
     ap.add_argument("--valid-text", type=int, default=64)
     ap.add_argument("--no-xcd", action="store_true")
@@ -44,7 +51,8 @@ def main():
                     help="experiment: every query block keeps a random 31.6 %% of the kv blocks [0, WINDOW) only")
     ap.add_argument("--k-head-major", action="store_true", help="K (and Q) stored [B,H,S,D]: contiguous 16 KiB K tiles")
     ap.add_argument("--flags", type=int, default=None,
-                    help="jenga_bsattn_fwd flags (1 = XCD remap, 2 = ping-pong, 4 = round-1 kernel; default: pair kernel + remap)")
+                    help="attention flags (_capi.ATTN_*): 1 = XCD remap, 8 = LP kernel (default 9), 16 = kept-count-aware "
+                         "order, 0 / 1 = round-1 kernel; experiments library only: 2 = ping-pong, 64 = pair, 72 = LP pair")
     ap.add_argument("--pair-overlap", type=float, default=-1.0,
                     help=">= 0: synthetic lists -- every odd query block shares this fraction of its list with the even "
                          "block in front of it (what Hilbert-adjacent blocks of a trained model look like); same counts")
@@ -66,6 +74,21 @@ def main():
         k = (k.view(1, nb, 128, H, 128).float() + cent).to(torch.bfloat16).view(1, S, H, 128)
         pick = torch.randint(0, nimg, (nb,), device=dev)
         q = (q.view(1, nb, 128, H, 128).float() + cent[:, pick]).to(torch.bfloat16).view(1, S, H, 128)
+    if a.coherent > 0:
+        g = torch.Generator(device=dev).manual_seed(11)
+        cent = torch.randn(nb, H, 128, device=dev, generator=g)
+        A = torch.zeros(nb, nb, device=dev)
+        A[:nimg, :nimg] = nbm.to(dev).float()
+        A[nimg:, nimg:] = torch.eye(tb, device=dev)
+        A = A / A.sum(-1, keepdim=True)
+        for _ in range(a.coherent):
+            cent = torch.einsum("mn,nhd->mhd", A, cent)
+            cent = cent / cent.norm(dim=-1, keepdim=True) * (128 ** 0.5)      # keep |c|^2 = 128 like white noise
+        qcent = torch.einsum("mn,nhd->mhd", A, cent)                          # mean centroid of the Hilbert neighbours
+        qcent = qcent / qcent.norm(dim=-1, keepdim=True) * (128 ** 0.5)
+        noise = lambda: torch.randn(1, nb, 128, H, 128, device=dev, generator=g)
+        k = (noise() + a.gain * cent.view(1, nb, 1, H, 128)).to(torch.bfloat16).view(1, S, H, 128)
+        q = (noise() + a.gain * qcent.view(1, nb, 1, H, 128)).to(torch.bfloat16).view(1, S, H, 128)
     top_k = int((1 - a.drop) * nimg)
     seqlens = torch.tensor([S_img + a.valid_text], dtype=torch.int32, device=dev)
 
@@ -76,6 +99,10 @@ def main():
     res["pool_GBps"] = (q.numel() * 2 * (nimg / nb) + k.numel() * 2) / ((ms + ms2) * 1e-3) / 1e9
     ms, (mask, idx, cnt) = timed(lambda: _capi.block_select(qpool, kpool, nbm, nimg, tb, top_k, a.p), a.iters)
     res["select_ms"] = ms
+    mk = _capi.block_select(qpool, kpool, nbm, nimg, tb, top_k, a.p, want_mask=True, want_lists=False)[0].bool()
+    both = (mk[:, :, :-1, :nimg] & mk[:, :, 1:, :nimg]).sum(-1).float()
+    res["adjacent_shared_frac"] = float((both / mk[:, :, :-1, :nimg].sum(-1).float()).mean().item())
+    del mk, both
     ms, vt = timed(lambda: _capi.pack_v(v, nb), a.iters)
     res["pack_v_ms"] = ms
     res["pack_v_GBps"] = 2 * v.numel() * 2 / (ms * 1e-3) / 1e9
@@ -120,8 +147,12 @@ def main():
     res["pairs"] = pairs
     res["kept_mean"] = kept / (H * nimg)
     res["kept_min_max"] = [int(cnt.min()), int(cnt.max())]
+    fl = a.flags
+    if a.sorted:
+        fl = (_capi.ATTN_DEFAULT_FLAGS if fl is None else fl) | _capi.ATTN_SORTED
+    res["flags"] = _capi.ATTN_DEFAULT_FLAGS if fl is None else fl
     ms, o = timed(lambda: _capi.bsattn_fwd(q, k, vt, seqlens, idx, cnt, nimg, 128 ** -0.5, 0.0, nimg,
-                                           xcd_remap=not a.no_xcd, flags=a.flags), a.iters)
+                                           xcd_remap=not a.no_xcd, flags=fl), a.iters)
     res["attn_ms"] = ms
     res["attn_TFLOPs"] = flops / (ms * 1e-3) / 1e12
     res["attn_frac_of_2.5PF"] = res["attn_TFLOPs"] / 2500
