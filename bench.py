@@ -148,7 +148,7 @@ def cpu_baseline(rates, p_remain, budget_s=9.0):
         tb = 2
         nb = S_img_blocks + tb
         S = nb * 128
-        nbm = None     # (the static neighbour matrix costs seconds of Python at this size; it adds ~2 % of the blocks)
+        nbm = og.gilbert_block_neighbor_mapping(*grid)    # the static Hilbert block adjacency (the oracle's C Gilbert)
         q = torch.randn(1, heads, S, 128, generator=gen).to(dtype)
         k = torch.randn(1, heads, S, 128, generator=gen).to(dtype)
         v = torch.randn(1, heads, S, 128, generator=gen).to(dtype)
@@ -164,11 +164,11 @@ def cpu_baseline(rates, p_remain, budget_s=9.0):
 
     legs = []
     for name, dtype in (("fp32", torch.float32), ("bf16", torch.bfloat16)):
-        t_sel, t_att, frac, dens = one(900, None, 1, dtype, budget_s)
+        t_sel, t_att, frac, dens = one(900, (32, 45, 80), 1, dtype, budget_s)
         legs.append((name, t_sel, t_att, frac, dens))
         out[f"full_res_1head_{name}"] = {"selection_s": round(t_sel, 3), "attention_s_extrapolated": round(t_att, 2),
                                         "rows_timed_frac": round(frac, 4), "kept_block_frac": round(dens, 3)}
-    t_sel, t_att, frac, dens = one(220, None, 24, torch.bfloat16, budget_s)
+    t_sel, t_att, frac, dens = one(220, (32, 22, 40), 24, torch.bfloat16, budget_s)
     out["half_res_layer_24heads_bf16"] = {"selection_s": round(t_sel, 3), "attention_s_extrapolated": round(t_att, 2),
                                           "rows_timed_frac": round(frac, 4), "kept_block_frac": round(dens, 3)}
     best = min(legs, key=lambda l_: l_[1] + l_[2])
@@ -474,6 +474,7 @@ def main():
                      "launches": ps["launches"],
                      "avg_launch_ms": round(ps["total_ms"] / max(ps["launches"], 1), 3),
                      "kept_block_pairs_per_launch": ps["pairs"] // max(ps["launches"], 1),
+                     "adjacent_shared_frac": round(ps.get("adjacent_shared_frac", float("nan")), 3),
                      "algorithmic_flops": "4*128^3 per kept (128-query, 128-key) block pair, realised masks"},
     }
     if dense_ms is not None:
@@ -490,7 +491,7 @@ def main():
             "value": round(cb["s_per_layer"] * layers * len(computed_steps), 1), "unit": "s/video",
             "cores": cb["cores"], "kind": "port", "cpu_model": cb["cpu_model"], "logical_cpus": cb["logical"],
             "sample": "reference PyTorch-CPU eager path restated in torch (oracle/eager_torch.py: torch block selection "
-                      "+ F.scaled_dot_product_attention with the block mask expanded per 128x128 tile; the reference's "
+                      "incl. the Hilbert block-neighbour matrix + F.scaled_dot_product_attention with the block mask expanded per 128x128 tile; the reference's "
                       "only CPU-capable attention mode, attenion.py:102-109), torch.set_num_threads(physical cores); "
                       "time-capped samples, extrapolated linearly in query rows: A = 1 head x full S=115456 in fp32 and "
                       f"bf16, B = one 24-head layer of the 0.5-res stage (S=28416) in bf16; value = 24 heads x "

@@ -68,10 +68,23 @@ class AttnProfile:
         self.events = []        # (start, stop)
         self.pairs = None       # device int64 scalar: kept (q-block, kv-block) pairs over all recorded launches
         self.launches = 0
+        self.last_lists = None  # (idx, cnt) of the most recent launch with image query blocks
 
     def summary(self):
         ms = sum(a.elapsed_time(b) for a, b in self.events)
-        return dict(launches=self.launches, total_ms=ms, pairs=int(self.pairs.item()) if self.pairs is not None else 0)
+        out = dict(launches=self.launches, total_ms=ms, pairs=int(self.pairs.item()) if self.pairs is not None else 0)
+        if self.last_lists is not None:
+            # share of a query block's kept image kv blocks that the NEXT query block of the same head keeps too
+            # (how coherent the lists are: ~0.35 for random lists at 30 % density, ~0.9 for a trained model's)
+            idx, cnt = self.last_lists
+            B, H, nq, nb = idx.shape
+            valid = torch.arange(nb, device=idx.device)[None, None, None, :] < cnt[..., None]
+            hit = torch.zeros((B, H, nq, nb), dtype=torch.int8, device=idx.device)
+            hit.scatter_add_(-1, torch.where(valid, idx, torch.zeros_like(idx)).long(), valid.to(torch.int8))
+            img = hit[..., :nq].bool()
+            both = (img[:, :, :-1] & img[:, :, 1:]).sum(-1).float()
+            out["adjacent_shared_frac"] = float((both / img[:, :, :-1].sum(-1).clamp(min=1).float()).mean().item())
+        return out
 
 
 ATTN_PROFILE = None
@@ -567,6 +580,8 @@ def bsattn_fwd(q, k, vt, seqlens, idx, cnt, nq_img, sm_scale, text_amp, text_blo
             pairs = B * H * (n_blocks - nq_img) * n_blocks
             tot = (cnt.sum(dtype=torch.int64) if cnt is not None else 0) + pairs
             prof.pairs = tot if prof.pairs is None else prof.pairs + tot
+            if idx is not None and nq_img > 1:
+                prof.last_lists = (idx, cnt)
     return out
 
 

@@ -122,7 +122,7 @@ def test_hunyuan_720p_lists_vs_oracle_from_hip_pooled(dev):
 
 
 def test_wan14b_720p_full_shape_properties(dev):
-    """BASELINE.json configs[3] at full shape (two of the 40 heads): 21x45x80 = 75 600 tokens, padded to 591 blocks,
+    """BASELINE.json configs[3] at full shape (eight of the 40 heads): 21x45x80 = 75 600 tokens, padded to 591 blocks,
     first_frame_blocks = 591 // 21 = 28, text_blocks = 0, p = 0.8, drop rates 0.7: (a) V == 1 -> every returned row
     is 1 (softmax weights sum to one through the padded tail, the first-frame rule and the kv-length mask);
     (b) list invariants incl. the dense first-frame corner; (c) lists vs the oracle from the HIP pooled tensors;
@@ -131,7 +131,7 @@ def test_wan14b_720p_full_shape_properties(dev):
     from jenga_amd.modules.attention_block_sparse import block_sparse_attention_wan
     from oracle import attention as oa
     t, h, w = 21, 45, 80
-    L, H = t * h * w, 2
+    L, H = t * h * w, 8
     nb = (L + 127) // 128
     assert nb == 591
     ffb = nb // 21
@@ -165,7 +165,7 @@ def test_wan14b_720p_full_shape_properties(dev):
                                    first_frame_blocks=ffb, shape_xfuse=True)
     vp_ = torch.nn.functional.pad(v, [0, 0, 0, 0, 0, pad])
     mc = m.cpu().numpy()
-    for (hh, mq) in [(0, 0), (1, 300), (0, nb - 1)]:
+    for (hh, mq) in [(0, 0), (1, 300), (0, nb - 1), (5, 27), (7, 28), (3, 450)]:
         blocks = np.nonzero(mc[0, hh, mq])[0].tolist()
         n = len(blocks)
         kk = torch.cat([kp_[0, b * 128:(b + 1) * 128, hh] for b in blocks]).float().cpu().numpy()[None, None]

@@ -15,4 +15,64 @@ A)
   bash tools/prof_bench.sh r03_sim8 --simulate-ranks 8 --steps 3 --no-cpu-baseline --no-dense-ref > $O/A_prof_sim8.log 2>&1
   head -40 gpurun_out/prof_r03_sim8/kernel_stats.csv
   ;;
+B)
+  # second session: the whole suite at the new ABI, the experiment kernels through libjenga_amd_exp.so, the coherent-list
+  # regime (LP in remap / plain / sorted order, LP pair), the N=8-shape launch, the per-rank step with the fused prologue
+  timeout 1500 python -m pytest tests -q -m gpu -x > $O/B_suite.log 2>&1; tail -15 $O/B_suite.log
+  JENGA_LIB=$PWD/jenga_amd/libjenga_amd_exp.so timeout 900 python -m pytest tests/test_gpu_pair.py tests/test_gpu_parity.py -q -m gpu -k "pair or sparse_kernel_vs_oracle" > $O/B_exp.log 2>&1; tail -5 $O/B_exp.log
+  ba() { tag=$1; shift; timeout 300 python tools/bench_attn.py "$@" > $O/B_attn_$tag.json 2> $O/B_attn_$tag.err; python - $O/B_attn_$tag.json $tag <<'PY'
+import json,sys
+try:
+    d=json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+    print(sys.argv[2], {k: (round(d[k],3) if isinstance(d[k],float) else d[k]) for k in ("attn_ms","attn_TFLOPs","kept_mean","adjacent_shared_frac","flags","finite") if k in d})
+except Exception as e:
+    print(sys.argv[2], "FAILED", e)
+PY
+  }
+  ba flat_lp --drop 0.7 --iters 20
+  ba flat_sorted --drop 0.7 --iters 20 --sorted
+  ba coh3_lp --drop 0.7 --iters 20 --coherent 3 --gain 2
+  ba coh3_plain --drop 0.7 --iters 20 --coherent 3 --gain 2 --flags 8
+  ba coh3_sorted --drop 0.7 --iters 20 --coherent 3 --gain 2 --sorted
+  ba coh8_lp --drop 0.7 --iters 20 --coherent 8 --gain 2
+  ba coh3_r1 --drop 0.7 --iters 20 --coherent 3 --gain 2 --flags 1
+  JENGA_LIB=$PWD/jenga_amd/libjenga_amd_exp.so ba coh3_lppair --drop 0.7 --iters 20 --coherent 3 --gain 2 --flags 73
+  JENGA_LIB=$PWD/jenga_amd/libjenga_amd_exp.so ba coh8_lppair --drop 0.7 --iters 20 --coherent 8 --gain 2 --flags 73
+  JENGA_LIB=$PWD/jenga_amd/libjenga_amd_exp.so ba flat_lppair --drop 0.7 --iters 20 --flags 73
+  ba n8_flat --heads 3 --drop 0.75 --iters 100
+  ba n8_flat_sorted --heads 3 --drop 0.75 --iters 100 --sorted
+  ba n8_coh3 --heads 3 --drop 0.75 --iters 100 --coherent 3 --gain 2
+  ba n8_coh3_sorted --heads 3 --drop 0.75 --iters 100 --coherent 3 --gain 2 --sorted
+  run B_sim8 --simulate-ranks 8 --steps 3 --no-cpu-baseline --no-dense-ref
+  run B_coherent --coherent 4 --peaky 3 --no-cpu-baseline
+  ;;
+C)
+  # third session: counters for the coherent and the flat regime (separate --pmc passes), sustained A/B of the
+  # kept-count-aware order, GEMMs at the per-rank shapes of an 8-rank job (default pick vs TunableOp), profile of the
+  # per-rank step after the prologue fusion, coherent latents through the whole DiT
+  bash tools/pmc_attn2.sh r03_coh3 --drop 0.7 --iters 2 --coherent 3 --gain 2 > $O/C_pmc_coh3.log 2>&1; tail -30 $O/C_pmc_coh3.log
+  bash tools/pmc_attn2.sh r03_flat --drop 0.7 --iters 2 > $O/C_pmc_flat.log 2>&1; tail -30 $O/C_pmc_flat.log
+  ba() { tag=$1; shift; timeout 300 python tools/bench_attn.py "$@" > $O/C_attn_$tag.json 2> $O/C_attn_$tag.err; python - $O/C_attn_$tag.json $tag <<'PY'
+import json,sys
+try:
+    d=json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+    print(sys.argv[2], {k: (round(d[k],3) if isinstance(d[k],float) else d[k]) for k in ("attn_ms","attn_TFLOPs","kept_mean","adjacent_shared_frac","flags","finite") if k in d})
+except Exception as e:
+    print(sys.argv[2], "FAILED", e)
+PY
+  }
+  ba ab_flat_plain_1 --drop 0.7 --iters 200
+  ba ab_flat_sorted_1 --drop 0.7 --iters 200 --sorted
+  ba ab_flat_plain_2 --drop 0.7 --iters 200
+  ba ab_flat_sorted_2 --drop 0.7 --iters 200 --sorted
+  ba ab_coh_plain --drop 0.7 --iters 200 --coherent 3 --gain 2
+  ba ab_coh_sorted --drop 0.7 --iters 200 --coherent 3 --gain 2 --sorted
+  ba ab_n8_plain --heads 3 --drop 0.75 --iters 1000
+  ba ab_n8_sorted --heads 3 --drop 0.75 --iters 1000 --sorted
+  timeout 300 python tools/tune_gemm.py --ranks=8 > $O/C_gemm_n8_default.txt 2>&1; cat $O/C_gemm_n8_default.txt
+  PYTORCH_TUNABLEOP_ENABLED=1 PYTORCH_TUNABLEOP_TUNING=1 PYTORCH_TUNABLEOP_FILENAME=$O/tunableop_n8.csv timeout 900 python tools/tune_gemm.py --ranks=8 > $O/C_gemm_n8_tuned.txt 2>&1; cat $O/C_gemm_n8_tuned.txt; cat $O/tunableop_n8*.csv | head -20
+  bash tools/prof_bench.sh r03_sim8_fused --simulate-ranks 8 --steps 3 --no-cpu-baseline --no-dense-ref > $O/C_prof_sim8.log 2>&1
+  run C_coherent4 --coherent 4 --no-cpu-baseline --no-dense-ref
+  run C_coherent4_peaky15 --coherent 4 --peaky 1.5 --no-cpu-baseline --no-dense-ref
+  ;;
 esac
