@@ -74,6 +74,11 @@ def parse():
     ap.add_argument("--i2v", action="store_true",
                     help="HunyuanVideo-I2V flavour: token_replace modulation of the first latent frame, 512 text tokens "
                          "(4 text blocks) -- BASELINE.json configs[4] with --preset 3stage")
+    ap.add_argument("--gemm-tuning", default="auto", metavar="FILE|auto|off|record:FILE",
+                    help="hipBLASLt solution selection for the dense GEMMs (jenga_amd/gemm_tuning.py): auto = replay "
+                         "jenga_amd/tuned/hipblaslt_gfx950.csv when present (no timing at run time), off = the library's "
+                         "default heuristic, record:FILE = let TunableOp time every solution for the shapes this run "
+                         "meets and write FILE (slow; not a measurement run)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-dense-ref", action="store_true",
                     help="skip the ONE dense (sa-drop 0) computed step that is run after the timed region to report "
@@ -232,8 +237,13 @@ def main():
                     return True
             return _W()
 
-    from jenga_amd import _capi
+    from jenga_amd import _capi, gemm_tuning
     from jenga_amd.dit import NON_SKIP_STEPS, JengaHYVideoDiT
+    gemm_file = None
+    if a.gemm_tuning.startswith("record:"):
+        gemm_file = gemm_tuning.enable(a.gemm_tuning[len("record:"):], tune=True)
+    elif a.gemm_tuning != "off":
+        gemm_file = gemm_tuning.enable(None if a.gemm_tuning == "auto" else a.gemm_tuning)
     from jenga_amd.modules import ulysses
 
     torch.manual_seed(0)
@@ -463,7 +473,11 @@ def main():
                    "classes_not_sampled": unsampled,     # non-empty only for very small --steps: they borrow a neighbour's mean
                    "parallelism": (f"rank 0 of a simulated ulysses{sim} job on ONE GPU, exchanges replaced by local copies"
                                    if sim > 1 else "single GPU" if world == 1 else f"ulysses{world} (RCCL all-to-all)"),
-                   "weights": "random init N(0,0.02), seed 0", "finite_output": finite},
+                   "weights": "random init N(0,0.02), seed 0", "finite_output": finite,
+                   "gemm_selection": (os.path.relpath(gemm_file, ROOT) + (" (RECORDING: not a measurement)"
+                                                                          if a.gemm_tuning.startswith("record:") else
+                                                                          " (TunableOp replay, tuning off)")
+                                      if gemm_file else "hipBLASLt default heuristic")},
         "roofline": {"kernel": "jenga::bsattn_lp_kernel<bf16>" if (_capi.ATTN_DEFAULT_FLAGS & 8) else "jenga::bsattn_fwd_kernel<bf16>", "bound": "mfma", "achieved": round(ach, 1),
                      "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_PEAK_TFLOPS, 4),
                      "traffic": traffic, "traffic_TBps": traffic_tbps,

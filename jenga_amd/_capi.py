@@ -18,7 +18,9 @@ ATTN_LP = 8          # round-1 decomposition + in-wave software pipeline (csrc/b
 ATTN_SORTED = 16     # (Python-side) kept-count-aware launch order: jenga_order_by_count feeds jenga_bsattn_fwd's `order`
 ATTN_PAIR = 64       # (Python-side, experiment) route to jenga_bsattn_pair_fwd: the pair kernel; with ATTN_LP the 8-wave
 #                      LP pair (csrc/experiments/); needs libjenga_amd_exp.so
-ATTN_DEFAULT_FLAGS = int(os.environ.get("JENGA_ATTN_FLAGS", str(ATTN_XCD_REMAP | ATTN_LP)))
+# default: LP kernel, XCD remap, kept-count-aware order inside every XCD's range (+3.3 % sustained on lists whose counts
+# vary, neutral on constant counts: profiles/r03_attn_order_ab.json)
+ATTN_DEFAULT_FLAGS = int(os.environ.get("JENGA_ATTN_FLAGS", str(ATTN_XCD_REMAP | ATTN_LP | ATTN_SORTED)))
 SELECT_DEVICE_SCAN = 1   # jenga_block_select flags: torch's DEVICE cumsum semantics for the kept-count rule
 SELECT_DEFAULT_FLAGS = int(os.environ.get("JENGA_SELECT_FLAGS", "0"))
 

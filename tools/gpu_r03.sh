@@ -75,4 +75,30 @@ PY
   run C_coherent4 --coherent 4 --no-cpu-baseline --no-dense-ref
   run C_coherent4_peaky15 --coherent 4 --peaky 1.5 --no-cpu-baseline --no-dense-ref
   ;;
+D)
+  # fourth session: launch order variants (is it head-of-line blocking between XCDs?), TunableOp recording for the
+  # GEMM shapes of the N=1 loop and of one rank of an 8-rank job, then the bench with and without the recorded picks
+  ba() { tag=$1; shift; timeout 300 python tools/bench_attn.py "$@" > $O/D_attn_$tag.json 2> $O/D_attn_$tag.err; python - $O/D_attn_$tag.json $tag <<'PY'
+import json,sys
+try:
+    d=json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+    print(sys.argv[2], {k: (round(d[k],3) if isinstance(d[k],float) else d[k]) for k in ("attn_ms","attn_TFLOPs","kept_mean","kept_min_max","adjacent_shared_frac","flags","finite") if k in d})
+except Exception as e:
+    print(sys.argv[2], "FAILED", e)
+PY
+  }
+  ba flat_9 --drop 0.7 --iters 200 --flags 9
+  ba flat_24 --drop 0.7 --iters 200 --flags 24
+  ba flat_25 --drop 0.7 --iters 200 --flags 25
+  ba flat80_9 --drop 0.8 --iters 200 --flags 9
+  ba flat80_25 --drop 0.8 --iters 200 --flags 25
+  rm -f $O/tuned_n1.csv $O/tuned_sim8.csv
+  timeout 1200 python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-dense-ref --gemm-tuning record:$O/tuned_n1.csv > $O/D_record_n1.json 2> $O/D_record_n1.err; tail -c 300 $O/D_record_n1.json; wc -l $O/tuned_n1.csv
+  timeout 900 python bench.py --simulate-ranks 8 --steps 1 --warmup 0 --no-cpu-baseline --no-dense-ref --gemm-tuning record:$O/tuned_sim8.csv > $O/D_record_sim8.json 2> $O/D_record_sim8.err; wc -l $O/tuned_sim8.csv
+  cat $O/tuned_n1.csv
+  run D_n1_default --no-cpu-baseline --gemm-tuning off
+  run D_n1_tuned --no-cpu-baseline --gemm-tuning $O/tuned_n1.csv
+  run D_sim8_default --simulate-ranks 8 --steps 3 --no-cpu-baseline --no-dense-ref --gemm-tuning off
+  run D_sim8_tuned --simulate-ranks 8 --steps 3 --no-cpu-baseline --no-dense-ref --gemm-tuning $O/tuned_sim8.csv
+  ;;
 esac
