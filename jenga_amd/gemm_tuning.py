@@ -27,7 +27,13 @@ def enable(path=None, tune=False):
     t.tuning_enable(bool(tune))
     t.set_filename(path, insert_device_ordinal=False)
     if not tune:
-        t.read_file(path)
+        try:
+            ok = t.read_file(path)
+        except Exception:          # noqa: BLE001 - a selection file is an optimisation, never a reason to fail
+            ok = False
+        if not ok:                 # validators do not match this stack: fall back to the library's heuristic
+            t.enable(False)
+            return None
     return path
 
 
