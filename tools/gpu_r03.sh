@@ -101,4 +101,27 @@ PY
   run D_sim8_default --simulate-ranks 8 --steps 3 --no-cpu-baseline --no-dense-ref --gemm-tuning off
   run D_sim8_tuned --simulate-ranks 8 --steps 3 --no-cpu-baseline --no-dense-ref --gemm-tuning $O/tuned_sim8.csv
   ;;
+E1)
+  # counters for the default kernel + order (flat and coherent), the presets, the per-rank steps, Wan2.1-14B
+  timeout 1500 python -m pytest tests -q -m gpu > $O/E_suite.log 2>&1; tail -4 $O/E_suite.log
+  bash tools/pmc_attn2.sh r03_lp --drop 0.7 --iters 2 > $O/E_pmc_lp.log 2>&1; tail -22 $O/E_pmc_lp.log
+  bash tools/pmc_attn2.sh r03_lp_unsorted --drop 0.7 --iters 2 --flags 9 > $O/E_pmc_lp9.log 2>&1; tail -22 $O/E_pmc_lp9.log
+  run E_turbo --preset turbo --no-cpu-baseline --no-dense-ref
+  run E_flash --preset flash --no-cpu-baseline --no-dense-ref
+  run E_3stage --preset 3stage --no-cpu-baseline --no-dense-ref
+  run E_3stage_i2v --preset 3stage --i2v --no-cpu-baseline --no-dense-ref
+  run E_dense --preset dense --steps 2 --warmup 1 --no-cpu-baseline
+  run E_base_shipped_rates --preset base-mgpu --no-cpu-baseline --no-dense-ref
+  run E_sim8_base --simulate-ranks 8 --steps 3 --no-cpu-baseline
+  run E_sim8_turbo --simulate-ranks 8 --preset turbo-mgpu --steps 3 --no-cpu-baseline --no-dense-ref
+  run E_sim8_3stage_i2v --simulate-ranks 8 --preset 3stage-mgpu --i2v --steps 3 --no-cpu-baseline --no-dense-ref
+  timeout 600 python tools/bench_wan.py --qk-gain 4 > $O/E_wan14b_gain4.json 2> $O/E_wan14b_gain4.err; tail -c 600 $O/E_wan14b_gain4.json
+  ;;
+E2)
+  # closing records at HEAD: rocprofv3 kernel stats of the default command, the default bench line, the full loop
+  bash tools/prof_bench.sh r03_default > $O/E2_prof.log 2>&1; head -12 gpurun_out/prof_r03_default/kernel_stats.csv | cut -c1-160
+  run E2_default
+  run E2_full50 --steps 50 --warmup 1 --no-cpu-baseline --no-dense-ref
+  run E2_coherent --coherent 4 --no-cpu-baseline --no-dense-ref
+  ;;
 esac
