@@ -124,4 +124,9 @@ E2)
   run E2_full50 --steps 50 --warmup 1 --no-cpu-baseline --no-dense-ref
   run E2_coherent --coherent 4 --no-cpu-baseline --no-dense-ref
   ;;
+F)
+  # A/B: the two workgroups of a CU given a start offset (alt_libs/dph*.so, tools/build_alt3.sh -DJENGA_LP_DEPHASE=n)
+  bash tools/gpu_ab.sh r03/F_ab "--drop 0.7 --iters 200" base dph1 dph2 dph4 base dph2
+  bash tools/gpu_ab.sh r03/F_ab_coh "--drop 0.7 --iters 200 --coherent 3 --gain 2" base dph2
+  ;;
 esac
