@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define JENGA_ABI_VERSION 2   /* 2: jenga_block_select(flags), jenga_bsattn_fwd(order), jenga_sp_qkv_prologue, jenga_order_by_count */
+#define JENGA_ABI_VERSION 2   /* 2: jenga_block_select(flags), jenga_bsattn_fwd(order), jenga_sp_qkv_prologue, jenga_order_by_count, jenga_linear */
 
 enum { JENGA_OK = 0, JENGA_EINVAL = 1, JENGA_ELAUNCH = 2, JENGA_EUNSUPPORTED = 3 };
 enum { JENGA_BF16 = 0, JENGA_FP16 = 1 };
@@ -114,6 +114,26 @@ int jenga_wan_ln_modulate(void* stream, const float* x, void* y, const float* we
                           int64_t y_row_stride, float eps, int out_dtype, int round_ln);
 int jenga_wan_gate_residual(void* stream, const float* x, const void* y, const float* gate, float* out, int64_t rows,
                             int64_t C, int64_t x_row_stride, int64_t y_row_stride, int64_t o_row_stride, int y_dtype);
+
+/* jenga_linear: a dense layer of the DiT blocks with its element-wise neighbours in the
+ * GEMM epilogue.  The GEMM is hipBLASLt's; this entry point only exposes what torch's front-end does not: an output
+ * row stride, the GELU epilogue into a strided destination, and gate / residual as alpha-vector / C-matrix.
+ *     out[m, n] = act( gate[n] * sum_k x[m,k] w[n,k]  +  bias[n]  +  res[m, n] )
+ *   x [M,K], w [N,K] (nn.Linear layout), res / out [M,N], all 16-bit `dtype`, row strides in elements (inner stride 1);
+ *   bias [N] in dtype or NULL -- added AS GIVEN (when a gate is used the caller passes gate * bias, which is what
+ *   apply_gate(linear(x)) means); gate fp32 [N] on the device or NULL (= 1); res NULL = no residual;
+ *   act: JENGA_ACT_GELU_TANH (mlp_act "gelu_tanh"; not together with gate / res) or JENGA_ACT_NONE.
+ *   workspace: device scratch the library may use (64 MiB is plenty); fp32 accumulation, ONE rounding to dtype at the
+ *   end (the eager reference rounds after the GEMM, after the gate multiply and after the residual add).
+ * Replaces: linear1's MLP half + nn.GELU(tanh) of MMSingleStreamBlock written straight into linear2's concat buffer
+ * (models_mul_block_gc_ha_multigpu.py:404-406, 498-499); apply_gate + residual add behind img/txt_attn_proj, the MLPs'
+ * fc2 and linear2 (:297-315, 500; modulate_layers.py:53-68). */
+#define JENGA_ACT_NONE 0
+#define JENGA_ACT_GELU_TANH 1
+int jenga_linear(void* stream, const void* x, const void* w, const void* bias, const void* res, const float* gate,
+                 void* out, int64_t M, int64_t N, int64_t K, int64_t x_row_stride, int64_t w_row_stride,
+                 int64_t res_row_stride, int64_t out_row_stride, int act, void* workspace, int64_t workspace_bytes,
+                 int dtype);
 
 /* jenga_qk_norm_rope_pool: jenga_rmsnorm_rope for Q AND K plus the two jenga_block_pool passes of a
  * layer in one kernel.  xq, xk [B, n_blocks*128, H, 128] share one set of strides (the q and k slices of a fused QKV

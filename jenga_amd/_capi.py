@@ -43,6 +43,7 @@ SIGNATURES = {
     "jenga_wan_gate_residual": (_i32, [_vp] * 5 + [_i64] * 5 + [_i32]),
     "jenga_qk_norm_rope_pool": (_i32, [_vp] * 11 + [_i64] * 13 + [_f32, _i32]),
     "jenga_sp_qkv_prologue": (_i32, [_vp] * 11 + [_i64] * 14 + [_f32, _i32]),
+    "jenga_linear": (_i32, [_vp] * 7 + [_i64] * 7 + [_i32, _vp, _i64, _i32]),
     "jenga_block_pool": (_i32, [_vp, _vp, _vp] + [_i64] * 6 + [_i32]),
     "jenga_block_select": (_i32, [_vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp] + [_i64] * 6 + [_f32, _i64, _i32, _i32]),
     "jenga_order_by_count": (_i32, [_vp, _vp, _i64, _i64, _i64, _vp]),
@@ -412,6 +413,54 @@ def gelu_tanh(x, out=None):
     with torch.cuda.device(x.device):
         _check(lib().jenga_gelu_tanh(_stream(x.device), _p(x2), _p(o2), rows, C, xrs, ors, dtype_code(x.dtype)),
                "jenga_gelu_tanh")
+    return out
+
+
+ACT_NONE, ACT_GELU_TANH = 0, 1
+_GEMM_WORKSPACE = {}
+
+
+def _gemm_workspace(device):
+    key = str(device)
+    if key not in _GEMM_WORKSPACE:
+        _GEMM_WORKSPACE[key] = torch.empty(64 << 20, dtype=torch.uint8, device=device)
+    return _GEMM_WORKSPACE[key]
+
+
+def linear(x, weight, bias=None, act=ACT_NONE, gate=None, res=None, out=None):
+    """out = act(gate * (x @ weight.T) + bias + res) in ONE hipBLASLt call (jenga_linear): x [..., K] with a uniform
+    row stride, weight [N, K] (nn.Linear layout), bias [N] (added as given), gate [N] or [1, N] (per-channel; the
+    caller folds it into the bias), res / out [..., N] (may be strided views: the MLP half of the single-stream blocks'
+    concat buffer).  fp32 accumulation, one rounding."""
+    _need_gpu(x, "linear")
+    x2, M, K, xrs = _rows2d(x)
+    N = weight.shape[0]
+    if weight.dim() != 2 or weight.shape[1] != K or weight.stride(1) != 1 or weight.dtype != x.dtype:
+        raise ValueError("linear: weight must be [N, K] in the input dtype with contiguous rows")
+    if out is None:
+        out = torch.empty(tuple(x.shape[:-1]) + (N,), dtype=x.dtype, device=x.device)
+    o2, Mo, No, ors = _rows2d(out)
+    if Mo != M or No != N or out.dtype != x.dtype:
+        raise ValueError("linear: out must be [..., N] with as many rows as x")
+    r2, rrs = None, 0
+    if res is not None:
+        r2, Mr, Nr, rrs = _rows2d(res)
+        if Mr != M or Nr != N or res.dtype != x.dtype:
+            raise ValueError("linear: res must match out")
+    if bias is not None:
+        bias = bias.reshape(-1).to(dtype=x.dtype).contiguous()
+        if bias.numel() != N:
+            raise ValueError("linear: bias must have N entries")
+    g32 = None
+    if gate is not None:
+        g32 = gate.reshape(-1).to(dtype=torch.float32).contiguous()
+        if g32.numel() != N:
+            raise ValueError("linear: gate must have N entries")
+    ws = _gemm_workspace(x.device)
+    with torch.cuda.device(x.device):
+        _check(lib().jenga_linear(_stream(x.device), _p(x2), _p(weight), _p(bias), _p(r2), _p(g32), _p(o2), M, N, K, xrs,
+                                  weight.stride(0), rrs, ors, int(act), _p(ws), ws.numel(), dtype_code(x.dtype)),
+               "jenga_linear")
     return out
 
 

@@ -15,6 +15,7 @@ ARCH = "gfx950"
 EAGER = ["-ffp-contract=off", "-Xclang", "-target-feature", "-Xclang", "-fma-mix-insts"]
 SOURCES = [
     ("capi.cpp", []),
+    ("gemm.cpp", []),          # host code: hipBLASLt GEMMs with epilogues torch's front-end does not expose
     ("gilbert.hip", []),
     ("rowops.hip", EAGER),
     ("select.hip", EAGER),
@@ -77,7 +78,7 @@ def build(force=False, verbose=False, experiments=False):
             raise RuntimeError(f"hipcc failed on {src}:\n{out.decode()}")
         if verbose and out:
             print(out.decode(), file=sys.stderr)
-    cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", lib] + objs
+    cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", lib] + objs + ["-lhipblaslt"]
     subprocess.check_call(cmd)
     return lib
 

@@ -227,17 +227,6 @@ __device__ __forceinline__ void attn_block_lp(const LpParams& P, unsigned char* 
     LP_WAIT_ALL();
     __syncthreads();
 
-#ifdef JENGA_LP_DEPHASE
-    // A/B experiment (round 3, tools/build_alt3.sh): the two workgroups of a CU that start together stay in phase and
-    // want the MFMA pipe / the DMA path at the same moments; give the one in the odd wave slot a head start offset
-    if (!TEXT) {
-        const unsigned wave_slot = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4);   // HW_REG_HW_ID[3:0]
-        if (wave_slot & 1) {
-#pragma unroll
-            for (int i = 0; i < JENGA_LP_DEPHASE; ++i) __builtin_amdgcn_s_sleep(8);        // 8 x 64 clocks each
-        }
-    }
-#endif
     // step t: stage V^T(t) and K(t+2); QK^T on K(t); P.V on V^T(t-1)
 #define LP_STEP(T_, PV_, SM0_)                                                                                        \
     do {                                                                                                              \

@@ -1,0 +1,133 @@
+// Dense linear layers of the DiT blocks with the element-wise work around them folded into the GEMM's own epilogue
+// ("fusing AttenCarve's neighbours into the DiT block ... adaLN modulate / apply_gate").
+// Host code only: the GEMM is hipBLASLt's (a plain library GEMM; nothing here is a hand-written matrix kernel), what this
+// file adds is the choice of epilogue / pointer mode / leading dimensions that torch's front-end does not expose:
+//   act = GELU   out = gelu_tanh(x W^T + b) written with an arbitrary row stride  -> the MLP half of the single-stream
+//                blocks' linear1 lands in linear2's concat buffer directly: the separate 5.7 GB GELU pass is gone
+//                (models_mul_block_gc_ha_multigpu.py:404-406, 498-499)
+//   gate / res   out = res + gate * (x W^T) + b'   (per-channel gate as hipBLASLt's alpha VECTOR, the residual as the
+//                C matrix with beta = 1)           -> apply_gate + residual add of proj / fc2 / linear2
+//                (models_mul_block_gc_ha_multigpu.py:297-315, 500; modulate_layers.py:53-68) in the GEMM epilogue
+// Row-major [M,K] x [N,K]^T is handed to the column-major library as D'[N,M] = op_T(W'[K,N]) * X'[K,M], the same "TN"
+// call torch makes for nn.Linear.
+#include <hip/hip_runtime.h>
+#include <hipblaslt/hipblaslt.h>
+
+#include <map>
+#include <mutex>
+#include <tuple>
+
+#include "../../include/jenga_amd.h"
+
+namespace jenga {
+void set_error(const char* fmt, ...);
+}
+using jenga::set_error;
+
+namespace {
+
+struct Plan {
+    hipblasLtMatmulDesc_t desc = nullptr;
+    hipblasLtMatrixLayout_t A = nullptr, B = nullptr, C = nullptr, D = nullptr;
+    hipblasLtMatmulAlgo_t algo;
+    size_t workspace = 0;
+};
+using Key = std::tuple<int, long long, long long, long long, long long, long long, long long, long long, int, int, int>;
+
+std::mutex g_mu;
+std::map<int, hipblasLtHandle_t> g_handles;
+std::map<Key, Plan> g_plans;
+
+#define LT_TRY(call)                                                             \
+    do {                                                                         \
+        hipblasStatus_t st_ = (call);                                            \
+        if (st_ != HIPBLAS_STATUS_SUCCESS) {                                     \
+            set_error("jenga_linear: %s failed with hipBLAS status %d", #call, (int)st_); \
+            return JENGA_ELAUNCH;                                                \
+        }                                                                        \
+    } while (0)
+
+}  // namespace
+
+extern "C" int jenga_linear(void* stream, const void* x, const void* w, const void* bias, const void* res,
+                            const float* gate, void* out, int64_t M, int64_t N, int64_t K, int64_t x_row_stride,
+                            int64_t w_row_stride, int64_t res_row_stride, int64_t out_row_stride, int act,
+                            void* workspace, int64_t workspace_bytes, int dtype) {
+    if (!x || !w || !out || M < 0 || N <= 0 || K <= 0 || x_row_stride < K || w_row_stride < K || out_row_stride < N ||
+        (res && res_row_stride < N) || (act != JENGA_ACT_NONE && act != JENGA_ACT_GELU_TANH) || workspace_bytes < 0 ||
+        (workspace_bytes > 0 && !workspace)) {
+        set_error("jenga_linear: bad arguments (row strides must cover the rows; act in {0, 1})");
+        return JENGA_EINVAL;
+    }
+    if (act != JENGA_ACT_NONE && (res || gate)) {
+        set_error("jenga_linear: the activation epilogue cannot be combined with gate / residual");
+        return JENGA_EUNSUPPORTED;
+    }
+    if (dtype != JENGA_BF16 && dtype != JENGA_FP16) {
+        set_error("jenga_linear: dtype must be bf16 or fp16");
+        return JENGA_EUNSUPPORTED;
+    }
+    if (M == 0) return JENGA_OK;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) {
+        set_error("jenga_linear: no current HIP device");
+        return JENGA_ELAUNCH;
+    }
+    std::lock_guard<std::mutex> lock(g_mu);
+    hipblasLtHandle_t& handle = g_handles[dev];
+    if (!handle) LT_TRY(hipblasLtCreate(&handle));
+    const hipDataType dt = dtype == JENGA_BF16 ? HIP_R_16BF : HIP_R_16F;
+    const int epi = (act == JENGA_ACT_GELU_TANH) ? (bias ? HIPBLASLT_EPILOGUE_GELU_BIAS : HIPBLASLT_EPILOGUE_GELU)
+                                                 : (bias ? HIPBLASLT_EPILOGUE_BIAS : HIPBLASLT_EPILOGUE_DEFAULT);
+    const int mode = gate ? HIPBLASLT_POINTER_MODE_ALPHA_DEVICE_VECTOR_BETA_HOST : HIPBLASLT_POINTER_MODE_HOST;
+    const long long ldc = res ? res_row_stride : out_row_stride;
+    const Key key{dev, (long long)M, (long long)N, (long long)K, (long long)x_row_stride, (long long)w_row_stride, ldc,
+                  (long long)out_row_stride, epi, mode | (res ? 16 : 0), dtype};
+    auto it = g_plans.find(key);
+    if (it == g_plans.end()) {
+        Plan p;
+        LT_TRY(hipblasLtMatmulDescCreate(&p.desc, HIPBLAS_COMPUTE_32F, HIP_R_32F));
+        const hipblasOperation_t ta = HIPBLAS_OP_T, tb = HIPBLAS_OP_N;
+        LT_TRY(hipblasLtMatmulDescSetAttribute(p.desc, HIPBLASLT_MATMUL_DESC_TRANSA, &ta, sizeof(ta)));
+        LT_TRY(hipblasLtMatmulDescSetAttribute(p.desc, HIPBLASLT_MATMUL_DESC_TRANSB, &tb, sizeof(tb)));
+        const uint32_t e32 = (uint32_t)epi;
+        LT_TRY(hipblasLtMatmulDescSetAttribute(p.desc, HIPBLASLT_MATMUL_DESC_EPILOGUE, &e32, sizeof(e32)));
+        if (bias) {
+            const int32_t bt = (int32_t)dt;
+            LT_TRY(hipblasLtMatmulDescSetAttribute(p.desc, HIPBLASLT_MATMUL_DESC_BIAS_DATA_TYPE, &bt, sizeof(bt)));
+            LT_TRY(hipblasLtMatmulDescSetAttribute(p.desc, HIPBLASLT_MATMUL_DESC_BIAS_POINTER, &bias, sizeof(bias)));
+        }
+        const int32_t pm = (int32_t)mode;
+        LT_TRY(hipblasLtMatmulDescSetAttribute(p.desc, HIPBLASLT_MATMUL_DESC_POINTER_MODE, &pm, sizeof(pm)));
+        LT_TRY(hipblasLtMatrixLayoutCreate(&p.A, dt, (uint64_t)K, (uint64_t)N, w_row_stride));    // W' [K,N], op = T
+        LT_TRY(hipblasLtMatrixLayoutCreate(&p.B, dt, (uint64_t)K, (uint64_t)M, x_row_stride));    // X' [K,M]
+        LT_TRY(hipblasLtMatrixLayoutCreate(&p.C, dt, (uint64_t)N, (uint64_t)M, ldc));             // res' [N,M]
+        LT_TRY(hipblasLtMatrixLayoutCreate(&p.D, dt, (uint64_t)N, (uint64_t)M, out_row_stride));  // out' [N,M]
+        hipblasLtMatmulPreference_t pref = nullptr;
+        LT_TRY(hipblasLtMatmulPreferenceCreate(&pref));
+        const uint64_t ws = (uint64_t)workspace_bytes;
+        LT_TRY(hipblasLtMatmulPreferenceSetAttribute(pref, HIPBLASLT_MATMUL_PREF_MAX_WORKSPACE_BYTES, &ws, sizeof(ws)));
+        hipblasLtMatmulHeuristicResult_t hr[1];
+        int found = 0;
+        const hipblasStatus_t hs = hipblasLtMatmulAlgoGetHeuristic(handle, p.desc, p.A, p.B, p.C, p.D, pref, 1, hr, &found);
+        hipblasLtMatmulPreferenceDestroy(pref);
+        if (hs != HIPBLAS_STATUS_SUCCESS || found < 1) {
+            set_error("jenga_linear: hipBLASLt has no solution for M=%lld N=%lld K=%lld epilogue=%d mode=%d (status %d)",
+                      (long long)M, (long long)N, (long long)K, epi, mode, (int)hs);
+            return JENGA_EUNSUPPORTED;
+        }
+        p.algo = hr[0].algo;
+        p.workspace = hr[0].workspaceSize;
+        it = g_plans.emplace(key, p).first;
+    }
+    Plan& p = it->second;
+    if (bias)   // (the pointer is per call; the descriptor is shared under the lock)
+        LT_TRY(hipblasLtMatmulDescSetAttribute(p.desc, HIPBLASLT_MATMUL_DESC_BIAS_POINTER, &bias, sizeof(bias)));
+    const float one = 1.0f, zero = 0.0f;
+    const void* alpha = gate ? (const void*)gate : (const void*)&one;
+    const float* beta = res ? &one : &zero;
+    const void* c = res ? res : out;
+    LT_TRY(hipblasLtMatmul(handle, p.desc, alpha, w, p.A, x, p.B, beta, c, p.C, out, p.D, &p.algo, workspace,
+                           (size_t)workspace_bytes, (hipStream_t)stream));
+    return JENGA_OK;
+}

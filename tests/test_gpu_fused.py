@@ -131,3 +131,50 @@ def test_sp_qkv_prologue_rejects_bad_arguments(dev):
                                                        _capi._p(w[1]), _capi._p(w[2]), None, None, None, None, 1, 40, 8,
                                                        8, 2, 2, *_capi._bshd_strides(x), 0, *_capi._bshd_strides(w[0]),
                                                        0, 1e-6, 0), "jenga_sp_qkv_prologue")
+
+
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("M,N,K", [(384, 512, 256), (1000, 768, 1024), (77, 3072, 512)])
+def test_linear_epilogues_vs_fp32_reference(dev, dt, M, N, K):
+    """jenga_linear (hipBLASLt GEMM + epilogue, fp32 accumulation, ONE rounding) against an fp32 torch reference of the
+    same expression: plain, bias, tanh-GELU into a STRIDED destination (the MLP half of the single-stream blocks'
+    concat buffer), and gate * (x W^T) + bias' + residual (apply_gate + residual add).  Tolerance: one rounding of the
+    result to the 16-bit dtype + fp32 summation-order noise."""
+    from jenga_amd import _capi
+    g = torch.Generator(device=dev).manual_seed(M + N + K)
+    x = torch.randn(1, M, K + 64, generator=g, device=dev).to(dt)[..., :K]        # strided rows
+    w = (torch.randn(N, K, generator=g, device=dev) * K ** -0.5).to(dt)
+    b = (torch.randn(N, generator=g, device=dev) * 0.1).to(dt)
+    xf, wf, bf = x.float(), w.float(), b.float()
+    ulp = 2.0 ** -8 if dt == torch.bfloat16 else 2.0 ** -11
+
+    def close(got, ref):
+        err = (got.float() - ref).abs()
+        bound = ulp * ref.abs().clamp_min(2.0 ** -6) + 1e-3
+        assert bool((err <= bound).all()), (err.max().item(), (err / bound).max().item())
+
+    close(_capi.linear(x, w), xf @ wf.t())
+    close(_capi.linear(x, w, b), xf @ wf.t() + bf)
+    # GELU epilogue into the right part of a wider buffer; the left part must stay untouched
+    cat = torch.full((1, M, 128 + N), 3.0, dtype=dt, device=dev)
+    _capi.linear(x, w, b, act=_capi.ACT_GELU_TANH, out=cat[..., 128:])
+    close(cat[..., 128:], torch.nn.functional.gelu(xf @ wf.t() + bf, approximate="tanh"))
+    assert bool((cat[..., :128] == 3.0).all())
+    # gate + residual: res + gate * (x W^T + b)  ==  gate * (x W^T) + (gate * b) + res
+    gate = (torch.randn(1, N, generator=g, device=dev) * 0.5).to(dt)
+    res = torch.randn(1, M, N, generator=g, device=dev).to(dt)
+    got = _capi.linear(x, w, b * gate.reshape(-1), gate=gate, res=res)
+    close(got, res.float() + gate.float() * (xf @ wf.t()) + (b * gate.reshape(-1)).float())
+    # the blocks' helper (bias folded by the helper) against the unfused kernels it replaces: within the roundings the
+    # eager chain adds (GEMM -> dtype, * gate -> dtype, + res -> dtype)
+    from jenga_amd.dit import linear_gate_residual
+    lin = torch.nn.Linear(K, N, dtype=dt, device=dev)
+    with torch.no_grad():
+        lin.weight.copy_(w)
+        lin.bias.copy_(b)
+        fused = linear_gate_residual(lin, x, gate, res)
+        unfused = _capi.gate_residual(res, lin(x), gate)
+    err = (fused.float() - unfused.float()).abs()
+    assert bool((err <= 3 * ulp * unfused.float().abs().clamp_min(2.0 ** -4) + 2e-3).all()), err.max().item()
+    with pytest.raises(_capi.JengaError):
+        _capi.linear(x, w, b, act=_capi.ACT_GELU_TANH, res=res)

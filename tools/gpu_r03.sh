@@ -129,4 +129,10 @@ F)
   bash tools/gpu_ab.sh r03/F_ab "--drop 0.7 --iters 200" base dph1 dph2 dph4 base dph2
   bash tools/gpu_ab.sh r03/F_ab_coh "--drop 0.7 --iters 200 --coherent 3 --gain 2" base dph2
   ;;
+G)
+  # jenga_linear (GEMM epilogues): tests, then the loop with it
+  timeout 1500 python -m pytest tests -q -m gpu -x > $O/G_suite.log 2>&1; tail -12 $O/G_suite.log
+  run G_default --no-cpu-baseline --no-dense-ref
+  run G_sim8 --simulate-ranks 8 --steps 3 --no-cpu-baseline --no-dense-ref
+  ;;
 esac
