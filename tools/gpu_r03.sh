@@ -131,7 +131,8 @@ F)
   ;;
 G)
   # jenga_linear (GEMM epilogues): tests, then the loop with it
-  timeout 1500 python -m pytest tests -q -m gpu -x > $O/G_suite.log 2>&1; tail -12 $O/G_suite.log
+  timeout 1500 python -m pytest tests -q -m gpu > $O/G_suite.log 2>&1; tail -12 $O/G_suite.log
+  [ "$2" = tests ] && exit 0
   run G_default --no-cpu-baseline --no-dense-ref
   run G_sim8 --simulate-ranks 8 --steps 3 --no-cpu-baseline --no-dense-ref
   ;;
