@@ -361,6 +361,14 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if world > 1 or sim > 1:
+        # per-rank GEMM shapes (M = S_img / N): hipBLASLt's first pick is not its fastest there (profiles/
+        # r03_gemm_tunableop.json, r03_gemm_epilogue_ab.json) -- let jenga_linear time its first 16 candidates once per
+        # shape, during the untimed priming steps below
+        os.environ.setdefault("JENGA_GEMM_CANDIDATES", "16")
+    if int(os.environ.get("JENGA_GEMM_CANDIDATES", "1")) > 1:
+        for k in range(len(stages)):      # one untimed computed step per stage: every GEMM shape gets its plan here
+            run_step(next(i for i in computed_steps if stage_of(i, split) == k))
     for w in range(a.warmup):
         run_step(computed_steps[0] if w % 2 == 0 else computed_steps[-1])   # computed steps: fills previous_residual
     barrier()

@@ -13,6 +13,7 @@
 #include <hip/hip_runtime.h>
 #include <hipblaslt/hipblaslt.h>
 
+#include <cstdlib>
 #include <map>
 #include <mutex>
 #include <tuple>
@@ -107,17 +108,55 @@ extern "C" int jenga_linear(void* stream, const void* x, const void* w, const vo
         LT_TRY(hipblasLtMatmulPreferenceCreate(&pref));
         const uint64_t ws = (uint64_t)workspace_bytes;
         LT_TRY(hipblasLtMatmulPreferenceSetAttribute(pref, HIPBLASLT_MATMUL_PREF_MAX_WORKSPACE_BYTES, &ws, sizeof(ws)));
-        hipblasLtMatmulHeuristicResult_t hr[1];
+        // JENGA_GEMM_CANDIDATES=k (default 1 = the library's first pick, no timing): time the heuristic's first k
+        // solutions on this call's operands once, when the shape is first met, and keep the fastest -- for warm-up
+        // passes only (it launches the GEMM several times and synchronises the stream; never inside graph capture)
+        int want = 1;
+        if (const char* e = getenv("JENGA_GEMM_CANDIDATES")) want = atoi(e);
+        if (want < 1) want = 1;
+        if (want > 32) want = 32;
+        hipblasLtMatmulHeuristicResult_t hr[32];
         int found = 0;
-        const hipblasStatus_t hs = hipblasLtMatmulAlgoGetHeuristic(handle, p.desc, p.A, p.B, p.C, p.D, pref, 1, hr, &found);
+        const hipblasStatus_t hs =
+            hipblasLtMatmulAlgoGetHeuristic(handle, p.desc, p.A, p.B, p.C, p.D, pref, want, hr, &found);
         hipblasLtMatmulPreferenceDestroy(pref);
         if (hs != HIPBLAS_STATUS_SUCCESS || found < 1) {
             set_error("jenga_linear: hipBLASLt has no solution for M=%lld N=%lld K=%lld epilogue=%d mode=%d (status %d)",
                       (long long)M, (long long)N, (long long)K, epi, mode, (int)hs);
             return JENGA_EUNSUPPORTED;
         }
-        p.algo = hr[0].algo;
-        p.workspace = hr[0].workspaceSize;
+        int best = 0;
+        if (found > 1) {
+            const float one_ = 1.0f, zero_ = 0.0f;
+            const void* alpha_ = gate ? (const void*)gate : (const void*)&one_;
+            const float* beta_ = res ? &one_ : &zero_;
+            const void* c_ = res ? res : out;
+            hipEvent_t e0, e1;
+            hipEventCreate(&e0);
+            hipEventCreate(&e1);
+            float best_ms = 1e30f;
+            for (int i = 0; i < found; ++i) {
+                if (hr[i].state != HIPBLAS_STATUS_SUCCESS || hr[i].workspaceSize > (size_t)workspace_bytes) continue;
+                bool ok = true;
+                for (int rep = 0; rep < 5 && ok; ++rep) {      // 2 warm-up launches, 3 timed
+                    if (rep == 2) hipEventRecord(e0, (hipStream_t)stream);
+                    ok = hipblasLtMatmul(handle, p.desc, alpha_, w, p.A, x, p.B, beta_, c_, p.C, out, p.D, &hr[i].algo,
+                                         workspace, (size_t)workspace_bytes, (hipStream_t)stream) == HIPBLAS_STATUS_SUCCESS;
+                }
+                hipEventRecord(e1, (hipStream_t)stream);
+                if (hipEventSynchronize(e1) != hipSuccess || !ok) continue;
+                float ms = 0.f;
+                hipEventElapsedTime(&ms, e0, e1);
+                if (ms < best_ms) {
+                    best_ms = ms;
+                    best = i;
+                }
+            }
+            hipEventDestroy(e0);
+            hipEventDestroy(e1);
+        }
+        p.algo = hr[best].algo;
+        p.workspace = hr[best].workspaceSize;
         it = g_plans.emplace(key, p).first;
     }
     Plan& p = it->second;

@@ -87,12 +87,16 @@ class MLP(nn.Module):
         return self.fc2(self.hidden(x))
 
 
+FUSE_GATE_RESIDUAL = os.environ.get("JENGA_FUSE_GATE", "1") != "0"
+SPLIT_LINEAR1 = os.environ.get("JENGA_SPLIT_LINEAR1", "1") != "0"
+
+
 def linear_gate_residual(lin, x, gate, res, gate2=None, mask=None):
     """res + apply_gate(lin(x), gate) (models_mul...:297-315, 500).  Without a token mask the gate multiply and the
     residual add ride in the GEMM's epilogue (jenga_linear: per-channel gate = alpha vector, residual = C matrix; the
     bias is pre-multiplied by the gate): one pass over the output instead of three.  With the I2V token_replace mask
     (rows choose between two gates) the separate kernel stays."""
-    if mask is not None or not x.is_cuda:
+    if mask is not None or not x.is_cuda or not FUSE_GATE_RESIDUAL:
         return _capi.gate_residual(res, lin(x), gate, gate2=gate2, mask=mask)
     g = gate.reshape(-1)
     bias = None if lin.bias is None else lin.bias * g.to(lin.bias.dtype)
@@ -297,10 +301,15 @@ class MMSingleStreamBlock(nn.Module):
         # linear1 as two GEMMs over the same input: the QKV half plain, the MLP half with the tanh-GELU in its epilogue
         # and linear2's concat buffer as its (strided) destination -- no separate 5.7 GB activation pass, no copy
         xm = _capi.ln_modulate(x, mod_shift, mod_scale, shift2=tr[0], scale2=tr[1], mask=fm)
-        w1, b1 = self.linear1.weight, self.linear1.bias
-        qkv = F.linear(xm, w1[: 3 * C], None if b1 is None else b1[: 3 * C]).unflatten(-1, (3, H, 128))
         cat = torch.empty((B, S, C + self.mlp_hidden_dim), dtype=x.dtype, device=x.device)
-        _capi.linear(xm, w1[3 * C:], None if b1 is None else b1[3 * C:], act=_capi.ACT_GELU_TANH, out=cat[..., C:])
+        if SPLIT_LINEAR1:
+            w1, b1 = self.linear1.weight, self.linear1.bias
+            qkv = F.linear(xm, w1[: 3 * C], None if b1 is None else b1[: 3 * C]).unflatten(-1, (3, H, 128))
+            _capi.linear(xm, w1[3 * C:], None if b1 is None else b1[3 * C:], act=_capi.ACT_GELU_TANH, out=cat[..., C:])
+        else:       # one GEMM, then the activation as a pass of its own (strided source and destination)
+            lin1 = self.linear1(xm)
+            qkv = lin1[..., : 3 * C].unflatten(-1, (3, H, 128))
+            _capi.gelu_tanh(lin1[..., 3 * C:], out=cat[..., C:])
         cos, sin = freqs_cis
         block_neighbor_list = curve_sel[0][2] if curve_sel is not None else None
         top_k = _select_top_k(sa_drop_rate, S_img // per_block_token)

@@ -136,4 +136,22 @@ G)
   run G_default --no-cpu-baseline --no-dense-ref
   run G_sim8 --simulate-ranks 8 --steps 3 --no-cpu-baseline --no-dense-ref
   ;;
+I)
+  # A/B in the loop: gate + residual in the GEMM epilogue vs the separate kernel; candidate timing at the 8-rank shapes
+  JENGA_FUSE_GATE=0 run I_n1_gate_unfused --no-cpu-baseline --no-dense-ref --steps 4
+  JENGA_FUSE_GATE=1 run I_n1_gate_fused --no-cpu-baseline --no-dense-ref --steps 4
+  JENGA_FUSE_GATE=0 run I_sim8_gate_unfused --simulate-ranks 8 --steps 3 --no-cpu-baseline --no-dense-ref
+  JENGA_FUSE_GATE=1 run I_sim8_gate_fused --simulate-ranks 8 --steps 3 --no-cpu-baseline --no-dense-ref
+  JENGA_FUSE_GATE=1 JENGA_GEMM_CANDIDATES=16 run I_sim8_gate_fused_k16 --simulate-ranks 8 --steps 3 --warmup 2 --no-cpu-baseline --no-dense-ref
+  ;;
+J)
+  # same-box A/B/C of the GEMM-epilogue changes (boxes differ by ~2 %: nothing else is comparable)
+  for rep in 1 2; do
+    JENGA_SPLIT_LINEAR1=0 JENGA_FUSE_GATE=0 run J_n1_00_$rep --no-cpu-baseline --no-dense-ref --steps 4
+    JENGA_SPLIT_LINEAR1=1 JENGA_FUSE_GATE=0 run J_n1_10_$rep --no-cpu-baseline --no-dense-ref --steps 4
+    JENGA_SPLIT_LINEAR1=1 JENGA_FUSE_GATE=1 run J_n1_11_$rep --no-cpu-baseline --no-dense-ref --steps 4
+  done
+  JENGA_SPLIT_LINEAR1=0 JENGA_FUSE_GATE=0 run J_sim8_00 --simulate-ranks 8 --steps 3 --no-cpu-baseline --no-dense-ref
+  JENGA_SPLIT_LINEAR1=1 JENGA_FUSE_GATE=0 run J_sim8_10 --simulate-ranks 8 --steps 3 --no-cpu-baseline --no-dense-ref
+  ;;
 esac
