@@ -154,4 +154,15 @@ J)
   JENGA_SPLIT_LINEAR1=0 JENGA_FUSE_GATE=0 run J_sim8_00 --simulate-ranks 8 --steps 3 --no-cpu-baseline --no-dense-ref
   JENGA_SPLIT_LINEAR1=1 JENGA_FUSE_GATE=0 run J_sim8_10 --simulate-ranks 8 --steps 3 --no-cpu-baseline --no-dense-ref
   ;;
+L)
+  # closing records at HEAD
+  timeout 1500 python -m pytest tests -q -m gpu > $O/L_suite.log 2>&1; tail -3 $O/L_suite.log
+  bash tools/prof_bench.sh r03_default --no-cpu-baseline --no-dense-ref > $O/L_prof.log 2>&1; head -14 gpurun_out/prof_r03_default/kernel_stats.csv | cut -c1-170
+  run L_default
+  run L_full50 --steps 50 --warmup 1 --no-cpu-baseline --no-dense-ref
+  run L_sim8_base --simulate-ranks 8 --steps 3 --no-cpu-baseline
+  run L_sim8_turbo --simulate-ranks 8 --preset turbo-mgpu --steps 3 --no-cpu-baseline --no-dense-ref
+  run L_turbo --preset turbo --no-cpu-baseline --no-dense-ref
+  run L_3stage --preset 3stage --no-cpu-baseline --no-dense-ref
+  ;;
 esac
