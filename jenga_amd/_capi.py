@@ -607,7 +607,9 @@ def bsattn_fwd(q, k, vt, seqlens, idx, cnt, nq_img, sm_scale, text_amp, text_blo
         if order is not None:
             order_t = order
         elif (fl & ATTN_SORTED) and nq_img > 0 and (fl & ATTN_LP) and not pair:
-            order_t = order_by_count(cnt, (nq_img + 7) // 8 if ((fl & ATTN_XCD_REMAP) and nq_img >= 64) else nq_img)
+            seg = (nq_img + 7) // 8 if ((fl & ATTN_XCD_REMAP) and nq_img >= 64) else nq_img
+            if seg <= 2048:      # (jenga_order_by_count ranks one segment per workgroup; beyond that: plain order)
+                order_t = order_by_count(cnt, seg)
         if order_t is not None and (tuple(order_t.shape) != (B, H, nq_img) or order_t.dtype != torch.int32
                                     or not order_t.is_contiguous() or order_t.device != q.device):
             raise ValueError("bsattn_fwd: order must be a contiguous int32 [B,H,nq_img] tensor on the device")

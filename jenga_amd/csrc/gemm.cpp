@@ -126,7 +126,7 @@ extern "C" int jenga_linear(void* stream, const void* x, const void* w, const vo
             return JENGA_EUNSUPPORTED;
         }
         int best = 0;
-        if (found > 1) {
+        if (found > 1 && res != out) {   // (in place, every extra launch would add the residual once more)
             const float one_ = 1.0f, zero_ = 0.0f;
             const void* alpha_ = gate ? (const void*)gate : (const void*)&one_;
             const float* beta_ = res ? &one_ : &zero_;
