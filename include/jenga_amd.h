@@ -82,6 +82,15 @@ int jenga_rmsnorm_rows(void* stream, const void* x, void* out, const void* weigh
 int jenga_rope_complex(void* stream, const void* x, void* out, const double* cos, const double* sin, int64_t B,
                        int64_t S, int64_t H, int64_t x_sb, int64_t x_ss, int64_t x_sh, int64_t o_sb, int64_t o_ss,
                        int64_t o_sh, int64_t s_rope, int in_dtype, int out_dtype);
+/* jenga_wan_norm_rope (round 3): the two above in ONE pass for the self-attention's q / k (model_mul.py:146-151 +
+ *   the bf16 cast of the attention op): WanRMSNorm with its fp32 weight over the full width C, the float64 RoPE on rows
+ *   < s_rope (tables [rows, 64], head_dim 128), one rounding to bf16 -- bit-identical to jenga_rmsnorm_rows
+ *   (weight_fp32) followed by jenga_rope_complex (fp32 in, bf16 out), without the two fp32 tensors in between.  The output
+ *   row stride lets the rows land in a buffer padded to a multiple of 128 tokens (the op's zero padding,
+ *   wan/modules/attention_block_triton_diffres.py:448-451).  cos == sin == NULL: norm + cast only (cross-attention q). */
+int jenga_wan_norm_rope(void* stream, const void* x, void* out, const float* weight, const double* cos,
+                        const double* sin, int64_t rows, int64_t C, int64_t x_row_stride, int64_t o_row_stride,
+                        int64_t s_rope, float eps, int dtype);
 
 /* DiT block glue around the GEMMs: fused replacements of eager elementwise chains.
  * jenga_ln_modulate: modulate(LayerNorm(x), shift, scale) = LN(x)*(1+scale)+shift

@@ -36,6 +36,7 @@ SIGNATURES = {
     "jenga_rmsnorm_rope": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp] + [_i64] * 10 + [_f32, _i32]),
     "jenga_rmsnorm_rows": (_i32, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _f32, _i32, _i32]),
     "jenga_rope_complex": (_i32, [_vp, _vp, _vp, _vp, _vp] + [_i64] * 10 + [_i32, _i32]),
+    "jenga_wan_norm_rope": (_i32, [_vp] * 5 + [_i64] * 5 + [_f32, _i32]),
     "jenga_ln_modulate": (_i32, [_vp] * 8 + [_i64] * 4 + [_f32, _i32]),
     "jenga_gate_residual": (_i32, [_vp] * 7 + [_i64] * 5 + [_i32]),
     "jenga_gelu_tanh": (_i32, [_vp, _vp, _vp] + [_i64] * 4 + [_i32]),
@@ -356,6 +357,35 @@ def rope_complex(x, cos64, sin64, s_rope, out_dtype=torch.float32):
         _check(lib().jenga_rope_complex(_stream(x.device), _p(x), _p(out), _p(cos64.contiguous()),
                                         _p(sin64.contiguous()), B, S, H, *_bshd_strides(x), *_bshd_strides(out),
                                         int(s_rope), codes[x.dtype], codes[out_dtype]), "jenga_rope_complex")
+    return out
+
+
+def wan_norm_rope(x, weight, cos64, sin64, s_rope, eps, out=None):
+    """Wan q / k prologue in one pass: x [..., C] (bf16/fp16, uniform row stride) -> bf16 [..., C] = bf16( rope64(
+    round(x * rsqrt(mean x^2 + eps)) * weight_fp32 ) ); cos64/sin64 float64 [>= s_rope, 64] or None (norm + cast only).
+    `out` may be the first rows of a larger (block-padded) buffer."""
+    _need_gpu(x, "wan_norm_rope")
+    C = x.shape[-1]
+    x2 = x.reshape(-1, C)
+    if x2.stride(-1) != 1:
+        x2 = x2.contiguous()
+    rows = x2.shape[0]
+    w = weight.to(device=x.device, dtype=torch.float32).contiguous()
+    if out is None:
+        out = torch.empty(tuple(x.shape[:-1]) + (C,), dtype=torch.bfloat16, device=x.device)
+    o2 = out.reshape(-1, C) if out.is_contiguous() else out
+    if o2.dim() != 2 or o2.shape[0] < rows or o2.stride(1) != 1 or out.dtype != torch.bfloat16:
+        raise ValueError("wan_norm_rope: out must be bf16 [>= rows, C] with contiguous channels")
+    if cos64 is not None:
+        if cos64.dtype != torch.float64 or sin64.dtype != torch.float64 or cos64.shape[-1] != 64 or cos64.shape[0] < s_rope:
+            raise ValueError("wan_norm_rope: float64 [S,64] tables required")
+        cos64, sin64 = cos64.contiguous(), sin64.contiguous()
+    else:
+        s_rope = 0
+    with torch.cuda.device(x.device):
+        _check(lib().jenga_wan_norm_rope(_stream(x.device), _p(x2), _p(o2), _p(w), _p(cos64), _p(sin64), rows, C,
+                                         x2.stride(0), o2.stride(0), int(s_rope), float(eps), dtype_code(x.dtype)),
+               "jenga_wan_norm_rope")
     return out
 
 

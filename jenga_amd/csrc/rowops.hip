@@ -685,6 +685,62 @@ __global__ void __launch_bounds__(256) rmsnorm_rows_kernel(const uint16_t* __res
     }
 }
 
+// Wan self-attention prologue in one pass (wan/modules/model_mul.py:146-151 + the bf16 cast of the attention op,
+// wan/modules/attention_block_triton_diffres.py:456-463): WanRMSNorm over the full model width (fp32 weight, so the
+// reference's product is fp32), then the float64 complex RoPE on tokens < s_rope, then ONE cast to bf16 -- exactly the
+// arithmetic of rmsnorm_rows_kernel<T, true> followed by rope_complex_kernel<2, 0>, without the two fp32 tensors in
+// between (4.6 GB per tensor and layer at the Wan2.1-14B 720p shape).  cosT == nullptr: norm + cast only (the
+// cross-attention's q).  One workgroup per token row; C % 8 == 0, C <= 8192; head_dim 128 (the table has 64 columns).
+template <typename T>
+__global__ void __launch_bounds__(256) wan_norm_rope_kernel(const uint16_t* __restrict__ x, uint16_t* __restrict__ out,
+                                                            const float* __restrict__ weight,
+                                                            const double* __restrict__ cosT,
+                                                            const double* __restrict__ sinT, long long rows, int C,
+                                                            long long x_rs, long long o_rs, long long s_rope, float eps) {
+    __shared__ float red[4];
+    for (long long row = blockIdx.x; row < rows; row += gridDim.x) {
+        const uint16_t* xr = x + row * x_rs;
+        float f[4][8];
+        float ss = 0.f;
+        int nv = 0;
+        for (int c = threadIdx.x * 8; c < C; c += 256 * 8, ++nv) {
+            unpack8<T>(*reinterpret_cast<const uint4*>(xr + c), f[nv]);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) ss = __fadd_rn(ss, __fmul_rn(f[nv][e], f[nv][e]));
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = ss;
+        __syncthreads();
+        ss = (red[0] + red[1]) + (red[2] + red[3]);
+        __syncthreads();
+        const float r = __fdiv_rn(1.0f, __fsqrt_rn(__fadd_rn(__fdiv_rn(ss, (float)C), eps)));
+        const bool rope = cosT && row < s_rope;
+        nv = 0;
+        for (int c = threadIdx.x * 8; c < C; c += 256 * 8, ++nv) {
+            const float4* wp = reinterpret_cast<const float4*>(weight + c);
+            const float4 w0 = wp[0], w1 = wp[1];
+            const float wv[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+            float y[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) y[e] = __fmul_rn(round_to<T>(__fmul_rn(f[nv][e], r)), wv[e]);   // fp32 product
+            if (rope) {
+                const double* cp = cosT + row * 64 + ((c & 127) >> 1);
+                const double* sp = sinT + row * 64 + ((c & 127) >> 1);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const double a = (double)y[2 * j], bb = (double)y[2 * j + 1], cc = cp[j], d = sp[j];
+                    const double re = __dsub_rn(__dmul_rn(a, cc), __dmul_rn(bb, d));
+                    const double im = __dadd_rn(__dmul_rn(a, d), __dmul_rn(bb, cc));
+                    y[2 * j] = (float)re;
+                    y[2 * j + 1] = (float)im;
+                }
+            }
+            *reinterpret_cast<uint4*>(out + row * o_rs + c) = pack8<BF16>(y);
+        }
+    }
+}
+
 // fp64 complex RoPE (wan/modules/model_mul.py:40-71): pairs (x[2j], x[2j+1]) as complex, multiplied in float64 by
 // (cos, sin)[s][j] (tables already expanded per position, incl. the Hilbert freq_remap), rounded to fp32 (".float()")
 // or further to the storage dtype when the consumer is the bf16 attention op.  Tokens s >= s_rope pass through.
@@ -755,6 +811,33 @@ extern "C" int jenga_rmsnorm_rows(void* stream, const void* x, void* out, const 
     else { if (weight_fp32) LAUNCH_RR(FP16, true); else LAUNCH_RR(FP16, false); }
 #undef LAUNCH_RR
     JENGA_CHECK_LAUNCH("jenga_rmsnorm_rows");
+    return JENGA_OK;
+}
+
+extern "C" int jenga_wan_norm_rope(void* stream, const void* x, void* out, const float* weight, const double* cosT,
+                                   const double* sinT, int64_t rows, int64_t C, int64_t x_row_stride,
+                                   int64_t o_row_stride, int64_t s_rope, float eps, int dtype) {
+    if (!x || !out || !weight || rows < 0 || C <= 0 || (C & 7) || C > 8192 || (x_row_stride & 7) || (o_row_stride & 7) ||
+        ((uintptr_t)x & 15) || ((uintptr_t)out & 15) || ((uintptr_t)weight & 15) || ((cosT == nullptr) != (sinT == nullptr)) ||
+        s_rope < 0 || (cosT && (C & 127))) {
+        set_error("jenga_wan_norm_rope: bad arguments (C multiple of 8 -- of 128 with RoPE --, <= 8192)");
+        return JENGA_EINVAL;
+    }
+    if (dtype != JENGA_BF16 && dtype != JENGA_FP16) {
+        set_error("jenga_wan_norm_rope: dtype must be bf16 or fp16");
+        return JENGA_EUNSUPPORTED;
+    }
+    if (rows == 0) return JENGA_OK;
+    const int grid = grid_for(rows, 65536);
+    if (dtype == JENGA_BF16)
+        hipLaunchKernelGGL(wan_norm_rope_kernel<BF16>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)x,
+                           (uint16_t*)out, weight, cosT, sinT, (long long)rows, (int)C, (long long)x_row_stride,
+                           (long long)o_row_stride, (long long)s_rope, eps);
+    else
+        hipLaunchKernelGGL(wan_norm_rope_kernel<FP16>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)x,
+                           (uint16_t*)out, weight, cosT, sinT, (long long)rows, (int)C, (long long)x_row_stride,
+                           (long long)o_row_stride, (long long)s_rope, eps);
+    JENGA_CHECK_LAUNCH("jenga_wan_norm_rope");
     return JENGA_OK;
 }
 

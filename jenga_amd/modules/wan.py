@@ -42,20 +42,27 @@ def expand_freqs(freqs, grid, freq_remap=None):
     return fi.real.contiguous(), fi.imag.contiguous()
 
 
-def rope_apply(x, grid_sizes, freqs, freq_remap=None, out_dtype=torch.float32, _cache={}):
-    """x [B,S,N,128]; grid_sizes [B,3]; freqs complex128 [1024,64] -> float32 [B,S,N,128] (the reference returns
-    `.float()`); out_dtype=torch.bfloat16 fuses the cast the Wan attention op applies next."""
+def rope_tables(grid_sizes, freqs, freq_remap, device, _cache={}):
+    """-> (cos, sin float64 [f*h*w, 64] on the device, f*h*w) for the batch's common (f, h, w) grid; built once per
+    resolution (static geometry) and kept."""
     grids = grid_sizes.tolist() if torch.is_tensor(grid_sizes) else list(grid_sizes)
     if len({tuple(g) for g in grids}) != 1:
         raise ValueError("jenga_amd rope_apply: all samples of the batch must share one (f,h,w) grid")
     f, h, w = grids[0]
-    key = (f, h, w, x.device, None if freq_remap is None else freq_remap.data_ptr(), freqs.data_ptr())
+    key = (f, h, w, device, None if freq_remap is None else freq_remap.data_ptr(), freqs.data_ptr())
     if key not in _cache:
         cos, sin = expand_freqs(freqs, (f, h, w), freq_remap)
         _cache.clear()
-        _cache[key] = (cos.to(x.device), sin.to(x.device))
+        _cache[key] = (cos.to(device), sin.to(device))
     cos, sin = _cache[key]
-    return _capi.rope_complex(x, cos, sin, f * h * w, out_dtype=out_dtype)
+    return cos, sin, f * h * w
+
+
+def rope_apply(x, grid_sizes, freqs, freq_remap=None, out_dtype=torch.float32):
+    """x [B,S,N,128]; grid_sizes [B,3]; freqs complex128 [1024,64] -> float32 [B,S,N,128] (the reference returns
+    `.float()`); out_dtype=torch.bfloat16 fuses the cast the Wan attention op applies next."""
+    cos, sin, n_rope = rope_tables(grid_sizes, freqs, freq_remap, x.device)
+    return _capi.rope_complex(x, cos, sin, n_rope, out_dtype=out_dtype)
 
 
 class WanRMSNorm(nn.Module):
@@ -88,6 +95,41 @@ class WanSelfAttention(nn.Module):
     def forward(self, x, seq_lens, grid_sizes, freqs, sa_drop_rate=0.0, per_block_tokens=128, p_remain_rates=0.8,
                 freq_remap=None, block_neighbor_list=None):
         b, s, n, d = *x.shape[:2], self.num_heads, self.head_dim
+        num_blocks = math.ceil(s / per_block_tokens)
+        dense = sa_drop_rate <= 0.25
+        if dense:
+            # dense: every block kept (flash_attention with k_lens = seq_lens masks keys >= seq_len, :153-159)
+            top_k, ffb = num_blocks, 0
+        else:
+            top_k = math.ceil(int(num_blocks * (1 - sa_drop_rate)))
+            ffb = math.ceil(num_blocks // 21)
+        nbm = None if dense else block_neighbor_list
+        p = 2.0 if dense else p_remain_rates
+        if x.is_cuda and b == 1 and d == 128 and per_block_tokens == 128 and isinstance(self.norm_q, WanRMSNorm) \
+                and x.dtype in (torch.bfloat16, torch.float16):
+            # one pass per tensor: WanRMSNorm (fp32 weight) + float64 RoPE + the op's bf16 cast, written straight into
+            # buffers padded to whole 128-token blocks (the op's zero padding, ...diffres.py:448-451) -- no fp32
+            # intermediates, no pad copies; V's GEMM writes into its padded buffer as well
+            S_pad = num_blocks * 128
+            cos, sin, n_rope = rope_tables(grid_sizes, freqs, freq_remap, x.device)
+            qkv = torch.empty((3, 1, S_pad, self.dim), dtype=torch.bfloat16, device=x.device)
+            if S_pad > s:
+                qkv[:, :, s:].zero_()
+            _capi.wan_norm_rope(self.q(x), self.norm_q.weight, cos, sin, min(n_rope, s), self.eps, out=qkv[0, 0])
+            _capi.wan_norm_rope(self.k(x), self.norm_k.weight, cos, sin, min(n_rope, s), self.eps, out=qkv[1, 0])
+            if x.dtype == torch.bfloat16:
+                torch.addmm(self.v.bias, x[0], self.v.weight.t(), out=qkv[2, 0, :s])
+            else:
+                qkv[2, 0, :s] = self.v(x)[0].to(torch.bfloat16)
+            if dense:
+                seqlens = torch.clamp(seq_lens.to(device=x.device, dtype=torch.int32).reshape(-1), max=s)
+            else:
+                seqlens = torch.full((1,), s, dtype=torch.int32, device=x.device)
+            q4, k4, v4 = (qkv[i].view(1, S_pad, n, d) for i in range(3))
+            out = _op._combined(q4, k4, v4, top_k, seqlens, 0, 0.0, p, nbm, False, first_frame_blocks=ffb,
+                                context_size=s)
+            return self.o(out.to(x.dtype))
+        # general path (any batch / head_dim the kernels take): the separate kernels and the padding op
         q = self.norm_q(self.q(x)).view(b, s, n, d)
         k = self.norm_k(self.k(x)).view(b, s, n, d)
         v = self.v(x).view(b, s, n, d)
@@ -95,17 +137,7 @@ class WanSelfAttention(nn.Module):
         # (attention_block_triton_diffres.py:456-463 / flash_attention's half()): fuse that cast into the kernel.
         qr = rope_apply(q, grid_sizes, freqs, freq_remap, out_dtype=torch.bfloat16)
         kr = rope_apply(k, grid_sizes, freqs, freq_remap, out_dtype=torch.bfloat16)
-        num_blocks = math.ceil(x.shape[1] / per_block_tokens)
-        if sa_drop_rate <= 0.25:
-            # dense: every block kept (flash_attention with k_lens = seq_lens masks keys >= seq_len, :153-159)
-            top_k, ffb = num_blocks, 0
-        else:
-            top_k = math.ceil(int(num_blocks * (1 - sa_drop_rate)))
-            ffb = math.ceil(num_blocks // 21)
-        dense = sa_drop_rate <= 0.25
         out = _op.block_sparse_attention_wan(qr, kr, v.to(torch.bfloat16), top_k, text_blocks=0,
-                                             block_neighbor_list=None if dense else block_neighbor_list,
-                                             p_remain_rates=2.0 if dense else p_remain_rates,
-                                             first_frame_blocks=ffb,
+                                             block_neighbor_list=nbm, p_remain_rates=p, first_frame_blocks=ffb,
                                              kv_lens=seq_lens if dense else None)   # k_lens mask: dense branch only
         return self.o(out.to(x.dtype).flatten(2))

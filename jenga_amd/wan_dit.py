@@ -62,7 +62,11 @@ class WanT2VCrossAttention(nn.Module):
         b, n, d = x.shape[0], self.num_heads, self.head_dim
         v = self.v(context).view(b, -1, n, d).transpose(1, 2)
         # WanRMSNorm with its fp32 weight returns fp32; flash_attention's half() rounds q, k to the 16-bit dtype
-        q = self.norm_q(self.q(x)).to(v.dtype).view(b, -1, n, d).transpose(1, 2)
+        if x.is_cuda and v.dtype == torch.bfloat16:      # norm (fp32 weight) + the cast in one pass, same arithmetic
+            q = _capi.wan_norm_rope(self.q(x), self.norm_q.weight, None, None, 0, self.norm_q.eps)
+            q = q.view(b, -1, n, d).transpose(1, 2)
+        else:
+            q = self.norm_q(self.q(x)).to(v.dtype).view(b, -1, n, d).transpose(1, 2)
         k = self.norm_k(self.k(context)).to(v.dtype).view(b, -1, n, d).transpose(1, 2)
         o = F.scaled_dot_product_attention(q, k, v)          # softmax scale d^-0.5, no mask: flash_attention(k_lens=None)
         return self.o(o.transpose(1, 2).flatten(2))
@@ -106,7 +110,10 @@ class WanAttentionBlock(nn.Module):
         _capi.wan_gate_residual(x, self.cross_attn(h, context, context_lens), None, out=x)
         # ffn: y = ffn(norm2(x) * (1 + e4) + e3);  x = x + y * e5
         h = _capi.wan_ln_modulate(x, shift=em[:, 3], scale=em[:, 4], eps=self.eps)
-        y = self.ffn[2](_capi.gelu_tanh(self.ffn[0](h)))
+        # ffn: Linear -> tanh-GELU as the GEMM's epilogue (one pass less over the [L, ffn_dim] activations) -> Linear
+        hh = torch._addmm_activation(self.ffn[0].bias, h[0], self.ffn[0].weight.t(), use_gelu=True).unsqueeze(0) \
+            if h.is_cuda else _capi.gelu_tanh(self.ffn[0](h))
+        y = self.ffn[2](hh)
         _capi.wan_gate_residual(x, y, em[:, 5], out=x)
         return x
 

@@ -59,6 +59,29 @@ def test_wan_glue_kernels_vs_oracle(dev, C, rows):
     assert np.array_equal(x2.cpu().numpy(), ow.gate_residual(x.numpy(), to_np(y)))
 
 
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("C,rows,s_rope", [(1536, 300, 300), (5120, 130, 100), (256, 77, 77)])
+def test_wan_norm_rope_equals_rmsnorm_rows_plus_rope_complex(dev, dt, C, rows, s_rope):
+    """jenga_wan_norm_rope (one pass: WanRMSNorm with its fp32 weight + float64 RoPE + bf16 cast, into a block-padded
+    buffer) against the two kernels it replaces -- jenga_rmsnorm_rows (fp32 out) + jenga_rope_complex (fp32 in, bf16
+    out), themselves pinned to the reference goldens -- bit for bit; without tables: norm + cast."""
+    from jenga_amd import _capi
+    g = torch.Generator(device=dev).manual_seed(C + rows)
+    x = (torch.randn(1, rows, C + 64, generator=g, device=dev) * 2).to(dt)[..., :C]           # strided rows
+    w = 1 + 0.1 * torch.randn(C, generator=g, device=dev)
+    H = C // 128
+    ang = torch.randn(s_rope, 64, generator=g, device=dev, dtype=torch.float64)
+    cos, sin = ang.cos(), ang.sin()
+    ref = _capi.rope_complex(_capi.rmsnorm_rows(x, w, 1e-6).view(1, rows, H, 128), cos, sin, s_rope,
+                             out_dtype=torch.bfloat16).view(1, rows, C)
+    pad = torch.full((rows + 51, C), 5.0, dtype=torch.bfloat16, device=dev)                    # rows land in its prefix
+    _capi.wan_norm_rope(x, w, cos, sin, s_rope, 1e-6, out=pad)
+    torch.cuda.synchronize()
+    assert torch.equal(pad[:rows], ref[0]) and bool((pad[rows:] == 5.0).all())
+    plain = _capi.wan_norm_rope(x, w, None, None, 0, 1e-6)
+    assert torch.equal(plain, _capi.rmsnorm_rows(x, w, 1e-6).to(torch.bfloat16))
+
+
 def _block(dev):
     from jenga_amd.wan_dit import WanAttentionBlock
     from jenga_amd.modules.wan import wan_freqs

@@ -165,4 +165,9 @@ L)
   run L_turbo --preset turbo --no-cpu-baseline --no-dense-ref
   run L_3stage --preset 3stage --no-cpu-baseline --no-dense-ref
   ;;
+W)
+  # Wan path: fused q/k prologue + cross-attention q cast + ffn GELU epilogue: tests, then the 14B forward
+  timeout 900 python -m pytest tests/test_gpu_wan_dit.py tests/test_gpu_dit.py -q -m gpu > $O/W_tests.log 2>&1; tail -5 $O/W_tests.log
+  timeout 600 python tools/bench_wan.py --qk-gain 4 > $O/W_wan14b_gain4.json 2> $O/W_wan14b_gain4.err; tail -c 500 $O/W_wan14b_gain4.json
+  ;;
 esac
