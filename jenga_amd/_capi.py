@@ -36,7 +36,7 @@ SIGNATURES = {
     "jenga_rmsnorm_rope": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp] + [_i64] * 10 + [_f32, _i32]),
     "jenga_rmsnorm_rows": (_i32, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _f32, _i32, _i32]),
     "jenga_rope_complex": (_i32, [_vp, _vp, _vp, _vp, _vp] + [_i64] * 10 + [_i32, _i32]),
-    "jenga_wan_norm_rope": (_i32, [_vp] * 5 + [_i64] * 5 + [_f32, _i32]),
+    "jenga_wan_norm_rope": (_i32, [_vp] * 6 + [_i64] * 5 + [_f32, _i32]),
     "jenga_ln_modulate": (_i32, [_vp] * 8 + [_i64] * 4 + [_f32, _i32]),
     "jenga_gate_residual": (_i32, [_vp] * 7 + [_i64] * 5 + [_i32]),
     "jenga_gelu_tanh": (_i32, [_vp, _vp, _vp] + [_i64] * 4 + [_i32]),

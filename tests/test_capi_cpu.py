@@ -98,3 +98,31 @@ def test_header_is_c99_and_library_links_from_plain_c(tmp_path):
     assert r.returncode == 0, r.stderr
     r = subprocess.run([exe], capture_output=True, text=True)
     assert r.returncode == 0 and r.stdout.startswith("ok abi="), (r.returncode, r.stdout, r.stderr)
+
+
+def test_ctypes_signatures_match_the_header_parameter_by_parameter():
+    """Every entry of _capi.SIGNATURES against the C declaration in include/jenga_amd.h: same number of parameters and
+    the same kind at every position (pointer / int64_t / int / float / size_t) -- a wrong ctypes signature shows up
+    here, on the CPU, instead of as an ArgumentError on the GPU box."""
+    import ctypes
+    header = open(os.path.join(ROOT, "include", "jenga_amd.h")).read()
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    kinds = {ctypes.c_void_p: "ptr", ctypes.c_char_p: "ptr", ctypes.c_int64: "i64", ctypes.c_int: "int",
+             ctypes.c_float: "float", ctypes.c_size_t: "size"}
+
+    def kind_of(param):
+        param = param.strip()
+        if "*" in param:
+            return "ptr"
+        t = param.rsplit(" ", 1)[0].replace("const", "").strip()
+        return {"int64_t": "i64", "int": "int", "float": "float", "size_t": "size"}[t]
+
+    sigs = dict(_capi.SIGNATURES)
+    sigs.update(_capi.EXPERIMENT_SIGNATURES)
+    for name, (_res, args) in sigs.items():
+        m = re.search(r"\b(?:int|size_t|const char\s*\*)\s*" + name + r"\s*\(([^;]*?)\)\s*;", header, re.S)
+        assert m, f"{name}: declaration not found"
+        params = [p_ for p_ in m.group(1).split(",") if p_.strip() and p_.strip() != "void"]
+        assert len(params) == len(args), f"{name}: header has {len(params)} parameters, ctypes {len(args)}"
+        for i, (p_, a_) in enumerate(zip(params, args)):
+            assert kind_of(p_) == kinds[a_], f"{name}: parameter {i} ({p_.strip()!r}) bound as {a_.__name__}"
