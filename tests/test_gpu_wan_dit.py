@@ -104,7 +104,8 @@ def test_wan_block_vs_reference_block(dev):
     cap = {}
     blk.self_attn.register_forward_hook(lambda m, a, o: cap.update(h1=a[0].clone(), y1=o.clone()))
     blk.cross_attn.register_forward_hook(lambda m, a, o: cap.update(h3=a[0].clone(), y3=o.clone()))
-    blk.ffn[0].register_forward_hook(lambda m, a, o: cap.update(h2=a[0].clone()))
+    ffn_hidden = blk.ffn_hidden          # (ffn[0] runs as a GEMM + GELU epilogue: capture its input at the method)
+    blk.ffn_hidden = lambda h_: (cap.update(h2=h_.clone()), ffn_hidden(h_))[1]
     kw = dict(seq_lens=torch.tensor([f * h * w]), grid_sizes=torch.tensor([[f, h, w]]), freqs=freqs,
               context=inp["context"].to(dev), context_lens=None, sa_drop_rate=0.0, freq_remap=inp["remap"].to(dev),
               block_neighbor_list=None, p_remain_rates=0.8)
