@@ -405,6 +405,67 @@ __global__ void __launch_bounds__(256) wan_ln_modulate_kernel(const float* __res
     }
 }
 
+// Wave-per-row form of wan_ln_modulate_kernel for widths C = 256 * NV (1536 -> NV 6, 5120 -> NV 20; round 3): a lane
+// keeps its NV float4 of the row in registers, both statistics passes are wave shuffles, no barrier, four rows per
+// workgroup in flight.  The block-per-row kernel above (two block-wide reductions per row) ran at 1.4 TB/s at C = 5120.
+template <typename T, int NV, bool AFFINE, bool MOD>
+__global__ void __launch_bounds__(256) wan_ln_modulate_wave_kernel(const float* __restrict__ x, uint16_t* __restrict__ y,
+                                                                   const float* __restrict__ w,
+                                                                   const float* __restrict__ b,
+                                                                   const float* __restrict__ shift,
+                                                                   const float* __restrict__ scale, long long rows,
+                                                                   long long x_rs, long long y_rs, float eps,
+                                                                   int round_ln) {
+    constexpr int C = NV * 256;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (long long row = (long long)blockIdx.x * 4 + wave; row < rows; row += (long long)gridDim.x * 4) {
+        const float4* xr = reinterpret_cast<const float4*>(x + row * x_rs) + lane;
+        float4 f[NV];
+#pragma unroll
+        for (int i = 0; i < NV; ++i) f[i] = xr[64 * i];
+        float s1 = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) s1 += (f[i].x + f[i].y) + (f[i].z + f[i].w);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) s1 += __shfl_xor(s1, o);
+        const float mean = s1 / (float)C;
+        float s2 = 0.f;   // two-pass variance (see the block-per-row kernel)
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const float d0 = f[i].x - mean, d1 = f[i].y - mean, d2 = f[i].z - mean, d3 = f[i].w - mean;
+            s2 += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) s2 += __shfl_xor(s2, o);
+        const float rstd = 1.0f / sqrtf(s2 / (float)C + eps);
+        uint16_t* yr = y + row * y_rs + lane * 4;
+        // the parameter vectors depend on the column only: branch-free loads (template flags), four chunks in flight
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = (lane + 64 * i) * 4;
+            float o[4] = {(f[i].x - mean) * rstd, (f[i].y - mean) * rstd, (f[i].z - mean) * rstd, (f[i].w - mean) * rstd};
+            if (AFFINE) {
+                const float4 wv = *reinterpret_cast<const float4*>(w + c), bv = *reinterpret_cast<const float4*>(b + c);
+                o[0] = o[0] * wv.x + bv.x; o[1] = o[1] * wv.y + bv.y; o[2] = o[2] * wv.z + bv.z; o[3] = o[3] * wv.w + bv.w;
+            }
+            if (round_ln) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = round_to<T>(o[e]);
+            }
+            if (MOD) {
+                const float4 sc = *reinterpret_cast<const float4*>(scale + c), sh = *reinterpret_cast<const float4*>(shift + c);
+                o[0] = o[0] * (1.0f + sc.x) + sh.x; o[1] = o[1] * (1.0f + sc.y) + sh.y;
+                o[2] = o[2] * (1.0f + sc.z) + sh.z; o[3] = o[3] * (1.0f + sc.w) + sh.w;
+            }
+            uint2 pk;
+            pk.x = pack2<T>(o[0], o[1]);
+            pk.y = pack2<T>(o[2], o[3]);
+            *reinterpret_cast<uint2*>(yr + 256 * i) = pk;
+            if ((i & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+}
+
 // out = x + float(y) [* gate]   (x, out fp32; y 16-bit; gate fp32 [C] or null)
 template <typename T>
 __global__ void wan_gate_residual_kernel(const float* x, const uint16_t* __restrict__ y,
@@ -421,8 +482,13 @@ __global__ void wan_gate_residual_kernel(const float* x, const uint16_t* __restr
         const float4 a0 = *reinterpret_cast<const float4*>(x + row * x_rs + c);
         const float4 a1 = *reinterpret_cast<const float4*>(x + row * x_rs + c + 4);
         float a[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+        float gv[8] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f};
+        if (gate) {
+            const float4 g0 = *reinterpret_cast<const float4*>(gate + c), g1 = *reinterpret_cast<const float4*>(gate + c + 4);
+            gv[0] = g0.x; gv[1] = g0.y; gv[2] = g0.z; gv[3] = g0.w; gv[4] = g1.x; gv[5] = g1.y; gv[6] = g1.z; gv[7] = g1.w;
+        }
 #pragma unroll
-        for (int e = 0; e < 8; ++e) a[e] = a[e] + (gate ? yv[e] * gate[c + e] : yv[e]);
+        for (int e = 0; e < 8; ++e) a[e] = a[e] + (gate ? yv[e] * gv[e] : yv[e]);
         *reinterpret_cast<float4*>(out + row * o_rs + c) = make_float4(a[0], a[1], a[2], a[3]);
         *reinterpret_cast<float4*>(out + row * o_rs + c + 4) = make_float4(a[4], a[5], a[6], a[7]);
     }
@@ -1073,7 +1139,24 @@ extern "C" int jenga_wan_ln_modulate(void* stream, const float* x, void* y, cons
     hipLaunchKernelGGL(wan_ln_modulate_kernel<T>, dim3(grid_for(rows, 65536)), dim3(256), 0, (hipStream_t)stream, \
                        x, (uint16_t*)y, weight, bias, shift, scale, (long long)rows, (int)C,                      \
                        (long long)x_row_stride, (long long)y_row_stride, eps, round_ln)
-    if (out_dtype == JENGA_BF16) LAUNCH_WLM(BF16); else LAUNCH_WLM(FP16);
+#define LAUNCH_WLMW(T, NV, A_, M_)                                                                               \
+    hipLaunchKernelGGL((wan_ln_modulate_wave_kernel<T, NV, A_, M_>), dim3(grid_for((rows + 3) / 4, 65536)),       \
+                       dim3(256), 0, (hipStream_t)stream, x, (uint16_t*)y, weight, bias, shift, scale,            \
+                       (long long)rows, (long long)x_row_stride, (long long)y_row_stride, eps, round_ln)
+#define LAUNCH_WLMW_T(T)                                                                                          \
+    do {                                                                                                          \
+        if (C == 5120) {                                                                                          \
+            if (weight && shift) LAUNCH_WLMW(T, 20, true, true); else if (weight) LAUNCH_WLMW(T, 20, true, false); \
+            else if (shift) LAUNCH_WLMW(T, 20, false, true); else LAUNCH_WLMW(T, 20, false, false);               \
+        } else {                                                                                                  \
+            if (weight && shift) LAUNCH_WLMW(T, 6, true, true); else if (weight) LAUNCH_WLMW(T, 6, true, false);   \
+            else if (shift) LAUNCH_WLMW(T, 6, false, true); else LAUNCH_WLMW(T, 6, false, false);                 \
+        }                                                                                                         \
+    } while (0)
+    if (C == 5120 || C == 1536) { if (out_dtype == JENGA_BF16) LAUNCH_WLMW_T(BF16); else LAUNCH_WLMW_T(FP16); }
+    else if (out_dtype == JENGA_BF16) LAUNCH_WLM(BF16); else LAUNCH_WLM(FP16);
+#undef LAUNCH_WLMW_T
+#undef LAUNCH_WLMW
 #undef LAUNCH_WLM
     JENGA_CHECK_LAUNCH("jenga_wan_ln_modulate");
     return JENGA_OK;
