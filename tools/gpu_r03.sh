@@ -170,4 +170,13 @@ W)
   timeout 900 python -m pytest tests/test_gpu_wan_dit.py tests/test_gpu_dit.py -q -m gpu > $O/W_tests.log 2>&1; tail -5 $O/W_tests.log
   timeout 600 python tools/bench_wan.py --qk-gain 4 > $O/W_wan14b_gain4.json 2> $O/W_wan14b_gain4.err; tail -c 500 $O/W_wan14b_gain4.json
   ;;
+Z)
+  # final: the whole suite at HEAD (product library, then the experiment kernels), Wan2.1-14B record + profile
+  timeout 1500 python -m pytest tests -q -m gpu > $O/Z_suite.log 2>&1; tail -3 $O/Z_suite.log
+  JENGA_LIB=$PWD/jenga_amd/libjenga_amd_exp.so timeout 900 python -m pytest tests/test_gpu_pair.py tests/test_gpu_parity.py -q -m gpu -k "pair or sparse_kernel_vs_oracle" > $O/Z_exp.log 2>&1; tail -2 $O/Z_exp.log
+  timeout 600 python tools/bench_wan.py --qk-gain 4 > $O/Z_wan14b_gain4.json 2> $O/Z_wan14b_gain4.err; tail -c 500 $O/Z_wan14b_gain4.json
+  timeout 600 python tools/bench_wan.py --task t2v-1.3B --size 832x480 --qk-gain 4 > $O/Z_wan1p3b.json 2> $O/Z_wan1p3b.err; tail -c 400 $O/Z_wan1p3b.json
+  bash tools/prof_wan.sh r03_wan8 --qk-gain 4 --layers 8 > $O/Z_prof_wan.log 2>&1
+  python __graft_entry__.py --smoke 2>&1 | tail -1
+  ;;
 esac
