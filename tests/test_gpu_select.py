@@ -210,8 +210,9 @@ def test_kept_count_rule_vs_device_cumsum_is_measured(dev):
     _record("cumsum_semantics.json", out)
 
 
-@pytest.mark.parametrize("H,nq,nimg", [(2, 900, 900), (2, 591, 591), (24, 64, 300), (1, 8, 900), (1, 2, 1500)])
-def test_device_scan_mode_equals_torch_device_cumsum(dev, H, nq, nimg):
+@pytest.mark.parametrize("H,nq,nimg,dt", [(2, 900, 900, "bfloat16"), (2, 591, 591, "bfloat16"), (24, 64, 300, "bfloat16"),
+                                          (1, 8, 900, "bfloat16"), (1, 2, 1500, "bfloat16"), (2, 300, 900, "float16")])
+def test_device_scan_mode_equals_torch_device_cumsum(dev, H, nq, nimg, dt):
     """JENGA_SELECT_DEVICE_SCAN: the kept-count rule with the semantics of torch.cumsum on a DEVICE bf16 tensor (what the
     reference as shipped runs, attention_block_triton_diffres.py:241-250), i.e. ATen's blocked Sklansky scan restated in
     block_select_kernel.  Checked against torch.cumsum itself on this GPU:
@@ -222,27 +223,28 @@ def test_device_scan_mode_equals_torch_device_cumsum(dev, H, nq, nimg):
     where torch's launcher picks 2 x 256- and 2 x 512-column chunks (the LDS path of the kernel)."""
     from jenga_amd import _capi
     from oracle import attention as oa
+    tdt = getattr(torch, dt)
     g = torch.Generator(device=dev).manual_seed(H * 7 + nq)
-    kpool = (torch.randn(1, H, nimg, 128, generator=g, device=dev) * 0.12).to(torch.bfloat16)
+    kpool = (torch.randn(1, H, nimg, 128, generator=g, device=dev) * 0.12).to(tdt)
     rec = {}
     for p in (0.3, 0.5, 0.8, 0.9):
         # ---- flat rows
-        q0 = torch.zeros(1, H, nq, 128, dtype=torch.bfloat16, device=dev)
+        q0 = torch.zeros(1, H, nq, 128, dtype=tdt, device=dev)
         _, _, cnt = _capi.block_select(q0, kpool, None, nimg, 0, 0, p, flags=_capi.SELECT_DEVICE_SCAN)
-        flat = torch.full((1, H, nq, nimg), 1.0 / nimg, device=dev).to(torch.bfloat16)
+        flat = torch.full((1, H, nq, nimg), 1.0 / nimg, device=dev).to(tdt)
         n_dev = ((torch.cumsum(flat, dim=-1) <= p).sum(-1) + 1).clamp(max=nimg)
         assert torch.equal(cnt.to(torch.int64), n_dev), (p, int((cnt - n_dev).abs().max()))
         # the default (CPU semantics) differs on such rows at large p -- that is the point of the flag
         _, _, cnt_cpu = _capi.block_select(q0, kpool, None, nimg, 0, 0, p)
         # ---- random rows
-        qpool = (torch.randn(1, H, nq, 128, generator=g, device=dev) * 0.12).to(torch.bfloat16)
+        qpool = (torch.randn(1, H, nq, 128, generator=g, device=dev) * 0.12).to(tdt)
         _, _, cnt_r = _capi.block_select(qpool, kpool, None, nimg, 0, 0, p, flags=_capi.SELECT_DEVICE_SCAN)
-        probs = oa.row_probs(oa.scores_from_pooled(to_np(qpool), to_np(kpool), "bfloat16"), "bfloat16")
-        sp, _ = torch.sort(torch.from_numpy(probs).to(dev).to(torch.bfloat16), dim=-1, descending=True)
+        probs = oa.row_probs(oa.scores_from_pooled(to_np(qpool), to_np(kpool), dt), dt)
+        sp, _ = torch.sort(torch.from_numpy(probs).to(dev).to(tdt), dim=-1, descending=True)
         n_ref = ((torch.cumsum(sp, dim=-1) <= p).sum(-1) + 1).clamp(max=nimg)
         same = float((cnt_r.to(torch.int64) == n_ref).float().mean().item())
         rec[f"p={p}"] = dict(flat_rows_equal=True, random_rows_equal_frac=same,
                              random_rows_max_abs_diff=int((cnt_r - n_ref).abs().max().item()),
                              flat_kept_device_scan=int(cnt[0, 0, 0]), flat_kept_cpu_semantics=int(cnt_cpu[0, 0, 0]))
         assert same >= 0.99, (p, same)
-    _record("cumsum_device_scan.json", {f"H{H}_nq{nq}_n{nimg}": rec})
+    _record("cumsum_device_scan.json", {f"H{H}_nq{nq}_n{nimg}_{dt}": rec})
