@@ -87,6 +87,12 @@ def parse():
                     help="> 0: spatially smooth synthetic latents (white noise at 1/SMOOTH of the latent resolution, "
                          "upsampled trilinearly, + 10 %% white noise) instead of iid noise: Hilbert-adjacent query blocks "
                          "then see similar keys and keep similar block lists, as a trained model's do (SURVEY.md 8(d))")
+    ap.add_argument("--sim-exchange-gbps", type=float, default=0.0, metavar="G",
+                    help="with --simulate-ranks: every exchange takes latency + (bytes leaving the rank) / G GB/s on a side "
+                         "stream (0 = plain local copies on the compute stream).  300 is what an 8-GPU xGMI all-to-all is "
+                         "assumed to sustain per GPU (7 links x ~77 GB/s per direction = 537 GB/s peak)")
+    ap.add_argument("--sim-exchange-latency-us", type=float, default=15.0,
+                    help="fixed cost per simulated collective (launch + rendezvous)")
     ap.add_argument("--simulate-ranks", type=int, default=0,
                     help="diagnostic, single process: run rank 0's share of an N-rank Ulysses job (per-rank shapes, "
                          "pack / unpack kernels, 24/N heads) with the exchanges replaced by local copies -- the "
@@ -212,11 +218,25 @@ def main():
             out.view((sim,) + tuple(x.shape)).copy_(x.unsqueeze(0).expand((sim,) + tuple(x.shape)))
         dist.all_gather_into_tensor = _gather_into
 
-    class _LocalExchange:
-        """--simulate-ranks: the exchanges of rank 0 replaced by local copies of the same shapes."""
+    class _EventWait:
+        def __init__(self, ev):
+            self.ev = ev
 
-        def __init__(self, n):
-            self.n = n
+        def wait(self):
+            torch.cuda.current_stream().wait_event(self.ev)
+            return True
+
+    class _LocalExchange:
+        """--simulate-ranks: the exchanges of rank 0 replaced by local copies of the same shapes.  With
+        --sim-exchange-gbps G the copy runs on a SIDE stream behind a delay of latency + (bytes that would leave this
+        rank) / G (jenga_stream_delay: one wavefront), and .wait() makes the compute stream wait for it -- the same
+        dependency structure as an RCCL exchange on the process group's stream, so what the blocks enqueue between
+        posting an exchange and waiting for it overlaps the simulated transfer exactly as it would overlap a real one."""
+
+        def __init__(self, n, gbps=0.0, latency_us=0.0):
+            self.n, self.gbps, self.lat = n, gbps, latency_us
+            self.side = torch.cuda.Stream() if gbps > 0 else None
+            self.sim_us = 0.0          # simulated transfer time posted so far (host-side sum)
 
         def size(self):
             return self.n
@@ -224,18 +244,36 @@ def main():
         def rank(self):
             return 0
 
+        def _post(self, copy, nbytes_out):
+            if self.side is None:
+                copy()
+                return _Done()
+            us = self.lat + nbytes_out / (self.gbps * 1e3)
+            self.sim_us += us
+            ready = torch.cuda.Event()
+            ready.record()
+            self.side.wait_event(ready)
+            with torch.cuda.stream(self.side):
+                _capi.stream_delay(us, stream=self.side)
+                copy()
+                done = torch.cuda.Event()
+                done.record(self.side)
+            return _EventWait(done)
+
         def all_to_all(self, recvs, sends):
-            for rc, sd in zip(recvs, sends):
-                rc.copy_(sd)
-            return []
+            def copy():
+                for rc, sd in zip(recvs, sends):
+                    rc.copy_(sd)
+            out = sum(sd.numel() * sd.element_size() for sd in sends) * (self.n - 1) // self.n
+            return [self._post(copy, out)]
 
         def all_gather(self, out, x):
-            out.copy_(x.unsqueeze(0).expand_as(out))
+            return self._post(lambda: out.copy_(x.unsqueeze(0).expand_as(out)),
+                              x.numel() * x.element_size() * (self.n - 1))
 
-            class _W:
-                def wait(self):
-                    return True
-            return _W()
+    class _Done:
+        def wait(self):
+            return True
 
     from jenga_amd import _capi, gemm_tuning
     from jenga_amd.dit import NON_SKIP_STEPS, JengaHYVideoDiT
@@ -265,10 +303,11 @@ def main():
             w__.wait()
         dist.all_reduce(w_)
         torch.cuda.synchronize()
+    sim_ex = _LocalExchange(sim, a.sim_exchange_gbps, a.sim_exchange_latency_us) if sim > 1 else None
     if world > 1 or sim > 1:
         ulysses.init_sequence_parallel()
         for blk in list(model.double_blocks) + list(model.single_blocks):
-            blk.hybrid_seq_parallel_attn = ulysses.UlyssesAttenCarve(exchange=_LocalExchange(sim) if sim > 1 else None)
+            blk.hybrid_seq_parallel_attn = ulysses.UlyssesAttenCarve(exchange=sim_ex)
     from jenga_amd import prores
     preset = dict(PRESETS[a.preset])
     if a.rates:
@@ -373,6 +412,8 @@ def main():
         run_step(computed_steps[0] if w % 2 == 0 else computed_steps[-1])   # computed steps: fills previous_residual
     barrier()
     _capi.ATTN_PROFILE = prof = _capi.AttnProfile()
+    if sim_ex is not None:
+        sim_ex.sim_us = 0.0
     evs = []
     t0 = time.perf_counter()
     for i in plan:
@@ -384,6 +425,8 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     _capi.ATTN_PROFILE = None
+    if sim_ex is not None:
+        sim_ex.sim_us_timed = sim_ex.sim_us
     if world > 1:
         tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -480,6 +523,9 @@ def main():
                                     for k, v in sorted(cls.items())},
                    "classes_not_sampled": unsampled,     # non-empty only for very small --steps: they borrow a neighbour's mean
                    "parallelism": (f"rank 0 of a simulated ulysses{sim} job on ONE GPU, exchanges replaced by local copies"
+                                   + (f" on a side stream behind a delay of {a.sim_exchange_latency_us:g} us + bytes "
+                                      f"leaving the rank / {a.sim_exchange_gbps:g} GB/s (the compute stream waits for "
+                                      "them as it would for RCCL)" if a.sim_exchange_gbps > 0 else "")
                                    if sim > 1 else "single GPU" if world == 1 else f"ulysses{world} (RCCL all-to-all)"),
                    "weights": "random init N(0,0.02), seed 0", "finite_output": finite,
                    "gemm_selection": (os.path.relpath(gemm_file, ROOT) + (" (RECORDING: not a measurement)"
@@ -499,6 +545,20 @@ def main():
                      "adjacent_shared_frac": round(ps.get("adjacent_shared_frac", float("nan")), 3),
                      "algorithmic_flops": "4*128^3 per kept (128-query, 128-key) block pair, realised masks"},
     }
+    if world > 1 or sim > 1:
+        from jenga_amd import dit as _dit
+        res["config"]["sp_overlap"] = {
+            "enabled": _dit.SP_OVERLAP, "mlp_tail_under_o_exchange": _dit.SP_MLP_TAIL,
+            "what": "single-stream blocks: Q,K,V exchange posted behind the QKV half of linear1, the MLP half (GEMM + GELU) "
+                    "issued under it, its last share under the O exchange; double-stream blocks: Q|K GEMM -> Q,K exchange, "
+                    "V GEMM + text stream under it (JENGA_SP_OVERLAP=0: everything in program order as in round 3)"}
+    if sim_ex is not None and a.sim_exchange_gbps > 0:
+        n_comp = sum(1 for i in plan if i in computed_steps)
+        res["config"]["sim_exchange"] = {
+            "gbps": a.sim_exchange_gbps, "latency_us": a.sim_exchange_latency_us,
+            "simulated_transfer_ms_per_computed_step": round(sim_ex.sim_us_timed / 1e3 / max(n_comp, 1), 2),
+            "note": "transfer time posted on the side stream during the timed steps / computed steps; what is NOT hidden "
+                    "shows up in value"}
     if dense_ms is not None:
         res["dense_reference"] = {
             "s_per_video": round(50 * dense_ms / 1e3, 2), "ms_per_dense_step": round(dense_ms, 1),

@@ -25,7 +25,8 @@
 extern "C" {
 #endif
 
-#define JENGA_ABI_VERSION 2   /* 2: jenga_block_select(flags), jenga_bsattn_fwd(order), jenga_sp_qkv_prologue, jenga_order_by_count, jenga_linear */
+#define JENGA_ABI_VERSION 3   /* 2: jenga_block_select(flags), jenga_bsattn_fwd(order), jenga_sp_qkv_prologue, jenga_order_by_count, jenga_linear
+                               * 3: jenga_sp_qkv_prologue takes (xq, xk) or xv alone; jenga_stream_delay */
 
 enum { JENGA_OK = 0, JENGA_EINVAL = 1, JENGA_ELAUNCH = 2, JENGA_EUNSUPPORTED = 3 };
 enum { JENGA_BF16 = 0, JENGA_FP16 = 1 };
@@ -168,6 +169,8 @@ int jenga_qk_norm_rope_pool(void* stream, const void* xq, const void* xk, void* 
  *   peer-major send buffers [N][B][S][H/N][128]: head0 = 0, n_heads = H, o_sp = B*S*(H/N)*128;
  *   a rank's own head slice of the replicated text rows, written straight behind the gathered image rows of the
  *   attention inputs (xdit_ring_atten.py:159-175 slices them the same way): head0 = rank*H/N, n_heads = H/N, o_sp = 0.
+ * Either the (xq, xk, oq, ok) group or (xv, ov) may be NULL (ABI 3): the sequence-parallel blocks issue the Q|K and
+ * the V GEMM separately and post the Q, K exchange before the V GEMM runs (exchange / compute overlap).
  * Bit-identical to the unfused kernels. */
 int jenga_sp_qkv_prologue(void* stream, const void* xq, const void* xk, const void* xv, void* oq, void* ok, void* ov,
                           const void* wq, const void* wk, const float* cosT, const float* sinT, int64_t B, int64_t S,
@@ -299,6 +302,13 @@ int jenga_ulysses_pack_heads(void* stream, const void* x, void* send, int64_t B,
                              int64_t N, int64_t x_sb, int64_t x_ss, int64_t x_sh);
 int jenga_ulysses_unpack_heads(void* stream, const void* recv, void* y, int64_t B, int64_t S_loc, int64_t H,
                                int64_t N, int64_t y_sb, int64_t y_ss, int64_t y_sh);
+
+/* ---------------------------------------------------------------------------------------------------
+ * Measurement aid, not part of the reference's path: one wavefront keeps `stream` busy for `microseconds` of the
+ * device's constant-rate wall clock.  bench.py --simulate-ranks N puts it on a side stream in front of the local
+ * copies that stand in for the Ulysses exchanges (xdit_ring_atten.py:118-131, 212-217), so that the overlap of
+ * the exchanges with the blocks' GEMMs can be timed on ONE GPU at a stated xGMI rate. */
+int jenga_stream_delay(void* stream, double microseconds);
 
 #ifdef __cplusplus
 }

@@ -53,6 +53,7 @@ SIGNATURES = {
     "jenga_bsattn_fwd": (_i32, [_vp] * 9 + [_i64] * 13 + [_f32, _f32, _i64, _i32, _i32]),
     "jenga_ulysses_pack_heads": (_i32, [_vp, _vp, _vp] + [_i64] * 7),
     "jenga_ulysses_unpack_heads": (_i32, [_vp, _vp, _vp] + [_i64] * 7),
+    "jenga_stream_delay": (_i32, [_vp, ctypes.c_double]),
 }
 
 # the experiments library (libjenga_amd_exp.so, include/jenga_amd.h under JENGA_EXPERIMENTS) adds these
@@ -114,7 +115,7 @@ def lib():
             if hasattr(L, name):
                 fn = getattr(L, name)
                 fn.restype, fn.argtypes = res, args
-        if L.jenga_abi_version() != 2:
+        if L.jenga_abi_version() != 3:
             raise JengaError("libjenga_amd.so ABI version mismatch; rebuild")
         _lib = L
     return _lib
@@ -275,37 +276,46 @@ def qk_norm_rope_pool(xq, xk, wq, wk, cos, sin, out_q, out_k, s_rope=None, qpool
 def sp_qkv_prologue(xq, xk, xv, wq, wk, cos, sin, out_q, out_k, out_v, heads_per_peer, head0=0, n_heads=None,
                     s_rope=None, eps=1e-6):
     """Sequence-parallel prologue: per-head RMSNorm + RoPE of Q and K and the Ulysses head scatter of Q, K, V in one
-    launch.  xq, xk, xv [B,S,H,128] with the SAME strides (any S).  Outputs, all three of one shape and stride set:
+    launch.  xq, xk, xv [B,S,H,128] with the SAME strides (any S).  Outputs, all of one shape and stride set:
       peer-major send buffers [N,B,S,H/N,128] (contiguous; head0 = 0, all heads), or
       [B,S,n_heads,128] views (any strides) receiving the head window [head0, head0 + n_heads) -- a rank's own slice
-      of the replicated text rows, written in place behind the gathered image rows."""
-    _need_gpu(xq, "sp_qkv_prologue")
-    B, S, H, D = xq.shape
-    if D != 128 or xk.shape != xq.shape or xv.shape != xq.shape:
+      of the replicated text rows, written in place behind the gathered image rows.
+    Either (xq, xk, out_q, out_k) or (xv, out_v) may be None: the blocks run the Q|K and the V GEMM separately and post
+    the Q, K exchange before the V GEMM (exchange / compute overlap)."""
+    has_qk, has_v = xq is not None, xv is not None
+    if not (has_qk or has_v) or (has_qk and (xk is None or out_q is None or out_k is None)) \
+            or (not has_qk and xk is not None) or (has_v and out_v is None):
+        raise ValueError("sp_qkv_prologue: pass (xq, xk, out_q, out_k) and / or (xv, out_v)")
+    xs = [t for t in (xq, xk, xv) if t is not None]
+    outs = ([out_q, out_k] if has_qk else []) + ([out_v] if has_v else [])
+    x0, o0 = xs[0], outs[0]
+    _need_gpu(x0, "sp_qkv_prologue")
+    B, S, H, D = x0.shape
+    if D != 128 or any(t.shape != x0.shape for t in xs):
         raise ValueError("sp_qkv_prologue: q / k / v must be [B, S, H, 128] of one shape")
-    if not (_bshd_strides(xq) == _bshd_strides(xk) == _bshd_strides(xv)):
+    if any(_bshd_strides(t) != _bshd_strides(x0) for t in xs):
         raise ValueError("sp_qkv_prologue: q, k and v must share their strides")
     if n_heads is None:
         n_heads = H - head0
     Hn = int(heads_per_peer)
-    if out_q.dim() == 5:
-        N = out_q.shape[0]
-        if head0 != 0 or n_heads != H or tuple(out_q.shape) != (N, B, S, Hn, 128) or N * Hn != H \
-                or not out_q.is_contiguous():
+    if o0.dim() == 5:
+        N = o0.shape[0]
+        if head0 != 0 or n_heads != H or tuple(o0.shape) != (N, B, S, Hn, 128) or N * Hn != H \
+                or not o0.is_contiguous():
             raise ValueError("sp_qkv_prologue: peer-major outputs must be contiguous [N, B, S, H/N, 128]")
-        o_sp, o_sb, o_ss, o_sh = out_q.stride(0), out_q.stride(1), out_q.stride(2), out_q.stride(3)
+        o_sp, o_sb, o_ss, o_sh = o0.stride(0), o0.stride(1), o0.stride(2), o0.stride(3)
     else:
-        if tuple(out_q.shape) != (B, S, n_heads, 128) or n_heads > Hn or head0 % Hn + n_heads > Hn:
+        if tuple(o0.shape) != (B, S, n_heads, 128) or n_heads > Hn or head0 % Hn + n_heads > Hn:
             raise ValueError("sp_qkv_prologue: head-window outputs must be [B, S, n_heads, 128] inside one peer's heads")
         o_sp = 0
-        o_sb, o_ss, o_sh = _bshd_strides(out_q)
+        o_sb, o_ss, o_sh = _bshd_strides(o0)
         if head0 % Hn:      # the kernel writes head h at local index h % Hn: shift the base so that head0 lands on 0
             raise ValueError("sp_qkv_prologue: head0 must be a multiple of heads_per_peer")
-    for t in (out_k, out_v):
-        if t.shape != out_q.shape or t.stride() != out_q.stride() or t.dtype != xq.dtype:
-            raise ValueError("sp_qkv_prologue: the three outputs must share shape, strides and dtype")
-    wq = None if wq is None else wq.to(device=xq.device, dtype=xq.dtype).contiguous()
-    wk = None if wk is None else wk.to(device=xq.device, dtype=xq.dtype).contiguous()
+    for t in outs:
+        if t.shape != o0.shape or t.stride() != o0.stride() or t.dtype != x0.dtype:
+            raise ValueError("sp_qkv_prologue: the outputs must share shape, strides and dtype")
+    wq = None if wq is None else wq.to(device=x0.device, dtype=x0.dtype).contiguous()
+    wk = None if wk is None else wk.to(device=x0.device, dtype=x0.dtype).contiguous()
     if cos is not None:
         if cos.dtype != torch.float32 or sin.dtype != torch.float32 or cos.shape[-1] != 128:
             raise ValueError("cos/sin must be float32 [S,128]")
@@ -316,12 +326,20 @@ def sp_qkv_prologue(xq, xk, xv, wq, wk, cos, sin, out_q, out_k, out_v, heads_per
             raise ValueError("s_rope exceeds the table / sequence length")
     else:
         s_rope = 0
-    with torch.cuda.device(xq.device):
-        _check(lib().jenga_sp_qkv_prologue(_stream(xq.device), _p(xq), _p(xk), _p(xv), _p(out_q), _p(out_k), _p(out_v),
+    with torch.cuda.device(x0.device):
+        _check(lib().jenga_sp_qkv_prologue(_stream(x0.device), _p(xq), _p(xk), _p(xv), _p(out_q), _p(out_k), _p(out_v),
                                            _p(wq), _p(wk), _p(cos), _p(sin), B, S, H, int(head0), int(n_heads), Hn,
-                                           *_bshd_strides(xq), int(o_sp), int(o_sb), int(o_ss), int(o_sh),
-                                           int(s_rope), float(eps), dtype_code(xq.dtype)), "jenga_sp_qkv_prologue")
+                                           *_bshd_strides(x0), int(o_sp), int(o_sb), int(o_ss), int(o_sh),
+                                           int(s_rope), float(eps), dtype_code(x0.dtype)), "jenga_sp_qkv_prologue")
     return out_q, out_k, out_v
+
+
+def stream_delay(microseconds, stream=None, device=None):
+    """Measurement aid (bench.py --simulate-ranks): keep `stream` (default: the current one) busy for that long."""
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else device
+    st = torch.cuda.current_stream(dev) if stream is None else stream
+    with torch.cuda.device(dev):
+        _check(lib().jenga_stream_delay(ctypes.c_void_p(st.cuda_stream), float(microseconds)), "jenga_stream_delay")
 
 
 def rmsnorm_rows(x, weight, eps):

@@ -222,9 +222,13 @@ __global__ void __launch_bounds__(256) sp_qkv_prologue_kernel(
         const long long hw = row % n_heads, s = (row / n_heads) % S, b = row / (n_heads * S);
         const long long h = head0 + hw;
         const long long xo = b * x_sb + s * x_ss + h * x_sh + sub * 8;
+        const long long oo = (h / Hn) * o_sp + b * o_sb + s * o_ss + (h % Hn) * o_sh + sub * 8;
+        // (xq, xk) or xv may be absent: the blocks issue the Q|K and the V GEMMs separately so that the Q, K exchange
+        // is already in flight while the V GEMM runs (pointers are launch-uniform: no divergence)
+        if (xv) *reinterpret_cast<uint4*>(ov + oo) = *reinterpret_cast<const uint4*>(xv + xo);
+        if (!xq) continue;
         const uint4 rq = *reinterpret_cast<const uint4*>(xq + xo);
         const uint4 rk = *reinterpret_cast<const uint4*>(xk + xo);
-        const uint4 rv = *reinterpret_cast<const uint4*>(xv + xo);
         float fq[8], fk[8];
         unpack8<T>(rq, fq);
         unpack8<T>(rk, fk);
@@ -239,10 +243,8 @@ __global__ void __launch_bounds__(256) sp_qkv_prologue_kernel(
         }
         norm_rope_row<T>(fq, wqv, wq != nullptr, eps, rope, c, sn);
         norm_rope_row<T>(fk, wkv, wk != nullptr, eps, rope, c, sn);
-        const long long oo = (h / Hn) * o_sp + b * o_sb + s * o_ss + (h % Hn) * o_sh + sub * 8;
         *reinterpret_cast<uint4*>(oq + oo) = pack8<T>(fq);
         *reinterpret_cast<uint4*>(ok + oo) = pack8<T>(fk);
-        *reinterpret_cast<uint4*>(ov + oo) = rv;
     }
 }
 
@@ -494,6 +496,16 @@ __global__ void wan_gate_residual_kernel(const float* x, const uint16_t* __restr
     }
 }
 
+// ------------------------------------------------------------------------------------------------ stream delay
+// Measurement aid (bench.py --simulate-ranks): ONE wavefront that keeps its stream busy for a given time of the
+// constant-rate wall clock (s_memrealtime) -- the stand-in for an xGMI transfer when a multi-rank job is replayed on a
+// single GPU.  It occupies one wave slot, so the compute stream beside it keeps (almost) the whole chip, as it does
+// beside an RCCL kernel that moves data with a handful of workgroups.
+__global__ void __launch_bounds__(64) stream_delay_kernel(long long ticks) {
+    const long long t0 = (long long)wall_clock64();
+    while ((long long)wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
+}
+
 }  // namespace
 }  // namespace jenga
 
@@ -594,7 +606,9 @@ extern "C" int jenga_sp_qkv_prologue(void* stream, const void* xq, const void* x
                                      int64_t B, int64_t S, int64_t H, int64_t head0, int64_t n_heads,
                                      int64_t heads_per_peer, int64_t x_sb, int64_t x_ss, int64_t x_sh, int64_t o_sp,
                                      int64_t o_sb, int64_t o_ss, int64_t o_sh, int64_t s_rope, float eps, int dtype) {
-    if (!xq || !xk || !xv || !oq || !ok || !ov || B < 0 || S < 0 || H <= 0 || head0 < 0 || n_heads < 0 ||
+    const bool has_qk = xq != nullptr, has_v = xv != nullptr;
+    if ((!has_qk && !has_v) || (has_qk && (!xk || !oq || !ok)) || (!has_qk && xk) || (has_v && !ov) || B < 0 || S < 0 ||
+        H <= 0 || head0 < 0 || n_heads < 0 ||
         head0 + n_heads > H || heads_per_peer <= 0 || !strides_ok(x_sb, x_ss, x_sh) || !strides_ok(o_sb, o_ss, o_sh) ||
         (o_sp & 7) || o_sp < 0 || ((uintptr_t)xq & 15) || ((uintptr_t)xk & 15) || ((uintptr_t)xv & 15) ||
         ((uintptr_t)oq & 15) || ((uintptr_t)ok & 15) || ((uintptr_t)ov & 15) ||
@@ -1183,5 +1197,23 @@ extern "C" int jenga_wan_gate_residual(void* stream, const float* x, const void*
     if (y_dtype == JENGA_BF16) LAUNCH_WGR(BF16); else LAUNCH_WGR(FP16);
 #undef LAUNCH_WGR
     JENGA_CHECK_LAUNCH("jenga_wan_gate_residual");
+    return JENGA_OK;
+}
+
+extern "C" int jenga_stream_delay(void* stream, double microseconds) {
+    if (!(microseconds >= 0.0) || microseconds > 5e6) {
+        set_error("jenga_stream_delay: microseconds must be in [0, 5e6]");
+        return JENGA_EINVAL;
+    }
+    int dev = 0, khz = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, dev) != hipSuccess ||
+        khz <= 0) {
+        set_error("jenga_stream_delay: cannot read the device's wall-clock rate");
+        return JENGA_ELAUNCH;
+    }
+    const long long ticks = (long long)(microseconds * 1e-3 * (double)khz);
+    if (ticks == 0) return JENGA_OK;
+    hipLaunchKernelGGL(stream_delay_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, ticks);
+    JENGA_CHECK_LAUNCH("jenga_stream_delay");
     return JENGA_OK;
 }

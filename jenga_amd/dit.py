@@ -89,6 +89,13 @@ class MLP(nn.Module):
 
 FUSE_GATE_RESIDUAL = os.environ.get("JENGA_FUSE_GATE", "1") != "0"
 SPLIT_LINEAR1 = os.environ.get("JENGA_SPLIT_LINEAR1", "1") != "0"
+# Sequence parallel, round 4: exchange / compute overlap (the reference issues everything on one stream,
+# xdit_ring_atten.py:118-131, 212-217).  Single-stream blocks: the Q, K, V exchange is posted right behind the QKV half of
+# linear1 and the MLP half (GEMM + GELU, 57 % of the block's GEMM FLOPs) is issued while it is in flight; the last
+# SP_MLP_TAIL share of the MLP columns is held back and issued behind the attention, under the O exchange.  Double-stream
+# blocks: the Q|K GEMM is followed by the Q, K exchange, the V GEMM and the whole text stream run under it.
+SP_OVERLAP = os.environ.get("JENGA_SP_OVERLAP", "1") != "0"
+SP_MLP_TAIL = float(os.environ.get("JENGA_SP_MLP_TAIL", "0.25"))
 
 
 def linear_gate_residual(lin, x, gate, res, gate2=None, mask=None):
@@ -199,26 +206,38 @@ class MMDoubleStreamBlock(nn.Module):
         if token_replace_vec is not None:
             tr = self.img_mod(token_replace_vec).chunk(6, dim=-1)
         fm = first_frame_mask if token_replace_vec is not None else None
-        # LayerNorm + adaLN modulation fused (one pass over HBM instead of three)
-        img_qkv = self.img_attn_qkv(_capi.ln_modulate(img, img_mod1_shift, img_mod1_scale, shift2=tr[0], scale2=tr[1],
-                                                      mask=fm)).view(B, S_img, 3, H, 128)
-        txt_qkv = self.txt_attn_qkv(_capi.ln_modulate(txt, txt_mod1_shift, txt_mod1_scale)).view(B, S_txt, 3, H, 128)
         block_neighbor_list = curve_sel[0][2] if curve_sel is not None else None
         top_k = _select_top_k(sa_drop_rate, S_img // per_block_token)
         cos, sin = freqs_cis
         sp = self.hybrid_seq_parallel_attn
-        if sp and hasattr(sp, "forward_qkv"):
-            # sequence parallel, fused prologue: RMSNorm + RoPE of Q, K and the peer-major pack of Q, K, V in ONE kernel
-            # per stream straight from the GEMM outputs (any shard length: 14400 tokens at N = 8 is not a multiple of
-            # 128); pooling happens after the exchange, on the gathered sequence
-            attn = sp.forward_qkv(
-                (img_qkv[:, :, 0], img_qkv[:, :, 1], img_qkv[:, :, 2]),
-                (txt_qkv[:, :, 0], txt_qkv[:, :, 1], txt_qkv[:, :, 2]),
-                (self.img_attn_q_norm.weight, self.img_attn_k_norm.weight),
-                (self.txt_attn_q_norm.weight, self.txt_attn_k_norm.weight), (cos, sin),
-                top_k=ulysses.get_sequence_parallel_world_size() * top_k, text_amp=txt_amp,
-                block_neighbor_list=block_neighbor_list, p_remain_rates=p_remain_rates,
-                cu_seqlens_q=cu_seqlens_q).reshape(B, S_img + S_txt, -1)
+        fused_sp = bool(sp) and hasattr(sp, "begin")
+        # LayerNorm + adaLN modulation fused (one pass over HBM instead of three)
+        xm = _capi.ln_modulate(img, img_mod1_shift, img_mod1_scale, shift2=tr[0], scale2=tr[1], mask=fm)
+        pend = None
+        if fused_sp and SP_OVERLAP:
+            # sequence parallel with overlap: Q|K GEMM -> prologue (RMSNorm + RoPE + peer-major pack, any shard length)
+            # -> Q, K exchange in flight; the V GEMM, its pack and the whole text stream run under it
+            C = H * 128
+            w, b = self.img_attn_qkv.weight, self.img_attn_qkv.bias
+            qk = F.linear(xm, w[: 2 * C], None if b is None else b[: 2 * C]).view(B, S_img, 2, H, 128)
+            pend = sp.begin(B, S_img, H, S_txt, qk.dtype, qk.device)
+            pend.post_qk(qk[:, :, 0], qk[:, :, 1], (self.img_attn_q_norm.weight, self.img_attn_k_norm.weight), (cos, sin))
+            pend.post_v(F.linear(xm, w[2 * C:], None if b is None else b[2 * C:]).view(B, S_img, H, 128))
+        else:
+            img_qkv = self.img_attn_qkv(xm).view(B, S_img, 3, H, 128)
+            if fused_sp:
+                pend = sp.begin(B, S_img, H, S_txt, img_qkv.dtype, img_qkv.device)
+                pend.post_qkv(img_qkv[:, :, 0], img_qkv[:, :, 1], img_qkv[:, :, 2],
+                              (self.img_attn_q_norm.weight, self.img_attn_k_norm.weight), (cos, sin))
+        txt_qkv = self.txt_attn_qkv(_capi.ln_modulate(txt, txt_mod1_shift, txt_mod1_scale)).view(B, S_txt, 3, H, 128)
+        if pend is not None:
+            # this rank's head slice of the (replicated) text rows goes straight behind the gathered image rows; pooling
+            # happens after the exchange, on the gathered sequence
+            pend.put_text(txt_qkv[:, :, 0], txt_qkv[:, :, 1], txt_qkv[:, :, 2],
+                          (self.txt_attn_q_norm.weight, self.txt_attn_k_norm.weight))
+            attn = pend.finish(top_k=ulysses.get_sequence_parallel_world_size() * top_k, text_amp=txt_amp,
+                               block_neighbor_list=block_neighbor_list, p_remain_rates=p_remain_rates,
+                               cu_seqlens_q=cu_seqlens_q).reshape(B, S_img + S_txt, -1)
         else:
             attn = self._attention_unfused(img_qkv, txt_qkv, cos, sin, sa_drop_rate, top_k, txt_amp, txt_block_num,
                                            p_remain_rates, block_neighbor_list, cu_seqlens_q, cu_seqlens_kv)
@@ -302,23 +321,46 @@ class MMSingleStreamBlock(nn.Module):
         # and linear2's concat buffer as its (strided) destination -- no separate 5.7 GB activation pass, no copy
         xm = _capi.ln_modulate(x, mod_shift, mod_scale, shift2=tr[0], scale2=tr[1], mask=fm)
         cat = torch.empty((B, S, C + self.mlp_hidden_dim), dtype=x.dtype, device=x.device)
-        if SPLIT_LINEAR1:
-            w1, b1 = self.linear1.weight, self.linear1.bias
-            qkv = F.linear(xm, w1[: 3 * C], None if b1 is None else b1[: 3 * C]).unflatten(-1, (3, H, 128))
-            _capi.linear(xm, w1[3 * C:], None if b1 is None else b1[3 * C:], act=_capi.ACT_GELU_TANH, out=cat[..., C:])
-        else:       # one GEMM, then the activation as a pass of its own (strided source and destination)
-            lin1 = self.linear1(xm)
-            qkv = lin1[..., : 3 * C].unflatten(-1, (3, H, 128))
-            _capi.gelu_tanh(lin1[..., 3 * C:], out=cat[..., C:])
         cos, sin = freqs_cis
         block_neighbor_list = curve_sel[0][2] if curve_sel is not None else None
         top_k = _select_top_k(sa_drop_rate, S_img // per_block_token)
         # attention writes its [B,S,H*128] output straight into the left part of the concat buffer
         attn_out = cat[..., :C].unflatten(-1, (H, 128))
         sp = self.hybrid_seq_parallel_attn
-        if sp and hasattr(sp, "forward_qkv"):
-            # fused sequence-parallel prologue (see MMDoubleStreamBlock): image rows -> peer-major send buffers, this
-            # rank's head slice of the text rows -> in place; the unpack kernels write into the concat buffer
+        fused_sp = bool(sp) and hasattr(sp, "begin")
+        w1, b1 = self.linear1.weight, self.linear1.bias
+
+        def mlp_half(c0, c1):      # columns [c0, c1) of the MLP half: GEMM + tanh-GELU epilogue into the concat buffer
+            if c1 > c0:
+                _capi.linear(xm, w1[3 * C + c0: 3 * C + c1], None if b1 is None else b1[3 * C + c0: 3 * C + c1],
+                             act=_capi.ACT_GELU_TANH, out=cat[..., C + c0: C + c1])
+
+        if fused_sp and SPLIT_LINEAR1:
+            # sequence parallel: QKV half -> fused prologue (image rows -> peer-major send buffers, this rank's head slice
+            # of the text rows -> in place) -> Q, K, V in flight; the MLP half runs under the exchange, its tail under
+            # the O exchange; the unpack kernels write into the concat buffer
+            qkv = F.linear(xm, w1[: 3 * C], None if b1 is None else b1[: 3 * C]).unflatten(-1, (3, H, 128))
+            w = (self.q_norm.weight, self.k_norm.weight)
+            pend = sp.begin(B, S_img, H, S - S_img, qkv.dtype, qkv.device)
+            pend.post_qkv(qkv[:, :S_img, 0], qkv[:, :S_img, 1], qkv[:, :S_img, 2], w, (cos, sin))
+            pend.put_text(qkv[:, S_img:, 0], qkv[:, S_img:, 1], qkv[:, S_img:, 2], w)
+            Mh = self.mlp_hidden_dim
+            tail = (int(Mh * SP_MLP_TAIL) // 256) * 256 if SP_OVERLAP else 0
+            mlp_half(0, Mh - tail)
+            pend.finish(top_k=ulysses.get_sequence_parallel_world_size() * top_k, text_amp=txt_amp,
+                        block_neighbor_list=block_neighbor_list, p_remain_rates=p_remain_rates,
+                        cu_seqlens_q=cu_seqlens_q, out=attn_out, while_out=lambda: mlp_half(Mh - tail, Mh))
+            return linear_gate_residual(self.linear2, cat, mod_gate, x, gate2=tr[2], mask=fm)
+        # linear1 as two GEMMs over the same input: the QKV half plain, the MLP half with the tanh-GELU in its epilogue
+        # and linear2's concat buffer as its (strided) destination -- no separate 5.7 GB activation pass, no copy
+        if SPLIT_LINEAR1:
+            qkv = F.linear(xm, w1[: 3 * C], None if b1 is None else b1[: 3 * C]).unflatten(-1, (3, H, 128))
+            mlp_half(0, self.mlp_hidden_dim)
+        else:       # one GEMM, then the activation as a pass of its own (strided source and destination)
+            lin1 = self.linear1(xm)
+            qkv = lin1[..., : 3 * C].unflatten(-1, (3, H, 128))
+            _capi.gelu_tanh(lin1[..., 3 * C:], out=cat[..., C:])
+        if fused_sp:
             w = (self.q_norm.weight, self.k_norm.weight)
             sp.forward_qkv(tuple(qkv[:, :S_img, i] for i in range(3)), tuple(qkv[:, S_img:, i] for i in range(3)), w, w,
                            (cos, sin), top_k=ulysses.get_sequence_parallel_world_size() * top_k, text_amp=txt_amp,

@@ -179,7 +179,8 @@ def _wait_all(works):
 
 
 def _hip_prologue(xq, xk, xv, wq, wk, cos, sin, outs, Hn, head0, n_heads, s_rope):
-    """RMSNorm + RoPE of Q, K and the head scatter of Q, K, V in one HIP launch (jenga_sp_qkv_prologue)."""
+    """RMSNorm + RoPE of Q, K and the head scatter of Q, K, V in one HIP launch (jenga_sp_qkv_prologue); (xq, xk) or xv
+    may be None together with their outputs."""
     _capi.sp_qkv_prologue(xq, xk, xv, wq, wk, cos, sin, outs[0], outs[1], outs[2], Hn, head0=head0, n_heads=n_heads,
                           s_rope=s_rope)
 
@@ -219,38 +220,6 @@ class UlyssesAttenCarve(torch.nn.Module):
         return self._exchange
 
     # ---- local stages ------------------------------------------------------------------------------------------
-    def stage_in(self, query, key, value, jq, jk, jv, N, r):
-        """-> (sends [3 x [N,S_loc,Hn,D]], gathered [3 x [1,S,Hn,D]] with the text rows already in place, recv views)."""
-        B, S_loc, H, D = query.shape
-        Hn = H // N
-        S_txt = jq.shape[1]
-        S_img = S_loc * N
-        hs = slice(r * Hn, (r + 1) * Hn)
-        sends, fulls, recvs = [], [], []
-        for t, joint in ((query, jq), (key, jk), (value, jv)):
-            sends.append(self.pack_fn(t, N).view(N, S_loc, Hn, D))
-            full = torch.empty((B, S_img + S_txt, Hn, D), dtype=t.dtype, device=t.device)
-            full[:, S_img:] = joint[:, :, hs]      # text is replicated on every rank: slice my heads, no exchange
-            fulls.append(full)
-            recvs.append(full[0, :S_img].view(N, S_loc, Hn, D))
-        return sends, fulls, recvs
-
-    def stage_in_fused(self, img, txt, w_img, w_txt, cos, sin, N, r):
-        """img / txt: (q, k, v) raw slices [1,S_loc,H,D] / [1,S_txt,H,D] of the QKV GEMM outputs; w_*: (wq, wk) RMSNorm
-        weights.  Same return value as stage_in, produced by two launches of the fused prologue."""
-        B, S_loc, H, D = img[0].shape
-        Hn = H // N
-        S_txt = txt[0].shape[1]
-        S_img = S_loc * N
-        dt, dev = img[0].dtype, img[0].device
-        sends = [torch.empty((N, B, S_loc, Hn, D), dtype=dt, device=dev) for _ in range(3)]
-        fulls = [torch.empty((B, S_img + S_txt, Hn, D), dtype=dt, device=dev) for _ in range(3)]
-        self.prologue_fn(img[0], img[1], img[2], w_img[0], w_img[1], cos, sin, sends, Hn, 0, H, S_loc)
-        self.prologue_fn(txt[0], txt[1], txt[2], w_txt[0], w_txt[1], None, None, [f[:, S_img:] for f in fulls], Hn,
-                         r * Hn, Hn, 0)
-        recvs = [f[0, :S_img].view(N, S_loc, Hn, D) for f in fulls]
-        return [s_.view(N, S_loc, Hn, D) for s_ in sends], fulls, recvs
-
     def stage_out(self, o_recv, txt_all, N, S_loc, S_txt, dtype, device, out=None):
         """o_recv [N,S_loc,Hn,D] (chunk p = my tokens, rank p's heads), txt_all [N,1,S_txt,Hn,D] -> [1,S_loc+S_txt,H,D]
         (written into `out` when given: may be a strided view, e.g. the left part of linear2's concat buffer)."""
@@ -260,34 +229,6 @@ class UlyssesAttenCarve(torch.nn.Module):
         self.unpack_fn(txt_all, N, result[:, S_loc:])
         return result
 
-    def _run(self, ex, N, sends, fulls, recvs, S_loc, S_txt, top_k, text_amp, block_neighbor_list, p_remain_rates,
-             cu_seqlens_q, out=None):
-        q_all, k_all, v_all = fulls
-        S_img = S_loc * N
-        B, _, Hn, D = q_all.shape
-        dev, dt = q_all.device, q_all.dtype
-        # ---- exchange in: scatter heads / gather sequence; Q+K first, V behind them on the communication stream
-        w_qk = ex.all_to_all(recvs[:2], sends[:2])
-        w_v = ex.all_to_all(recvs[2:], sends[2:])
-        # cu_seqlens = [0, n_valid_text + S_img, S] (xdit_ring_atten.py:105,183-184) -- stays on the device
-        seqlens = (cu_seqlens_q[1:2].to(torch.int64) - S_loc + S_img).to(device=dev, dtype=torch.int32)
-        _wait_all(w_qk)
-        idx, cnt = self.select_fn(q_all, k_all, top_k, S_txt // 128, p_remain_rates, block_neighbor_list)
-        _wait_all(w_v)                                         # the V transfer overlapped pooling + selection
-        o = self.attend_fn(q_all, k_all, v_all, idx, cnt, seqlens, S_txt // 128, text_amp)
-        # ---- exchange out: image rows (already peer-major: chunk p = rank p's tokens) back to sequence shards;
-        #      text rows gathered over heads (the reference repeats them N times and all-to-alls, :206-217)
-        o_img = o[0, :S_img].reshape(N, S_loc, Hn, D)
-        if not o_img.is_contiguous():
-            o_img = o_img.contiguous()
-        o_recv = torch.empty((N, S_loc, Hn, D), dtype=dt, device=dev)
-        txt_all = torch.empty((N, B, S_txt, Hn, D), dtype=dt, device=dev)
-        w_o = ex.all_to_all([o_recv], [o_img])
-        w_t = ex.all_gather(txt_all, o[:, S_img:])
-        _wait_all(w_o)
-        w_t.wait()
-        return self.stage_out(o_recv, txt_all, N, S_loc, S_txt, dt, dev, out=out)
-
     def _check(self, B, S_loc, H, S_txt, N):
         if B != 1:
             raise ValueError("jenga_amd Ulysses: batch must be 1")
@@ -295,6 +236,16 @@ class UlyssesAttenCarve(torch.nn.Module):
             raise ValueError(f"heads ({H}) must be divisible by the sequence-parallel degree ({N})")
         if (S_loc * N) % 128 or S_txt % 128:
             raise ValueError("gathered image length and text length must be multiples of 128")
+
+    def begin(self, B, S_loc, H, S_txt, dtype, device, D=128):
+        """Start one attention call of the sequence-parallel blocks: allocates the peer-major send buffers and the
+        gathered attention inputs and returns the pending call (`PendingAttenCarve`).  The caller posts Q, K (and V)
+        as soon as their GEMM is done, keeps issuing independent work (the V GEMM, the text stream, the MLP half of
+        linear1) while the exchange is in flight on RCCL's stream, and calls .finish()."""
+        ex = self.exchange()
+        N, r = ex.size(), ex.rank()
+        self._check(B, S_loc, H, S_txt, N)
+        return PendingAttenCarve(self, ex, N, r, B, S_loc, H, S_txt, D, dtype, device)
 
     @torch.no_grad()
     def forward(self, attn, query, key, value, *, joint_tensor_query=None, joint_tensor_key=None,
@@ -304,32 +255,123 @@ class UlyssesAttenCarve(torch.nn.Module):
         if joint_strategy != "rear" or joint_tensor_query is None or joint_tensor_key is None \
                 or joint_tensor_value is None:
             raise ValueError("jenga_amd Ulysses: only joint_strategy='rear' with text q/k/v (the Jenga call) is supported")
-        ex = self.exchange()
-        N, r = ex.size(), ex.rank()
         B, S_loc, H, D = query.shape
         S_txt = joint_tensor_query.shape[1]
-        self._check(B, S_loc, H, S_txt, N)
-        sends, fulls, recvs = self.stage_in(query, key, value, joint_tensor_query, joint_tensor_key,
-                                            joint_tensor_value, N, r)
-        return self._run(ex, N, sends, fulls, recvs, S_loc, S_txt, top_k, text_amp, block_neighbor_list,
-                         p_remain_rates, cu_seqlens_q)
+        pend = self.begin(B, S_loc, H, S_txt, query.dtype, query.device, D)
+        pend.post_packed(query, key, value, joint_tensor_query, joint_tensor_key, joint_tensor_value)
+        return pend.finish(top_k=top_k, text_amp=text_amp, block_neighbor_list=block_neighbor_list,
+                           p_remain_rates=p_remain_rates, cu_seqlens_q=cu_seqlens_q)
 
     @torch.no_grad()
     def forward_qkv(self, img_qkv, txt_qkv, img_norm_w, txt_norm_w, freqs_cis, *, top_k=0, text_amp=0.0,
                     block_neighbor_list=None, p_remain_rates=0.0, cu_seqlens_q=None, out=None):
-        """The fused entry (jenga_amd.dit): img_qkv / txt_qkv = (q, k, v) RAW slices of the QKV GEMM outputs of the
-        local image shard [1,S_loc,H,D] and of the (replicated) text rows [1,S_txt,H,D]; *_norm_w = (q_norm.weight,
+        """The fused entry in one call: img_qkv / txt_qkv = (q, k, v) RAW slices of the QKV GEMM outputs of the local
+        image shard [1,S_loc,H,D] and of the (replicated) text rows [1,S_txt,H,D]; *_norm_w = (q_norm.weight,
         k_norm.weight); freqs_cis = (cos, sin) rows of the local shard.  Same result as forward() on the
-        normalised / rotated tensors, bit for bit; returns [1, S_loc + S_txt, H, D] (in `out` when given)."""
-        ex = self.exchange()
-        N, r = ex.size(), ex.rank()
+        normalised / rotated tensors, bit for bit; returns [1, S_loc + S_txt, H, D] (in `out` when given).
+        (jenga_amd.dit's blocks use begin() / post_*() / finish() themselves to put GEMMs between the steps.)"""
         B, S_loc, H, D = img_qkv[0].shape
-        S_txt = txt_qkv[0].shape[1]
-        self._check(B, S_loc, H, S_txt, N)
+        pend = self.begin(B, S_loc, H, txt_qkv[0].shape[1], img_qkv[0].dtype, img_qkv[0].device, D)
+        pend.post_qkv(img_qkv[0], img_qkv[1], img_qkv[2], img_norm_w, freqs_cis)
+        pend.put_text(txt_qkv[0], txt_qkv[1], txt_qkv[2], txt_norm_w)
+        return pend.finish(top_k=top_k, text_amp=text_amp, block_neighbor_list=block_neighbor_list,
+                           p_remain_rates=p_remain_rates, cu_seqlens_q=cu_seqlens_q, out=out)
+
+
+class PendingAttenCarve:
+    """One sequence-parallel attention call between its first posted exchange and its result (exchange / compute
+    overlap; the reference runs everything on one stream, xdit_ring_atten.py:118-131, 212-217).
+
+      post_qk(q, k, (wq, wk), (cos, sin))   prologue kernel (RMSNorm + RoPE + peer-major pack) + Q, K exchange
+      post_v(v)                             pack + V exchange
+      post_qkv(q, k, v, ...)                both from ONE prologue launch (one QKV GEMM in front)
+      put_text(q, k, v, (wq, wk))           local: this rank's head slice of the replicated text rows, in place
+      finish(..., out=, while_out=)         wait Q, K -> pool + select -> wait V -> re-tile + attention -> post the
+                                            O exchange -> while_out() (caller's independent work) -> wait -> unpack
+
+    Everything between a post_* and finish() that the caller enqueues on the compute stream overlaps the transfer."""
+
+    def __init__(self, sp, ex, N, r, B, S_loc, H, S_txt, D, dtype, device):
+        self.sp, self.ex, self.N, self.r = sp, ex, N, r
+        self.B, self.S_loc, self.H, self.S_txt, self.D = B, S_loc, H, S_txt, D
+        self.Hn, self.S_img = H // N, S_loc * N
+        self.dtype, self.device = dtype, device
+        mk = lambda shape: torch.empty(shape, dtype=dtype, device=device)
+        self.fulls = [mk((B, self.S_img + S_txt, self.Hn, D)) for _ in range(3)]
+        self.recvs = [f[0, :self.S_img].view(N, S_loc, self.Hn, D) for f in self.fulls]
+        self.sends = [None, None, None]
+        self.w_qk = self.w_v = None
+
+    def _send_buffers(self, which):
+        for i in which:
+            self.sends[i] = torch.empty((self.N, self.B, self.S_loc, self.Hn, self.D), dtype=self.dtype,
+                                        device=self.device)
+        return [self.sends[i] for i in which]
+
+    def _views(self, which):
+        return [self.sends[i].view(self.N, self.S_loc, self.Hn, self.D) for i in which]
+
+    def post_qk(self, q, k, norm_w, freqs_cis):
         cos, sin = freqs_cis
-        sends, fulls, recvs = self.stage_in_fused(img_qkv, txt_qkv, img_norm_w, txt_norm_w, cos, sin, N, r)
-        return self._run(ex, N, sends, fulls, recvs, S_loc, S_txt, top_k, text_amp, block_neighbor_list,
-                         p_remain_rates, cu_seqlens_q, out=out)
+        oq, ok = self._send_buffers((0, 1))
+        self.sp.prologue_fn(q, k, None, norm_w[0], norm_w[1], cos, sin, [oq, ok, None], self.Hn, 0, self.H, self.S_loc)
+        self.w_qk = self.ex.all_to_all(self.recvs[:2], self._views((0, 1)))
+
+    def post_v(self, v):
+        (ov,) = self._send_buffers((2,))
+        self.sp.prologue_fn(None, None, v, None, None, None, None, [None, None, ov], self.Hn, 0, self.H, 0)
+        self.w_v = self.ex.all_to_all(self.recvs[2:], self._views((2,)))
+
+    def post_qkv(self, q, k, v, norm_w, freqs_cis):
+        cos, sin = freqs_cis
+        outs = self._send_buffers((0, 1, 2))
+        self.sp.prologue_fn(q, k, v, norm_w[0], norm_w[1], cos, sin, outs, self.Hn, 0, self.H, self.S_loc)
+        # Q + K first, V behind them on the communication stream (the V transfer overlaps pooling + selection)
+        self.w_qk = self.ex.all_to_all(self.recvs[:2], self._views((0, 1)))
+        self.w_v = self.ex.all_to_all(self.recvs[2:], self._views((2,)))
+
+    def put_text(self, q, k, v, norm_w):
+        self.sp.prologue_fn(q, k, v, norm_w[0], norm_w[1], None, None, [f[:, self.S_img:] for f in self.fulls],
+                            self.Hn, self.r * self.Hn, self.Hn, 0)
+
+    def post_packed(self, query, key, value, jq, jk, jv):
+        """The reference-signature path: already normalised / rotated tensors, separate pack kernels."""
+        hs = slice(self.r * self.Hn, (self.r + 1) * self.Hn)
+        for i, (t, joint) in enumerate(((query, jq), (key, jk), (value, jv))):
+            self.sends[i] = self.sp.pack_fn(t, self.N)
+            self.fulls[i][:, self.S_img:] = joint[:, :, hs]    # text is replicated on every rank: slice my heads
+        self.w_qk = self.ex.all_to_all(self.recvs[:2], self._views((0, 1)))
+        self.w_v = self.ex.all_to_all(self.recvs[2:], self._views((2,)))
+
+    def finish(self, *, top_k=0, text_amp=0.0, block_neighbor_list=None, p_remain_rates=0.0, cu_seqlens_q=None,
+               out=None, while_out=None):
+        if self.w_qk is None or self.w_v is None:
+            raise RuntimeError("PendingAttenCarve.finish(): Q, K and V have not all been posted")
+        sp, ex, N = self.sp, self.ex, self.N
+        q_all, k_all, v_all = self.fulls
+        S_img, S_loc, S_txt, Hn, D = self.S_img, self.S_loc, self.S_txt, self.Hn, self.D
+        dev, dt = self.device, self.dtype
+        # cu_seqlens = [0, n_valid_text + S_img, S] (xdit_ring_atten.py:105,183-184) -- stays on the device
+        seqlens = (cu_seqlens_q[1:2].to(torch.int64) - S_loc + S_img).to(device=dev, dtype=torch.int32)
+        _wait_all(self.w_qk)
+        idx, cnt = sp.select_fn(q_all, k_all, top_k, S_txt // 128, p_remain_rates, block_neighbor_list)
+        _wait_all(self.w_v)                                    # the V transfer overlapped pooling + selection
+        o = sp.attend_fn(q_all, k_all, v_all, idx, cnt, seqlens, S_txt // 128, text_amp)
+        # ---- exchange out: image rows (already peer-major: chunk p = rank p's tokens) back to sequence shards;
+        #      text rows gathered over heads (the reference repeats them N times and all-to-alls, :206-217)
+        o_img = o[0, :S_img].reshape(N, S_loc, Hn, D)
+        if not o_img.is_contiguous():
+            o_img = o_img.contiguous()
+        o_recv = torch.empty((N, S_loc, Hn, D), dtype=dt, device=dev)
+        txt_all = torch.empty((N, self.B, S_txt, Hn, D), dtype=dt, device=dev)
+        w_o = ex.all_to_all([o_recv], [o_img])
+        w_t = ex.all_gather(txt_all, o[:, S_img:])
+        if while_out is not None:
+            while_out()                                        # the caller's work that needs neither O nor its buffers
+        _wait_all(w_o)
+        w_t.wait()
+        self.sends = self.fulls = self.recvs = None
+        return sp.stage_out(o_recv, txt_all, N, S_loc, S_txt, dt, dev, out=out)
 
 
 # name the reference uses (jenga_hyvideo_multigpu.py:181)

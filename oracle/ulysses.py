@@ -70,13 +70,19 @@ def qkv_prologue(xq, xk, xv, wq, wk, cos, sin, outs, heads_per_peer, head0, n_he
     from . import norm_rope as onr
     tn = lambda t: t.detach().float().numpy()
     res = []
+    # (xq, xk) or xv may be None together with their outputs: the blocks post Q, K before the V GEMM has run
     for x, w in ((xq, wq), (xk, wk)):
+        if x is None:
+            res.append(None)
+            continue
         y = onr.rmsnorm(tn(x), None if w is None else tn(w), dtype)
         if cos is not None and s_rope > 0:
             y[:, :s_rope] = onr.apply_rotary_emb(y[:, :s_rope], tn(cos)[:s_rope], tn(sin)[:s_rope], dtype)
-        res.append(torch.from_numpy(y).to(xq.dtype))
+        res.append(torch.from_numpy(y).to(x.dtype))
     res.append(xv)
     for o, y in zip(outs, res):
+        if y is None:
+            continue
         y = y[:, :, head0:head0 + n_heads]
         if o.dim() == 5:
             o.copy_(pack_heads(y, o.shape[0]))

@@ -15,7 +15,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def test_library_builds_and_loads():
     build.build()
     L = _capi.lib()
-    assert L.jenga_abi_version() == 2
+    assert L.jenga_abi_version() == 3
 
 
 def _declared():

@@ -100,6 +100,17 @@ def _worker(rank, world, port, ret, mode):
         unfused = my_parallel_attention(sp2, nrm[0], nrm[1], raw[2], img_q_len=S_loc, img_kv_len=S_loc,
                                         cu_seqlens_kv=cu, **kw).reshape(fused.shape)
         assert torch.equal(fused, unfused), "forward_qkv differs from forward on the normalised tensors"
+        # the overlap form the DiT blocks use (round 4): Q, K posted first, V and the text rows later, caller's work
+        # between the steps and while the output exchange is in flight -- same collectives in the same order, same bits
+        ran = []
+        pend = sp2.begin(1, S_loc, H, tb * 128, torch.bfloat16, raw[0].device)
+        pend.post_qk(raw[0][:, :S_loc], raw[1][:, :S_loc], (wq, wk), (cos, sin))
+        ran.append("between")                                   # (a GEMM would sit here)
+        pend.post_v(raw[2][:, :S_loc])
+        pend.put_text(*(t[:, S_loc:] for t in raw), (wq, wk))
+        split = pend.finish(while_out=lambda: ran.append("while_out"), **kw)
+        assert ran == ["between", "while_out"]
+        assert torch.equal(split, fused), "begin / post_qk / post_v / finish differs from forward_qkv"
         # the all_gather used by the driver (jenga_hyvideo_multigpu.py:193)
         g = ulysses.get_sp_group().all_gather(torch.full((1, 2, 3), float(rank)), dim=1)
         assert g.shape == (1, 2 * world, 3) and g[0, 2 * rank, 0] == rank
