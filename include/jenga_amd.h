@@ -26,7 +26,7 @@ extern "C" {
 #endif
 
 #define JENGA_ABI_VERSION 3   /* 2: jenga_block_select(flags), jenga_bsattn_fwd(order), jenga_sp_qkv_prologue, jenga_order_by_count, jenga_linear
-                               * 3: jenga_sp_qkv_prologue takes (xq, xk) or xv alone; jenga_stream_delay */
+                               * 3: jenga_sp_qkv_prologue takes (xq, xk) or xv alone; jenga_stream_delay; jenga_cross_attn_fwd */
 
 enum { JENGA_OK = 0, JENGA_EINVAL = 1, JENGA_ELAUNCH = 2, JENGA_EUNSUPPORTED = 3 };
 enum { JENGA_BF16 = 0, JENGA_FP16 = 1 };
@@ -286,6 +286,18 @@ int jenga_bsattn_pair_fwd(void* stream, const void* q, const void* k, const void
                           int64_t k_ss, int64_t k_sh, int64_t o_sb, int64_t o_ss, int64_t o_sh, float sm_scale,
                           float text_amp, int64_t text_block_start, int dtype, int flags);
 #endif /* JENGA_EXPERIMENTS */
+
+/* ---------------------------------------------------------------------------------------------------
+ * Dense cross-attention (ABI 3).  Replaces the flash_attention call of WanT2VCrossAttention.forward
+ * (wan/modules/model_mul.py:183-205; wan/modules/attention.py flash_attention with k_lens = None): every query
+ * row attends to ALL nkv_blocks*128 keys, softmax(q.k^T * sm_scale) in fp32, P rounded to dtype before P.V.
+ * The same kernel as the text rows of jenga_bsattn_fwd (LP kernel, TEXT mode), with a kv sequence of its own
+ * length.  q [B, nq_blocks*128, H, 128] strided (pad the last block; padded rows produce padded output rows),
+ * k [B, nkv_blocks*128, H, 128] strided, vt = jenga_pack_v(v, n_blocks = nkv_blocks), o like q. */
+int jenga_cross_attn_fwd(void* stream, const void* q, const void* k, const void* vt, void* o, int64_t B, int64_t H,
+                         int64_t nq_blocks, int64_t nkv_blocks, int64_t q_sb, int64_t q_ss, int64_t q_sh,
+                         int64_t k_sb, int64_t k_ss, int64_t k_sh, int64_t o_sb, int64_t o_ss, int64_t o_sh,
+                         float sm_scale, int dtype);
 
 /* ---------------------------------------------------------------------------------------------------
  * Ulysses head pack/unpack: the local halves of xFuserLongContextAttention.forward's SeqAllToAll4D calls

@@ -54,6 +54,7 @@ SIGNATURES = {
     "jenga_ulysses_pack_heads": (_i32, [_vp, _vp, _vp] + [_i64] * 7),
     "jenga_ulysses_unpack_heads": (_i32, [_vp, _vp, _vp] + [_i64] * 7),
     "jenga_stream_delay": (_i32, [_vp, ctypes.c_double]),
+    "jenga_cross_attn_fwd": (_i32, [_vp] * 5 + [_i64] * 13 + [_f32, _i32]),
 }
 
 # the experiments library (libjenga_amd_exp.so, include/jenga_amd.h under JENGA_EXPERIMENTS) adds these
@@ -683,6 +684,26 @@ def bsattn_fwd(q, k, vt, seqlens, idx, cnt, nq_img, sm_scale, text_amp, text_blo
             prof.pairs = tot if prof.pairs is None else prof.pairs + tot
             if idx is not None and nq_img > 1:
                 prof.last_lists = (idx, cnt)
+    return out
+
+
+def cross_attn_fwd(q, k, v, sm_scale=None, out=None):
+    """Dense cross-attention (WanT2VCrossAttention): q [B,Sq,H,128], k / v [B,Skv,H,128], Sq and Skv multiples of 128
+    (pad the buffers; rows are independent) -> o [B,Sq,H,128]; every query row sees all Skv keys."""
+    _need_gpu(q, "cross_attn_fwd")
+    B, Sq, H, D = q.shape
+    Skv = k.shape[1]
+    if D != 128 or Sq % 128 or Skv % 128 or Sq == 0 or Skv == 0 or tuple(k.shape) != (B, Skv, H, 128) \
+            or v.shape != k.shape or k.dtype != q.dtype or v.dtype != q.dtype:
+        raise ValueError("cross_attn_fwd: q [B,Sq,H,128], k / v [B,Skv,H,128] of one dtype, Sq and Skv multiples of 128")
+    if out is None:
+        out = torch.empty((B, Sq, H, 128), dtype=q.dtype, device=q.device)
+    vt = pack_v(v, Skv // 128)
+    with torch.cuda.device(q.device):
+        _check(lib().jenga_cross_attn_fwd(_stream(q.device), _p(q), _p(k), _p(vt), _p(out), B, H, Sq // 128, Skv // 128,
+                                          *_bshd_strides(q), *_bshd_strides(k), *_bshd_strides(out),
+                                          float(D ** -0.5 if sm_scale is None else sm_scale), dtype_code(q.dtype)),
+               "jenga_cross_attn_fwd")
     return out
 
 

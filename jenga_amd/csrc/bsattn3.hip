@@ -50,6 +50,8 @@ struct LpParams {
     int text_block_start;
     float qk_scale;
     float text_amp;
+    int n_text_q;    // query blocks that run in TEXT mode (all kv blocks, no list, no mask) and the first of them
+    int q_text0;
     int n_text_wg_pad;
     int img_per_head;
     int xcd_chunk;
@@ -309,11 +311,11 @@ __device__ __forceinline__ void attn_block_lp(const LpParams& P, unsigned char* 
 template <typename T>
 __global__ void __launch_bounds__(LP_THREADS, 2) bsattn_lp_kernel(LpParams P) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int n_text = P.n_blocks - P.nq_img;
+    const int n_text = P.n_text_q;
     const int id = blockIdx.x;
     if (id < P.n_text_wg_pad) {   // text query blocks first: the longest work items start earliest
         if (id >= P.B * P.H * n_text) return;
-        const int m = P.nq_img + id % n_text;
+        const int m = P.q_text0 + id % n_text;
         const int bh = id / n_text;
         attn_block_lp<T, true>(P, smem, bh / P.H, bh % P.H, m);
         return;
@@ -361,6 +363,8 @@ int jenga_bsattn_lp_launch(void* stream, const void* q, const void* k, const voi
     P.text_amp = text_amp;
     const long long n_text = n_blocks - nq_img;
     const long long n_text_wg = B * H * n_text;
+    P.n_text_q = (int)n_text;
+    P.q_text0 = (int)nq_img;
     P.n_text_wg_pad = (int)((n_text_wg + 7) / 8 * 8);
     if ((flags & JENGA_ATTN_XCD_REMAP) && nq_img >= 64) {
         P.xcd_chunk = (int)((nq_img + 7) / 8);
@@ -391,6 +395,65 @@ int jenga_bsattn_lp_launch(void* stream, const void* q, const void* k, const voi
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         set_error("jenga_bsattn_fwd (lp): %s", hipGetErrorString(e));
+        return JENGA_ELAUNCH;
+    }
+    return JENGA_OK;
+}
+
+// Dense cross-attention on the same kernel: every query block runs in TEXT mode (all kv blocks, fp32 scores x
+// sm_scale * log2 e, no kv-length mask, no list) against a kv sequence of its OWN length.  Replaces the flash_attention
+// call of WanT2VCrossAttention (wan/modules/model_mul.py:183-205: 512 context tokens, k_lens = None).
+extern "C" int jenga_cross_attn_fwd(void* stream, const void* q, const void* k, const void* vt, void* o, int64_t B,
+                                    int64_t H, int64_t nq_blocks, int64_t nkv_blocks, int64_t q_sb, int64_t q_ss,
+                                    int64_t q_sh, int64_t k_sb, int64_t k_ss, int64_t k_sh, int64_t o_sb, int64_t o_ss,
+                                    int64_t o_sh, float sm_scale, int dtype) {
+    auto bad8 = [](int64_t a, int64_t b_, int64_t c) { return (a & 7) || (b_ & 7) || (c & 7); };
+    if (!q || !k || !vt || !o || B <= 0 || H <= 0 || nq_blocks <= 0 || nkv_blocks <= 0 || bad8(q_sb, q_ss, q_sh) ||
+        bad8(k_sb, k_ss, k_sh) || bad8(o_sb, o_ss, o_sh) || ((uintptr_t)q & 15) || ((uintptr_t)k & 15) ||
+        ((uintptr_t)vt & 15) || ((uintptr_t)o & 7) || k_ss < 0 || k_ss >= (1LL << 31)) {
+        set_error("jenga_cross_attn_fwd: bad arguments (non-null 16-B aligned pointers, strides multiples of 8 elements, "
+                  "at least one query and one kv block)");
+        return JENGA_EINVAL;
+    }
+    if (dtype != JENGA_BF16 && dtype != JENGA_FP16) {
+        set_error("jenga_cross_attn_fwd: dtype must be bf16 or fp16");
+        return JENGA_EUNSUPPORTED;
+    }
+    LpParams P;
+    P.q = (const uint16_t*)q; P.k = (const uint16_t*)k; P.vt = (const uint16_t*)vt; P.o = (uint16_t*)o;
+    P.seqlens = nullptr; P.idx = nullptr; P.cnt = nullptr; P.order = nullptr;
+    P.q_sb = q_sb; P.q_ss = q_ss; P.q_sh = q_sh;
+    P.k_sb = k_sb; P.k_ss = k_ss; P.k_sh = k_sh;
+    P.o_sb = o_sb; P.o_ss = o_ss; P.o_sh = o_sh;
+    P.B = (int)B; P.H = (int)H; P.n_blocks = (int)nkv_blocks; P.nq_img = 0;
+    P.text_block_start = (int)nkv_blocks;
+    P.qk_scale = (float)((double)sm_scale * 1.44269504);
+    P.text_amp = 0.f;
+    P.n_text_q = (int)nq_blocks;
+    P.q_text0 = 0;
+    const long long wg = B * H * nq_blocks;
+    P.n_text_wg_pad = (int)((wg + 7) / 8 * 8);
+    P.xcd_chunk = 0;
+    P.img_per_head = 0;
+    if (wg > 0x7ffffff0LL) {
+        set_error("jenga_cross_attn_fwd: grid size %lld out of range", wg);
+        return JENGA_EINVAL;
+    }
+    const size_t smem = LP_LDS_BYTES;
+    if (dtype == JENGA_BF16) {
+        (void)hipFuncSetAttribute((const void*)bsattn_lp_kernel<BF16>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)smem);
+        hipLaunchKernelGGL(bsattn_lp_kernel<BF16>, dim3((unsigned)P.n_text_wg_pad), dim3(LP_THREADS), smem,
+                           (hipStream_t)stream, P);
+    } else {
+        (void)hipFuncSetAttribute((const void*)bsattn_lp_kernel<FP16>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)smem);
+        hipLaunchKernelGGL(bsattn_lp_kernel<FP16>, dim3((unsigned)P.n_text_wg_pad), dim3(LP_THREADS), smem,
+                           (hipStream_t)stream, P);
+    }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        set_error("jenga_cross_attn_fwd: %s", hipGetErrorString(e));
         return JENGA_ELAUNCH;
     }
     return JENGA_OK;

@@ -75,13 +75,9 @@ class MLP(nn.Module):
         self.fc2 = nn.Linear(hidden_channels, in_channels, bias=True, dtype=dtype, device=device)
 
     def hidden(self, x):
-        # fc1 + bias + tanh-GELU in ONE hipBLASLt call (GELU epilogue on the fp32 accumulator): the separate
+        # fc1 + bias + tanh-GELU in ONE hipBLASLt call (jenga_linear: GELU epilogue on the fp32 accumulator): the separate
         # activation pass was 5.7 GB of HBM traffic per layer at the 720p shape
-        if x.is_cuda and x.dim() == 3:
-            h = torch._addmm_activation(self.fc1.bias, x.flatten(0, 1), self.fc1.weight.t(), use_gelu=True)
-            return h.view(x.shape[0], x.shape[1], -1)
-        h = self.fc1(x)
-        return _capi.gelu_tanh(h, out=h)
+        return _capi.linear(x, self.fc1.weight, self.fc1.bias, act=_capi.ACT_GELU_TANH)
 
     def forward(self, x):
         return self.fc2(self.hidden(x))

@@ -6,8 +6,8 @@ What runs where: the residual stream is fp32 (the reference evaluates `x + y * e
 LayerNorm + modulation that feed the GEMMs and the gated residual adds are the two fused HIP kernels
 jenga_wan_ln_modulate / jenga_wan_gate_residual; self-attention is jenga_amd.modules.wan.WanSelfAttention (full-width
 RMSNorm, fp64 complex RoPE, block selection + block-sparse attention kernels); GELU is jenga_gelu_tanh; linear layers
-are hipBLASLt through torch; the text cross-attention (512 keys, 0.4 % of the FLOPs, not on the AttenCarve path) uses
-torch's scaled_dot_product_attention.  Weights are random-initialised here (no checkpoints in this environment);
+are hipBLASLt (jenga_linear where an epilogue rides along, torch otherwise); the text cross-attention (512 keys, 0.4 % of
+the FLOPs) runs on the LP attention kernel's dense mode (jenga_cross_attn_fwd) -- no library attention kernel anywhere.  Weights are random-initialised here (no checkpoints in this environment);
 state-dict keys follow the reference so that a Wan checkpoint loads with `patch_embedding.weight` flattened."""
 import math
 
@@ -60,16 +60,26 @@ class WanT2VCrossAttention(nn.Module):
         if context_lens is not None:
             raise ValueError("jenga_amd Wan cross-attention: context_lens must be None (the Jenga driver passes None)")
         b, n, d = x.shape[0], self.num_heads, self.head_dim
-        v = self.v(context).view(b, -1, n, d).transpose(1, 2)
-        # WanRMSNorm with its fp32 weight returns fp32; flash_attention's half() rounds q, k to the 16-bit dtype
-        if x.is_cuda and v.dtype == torch.bfloat16:      # norm (fp32 weight) + the cast in one pass, same arithmetic
-            q = _capi.wan_norm_rope(self.q(x), self.norm_q.weight, None, None, 0, self.norm_q.eps)
-            q = q.view(b, -1, n, d).transpose(1, 2)
+        L, Lc = x.shape[1], context.shape[1]
+        if b != 1 or d != 128 or Lc % 128 or context.dtype not in (torch.bfloat16, torch.float16):
+            raise ValueError("jenga_amd Wan cross-attention: batch 1, head_dim 128, a 16-bit context whose length is a "
+                             "multiple of 128 (text_len = 512)")
+        v = self.v(context).view(b, Lc, n, d)
+        # WanRMSNorm with its fp32 weight returns fp32; flash_attention's half() rounds q, k to the 16-bit dtype: norm
+        # (fp32 weight) + the cast in one pass, written into a buffer padded to whole 128-row query blocks
+        Lp = (L + 127) // 128 * 128
+        q = torch.empty((b, Lp, n * d), dtype=v.dtype, device=x.device)
+        if v.dtype == torch.bfloat16:
+            _capi.wan_norm_rope(self.q(x), self.norm_q.weight, None, None, 0, self.norm_q.eps, out=q.view(Lp, n * d))
         else:
-            q = self.norm_q(self.q(x)).to(v.dtype).view(b, -1, n, d).transpose(1, 2)
-        k = self.norm_k(self.k(context)).to(v.dtype).view(b, -1, n, d).transpose(1, 2)
-        o = F.scaled_dot_product_attention(q, k, v)          # softmax scale d^-0.5, no mask: flash_attention(k_lens=None)
-        return self.o(o.transpose(1, 2).flatten(2))
+            q[:, :L] = self.norm_q(self.q(x)).to(v.dtype)
+        if Lp > L:
+            q[:, L:].zero_()
+        k = self.norm_k(self.k(context)).to(v.dtype).view(b, Lc, n, d)
+        # softmax scale d^-0.5, no mask (flash_attention(k_lens=None)): the LP attention kernel in its dense mode, every
+        # query block against the Lc / 128 context blocks (jenga_cross_attn_fwd)
+        o = _capi.cross_attn_fwd(q.view(b, Lp, n, d), k, v)
+        return self.o(o[:, :L].flatten(2))
 
 
 class WanAttentionBlock(nn.Module):
@@ -94,11 +104,9 @@ class WanAttentionBlock(nn.Module):
         self.modulation = nn.Parameter(torch.randn(1, 6, dim, device=device) / dim ** 0.5)
 
     def ffn_hidden(self, h):
-        """ffn[0] + tanh-GELU: the activation rides in the GEMM's epilogue (hipBLASLt through torch) -- one pass less
+        """ffn[0] + tanh-GELU: the activation rides in the GEMM's epilogue (jenga_linear) -- one pass less
         over the [L, ffn_dim] activations (4.2 GB per layer at the 14B 720p shape)."""
-        if h.is_cuda and h.dim() == 3 and h.shape[0] == 1:
-            return torch._addmm_activation(self.ffn[0].bias, h[0], self.ffn[0].weight.t(), use_gelu=True).unsqueeze(0)
-        return _capi.gelu_tanh(self.ffn[0](h))
+        return _capi.linear(h, self.ffn[0].weight, self.ffn[0].bias, act=_capi.ACT_GELU_TANH)
 
     @torch.no_grad()
     def forward(self, x, e, seq_lens, grid_sizes, freqs, context, context_lens, sa_drop_rate=0.0, freq_remap=None,
