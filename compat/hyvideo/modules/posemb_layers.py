@@ -1,0 +1,3 @@
+"""hyvideo.modules.posemb_layers (jenga_hyvideo.py:20, models_mul_block_gc_ha_multigpu.py:20) -> jenga_amd."""
+from jenga_amd.modules.posemb_layers import (apply_rotary_emb, apply_rotary_emb_single, get_1d_rotary_pos_embed,  # noqa: F401
+                                             get_meshgrid_nd, get_nd_rotary_pos_embed)

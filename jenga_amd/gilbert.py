@@ -51,3 +51,15 @@ def gilbert_block_neighbor_mapping(t, h, w, block_size=128, transpose_order=None
 def sliced_gilbert_block_neighbor_mapping(t, h, w, block_size=128, transpose_order=None, as_tensor=False,
                                           device=None):
     return _neighbors(t, h, w, block_size, True, transpose_order, as_tensor, device)
+
+
+def transpose_gilbert_mapping(dims, order=None, as_tensor=False, device=None):
+    """gilbert.py:274-330 (imported by jenga_hyvideo.py:24 / jenga_hyi2v.py:26, called by no entry script): with the
+    default axis order it is gilbert_mapping(*dims); other orders are not supported."""
+    if len(dims) != 3:
+        raise ValueError("Dimensions must be three-dimensional")
+    if order is not None and list(order) != [0, 1, 2]:
+        if len(order) != 3 or set(order) != {0, 1, 2}:
+            raise ValueError("order must be a permutation of 0,1,2")
+        raise NotImplementedError("only the default axis order [0, 1, 2] is supported (no Jenga entry script passes another)")
+    return _mapping(dims[0], dims[1], dims[2], False, None, as_tensor, device)

@@ -31,6 +31,14 @@ def my_parallel_attention(hybrid_seq_parallel_attn, q, k, v, img_q_len, img_kv_l
     return attn.reshape(b, s, -1)
 
 
+def parallel_attention(hybrid_seq_parallel_attn, q, k, v, img_q_len, img_kv_len, cu_seqlens_q, cu_seqlens_kv):
+    """attenion.py:198-247: the sequence-parallel attention of the NON-Jenga model files (hyvideo/modules/models.py:216,
+    381).  The Jenga entry scripts import the name (jenga_hyvideo.py:19) but their blocks call my_parallel_attention
+    (models_mul_block_gc_ha_multigpu.py:276, 483); it exists here so that those imports resolve and says so when called."""
+    raise NotImplementedError("parallel_attention belongs to the non-Jenga HunyuanVideo blocks; the Jenga blocks call "
+                              "my_parallel_attention (jenga_amd.modules.attention.my_parallel_attention)")
+
+
 _DENSE_LISTS = {}
 
 

@@ -795,13 +795,80 @@ def gen_wan_sched():
     np.savez_compressed(os.path.join(OUT, "wan_sched_cases.npz"), **out)
 
 
+# ---- boundary signatures: parameter names, order, kinds and defaults of the callables a reference
+#      driver reaches through `hyvideo.modules.*`, `gilbert`, `wan.modules.*` -- data, not source text
+SIGNATURE_TARGETS = [   # (reference file, qualified name inside it)
+    ("hyvideo/modules/attention_block_triton_diffres.py", "block_sparse_attention"),
+    ("hyvideo_i2v/modules/attention_block_triton_diffres.py", "block_sparse_attention"),
+    ("wan/modules/attention_block_triton_diffres.py", "block_sparse_attention"),
+    ("hyvideo/modules/posemb_layers.py", "apply_rotary_emb"),
+    ("hyvideo/modules/posemb_layers.py", "get_nd_rotary_pos_embed"),
+    ("hyvideo/modules/attenion.py", "get_cu_seqlens"),
+    ("hyvideo/modules/attenion.py", "attention"),
+    ("hyvideo/modules/attenion.py", "my_parallel_attention"),
+    ("hyvideo/modules/norm_layers.py", "RMSNorm.__init__"),
+    ("hyvideo/modules/norm_layers.py", "RMSNorm.forward"),
+    ("hyvideo/modules/xdit_ring_atten.py", "xFuserLongContextAttention.forward"),
+    ("gilbert.py", "gilbert_mapping"),
+    ("gilbert.py", "sliced_gilbert_mapping"),
+    ("gilbert.py", "gilbert_block_neighbor_mapping"),
+    ("gilbert.py", "sliced_gilbert_block_neighbor_mapping"),
+    ("wan/modules/model_mul.py", "WanSelfAttention.forward"),
+    ("wan/modules/model_mul.py", "WanSelfAttention.__init__"),
+    ("wan/modules/model_mul.py", "WanRMSNorm.__init__"),
+    ("wan/modules/model_mul.py", "rope_apply"),
+    ("wan/modules/model_mul.py", "rope_params"),
+    ("hyvideo/modules/models_mul_block_gc_ha_multigpu.py", "MMDoubleStreamBlock.forward"),
+    ("hyvideo/modules/models_mul_block_gc_ha_multigpu.py", "MMSingleStreamBlock.forward"),
+]
+
+
+def gen_signatures():
+    """Parses the reference files with `ast` (nothing is imported: xdit_ring_atten.py needs yunchang / xfuser) and
+    writes tests/golden/signatures.json: per callable the positional parameters in order, the keyword-only ones, which
+    have defaults and the literal value of each default."""
+    import ast
+
+    def find(tree, qual):
+        node = tree
+        for part in qual.split("."):
+            node = next(n for n in ast.iter_child_nodes(node)
+                        if isinstance(n, (ast.FunctionDef, ast.ClassDef)) and n.name == part)
+        return node
+
+    def lit(node):
+        try:
+            return {"value": ast.literal_eval(node)}
+        except Exception:
+            return {"expr": ast.unparse(node)}          # e.g. a negative tuple or a name: the default's spelling
+
+    out = {}
+    for rel, qual in SIGNATURE_TARGETS:
+        tree = ast.parse(open(os.path.join(REF, rel)).read())
+        fn = find(tree, qual)
+        a = fn.args
+        pos = [x.arg for x in a.posonlyargs + a.args]
+        dpos = {}
+        for name, d in zip(pos[len(pos) - len(a.defaults):], a.defaults):
+            dpos[name] = lit(d)
+        kwonly = [x.arg for x in a.kwonlyargs]
+        dkw = {n: lit(d) for n, d in zip(kwonly, a.kw_defaults) if d is not None}
+        out[f"{rel}::{qual}"] = {"line": fn.lineno, "positional": pos, "positional_defaults": dpos,
+                                 "keyword_only": kwonly, "keyword_only_defaults": dkw,
+                                 "var_positional": a.vararg.arg if a.vararg else None,
+                                 "var_keyword": a.kwarg.arg if a.kwarg else None}
+    json.dump(out, open(os.path.join(OUT, "signatures.json"), "w"), indent=1, sort_keys=True)
+    print("signatures:", len(out), "callables")
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--big", action="store_true", help="also hash the full-size curves (about 1 min)")
     ap.add_argument("--only", default="")
     a = ap.parse_args()
     torch.set_grad_enabled(False)
-    if a.only not in ("wan", "sched", "wansched", "wanblock", "hyblocks", "wanforward", "hyforward", "i2vblock", "wan1p3b"):
+    if a.only not in ("wan", "sched", "wansched", "wanblock", "hyblocks", "wanforward", "hyforward", "i2vblock", "wan1p3b",
+                      "signatures"):
         gen_gilbert(a.big)
     if a.only in ("", "select", "attn"):
         gen_select()
@@ -827,4 +894,6 @@ if __name__ == "__main__":
         gen_scheduler()
     if a.only in ("", "sched", "wansched"):
         gen_wan_sched()
+    if a.only in ("", "signatures"):
+        gen_signatures()
     print("golden fixtures written to", OUT)
