@@ -79,6 +79,15 @@ def parse():
                          "jenga_amd/tuned/hipblaslt_gfx950.csv when present (no timing at run time), off = the library's "
                          "default heuristic, record:FILE = let TunableOp time every solution for the shapes this run "
                          "meets and write FILE (slow; not a measurement run)")
+    ap.add_argument("--workload", choices=["hy720p", "wan14b"], default="hy720p",
+                    help="hy720p = BASELINE.json configs[1] (the headline); wan14b = configs[3]: Wan2.1-14B T2V 1280x720x81f "
+                         "Jenga-Base (scripts/wan_14B_jenga_base.sh), a step = one scheduler step = two CFG forwards")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="skip roofline_secondary (isolated HIP-event timings of the bandwidth-bound kernels and the GEMM "
+                         "classes at the workload's shapes, run after the timed region)")
+    ap.add_argument("--no-wan-extra", action="store_true",
+                    help="skip the short Wan2.1-14B leg (one forward at each drop rate, after the timed region) that puts a "
+                         "configs[3] number into the default N=1 record")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-dense-ref", action="store_true",
                     help="skip the ONE dense (sa-drop 0) computed step that is run after the timed region to report "
@@ -142,12 +151,183 @@ def _host_cpu():
     return model, physical, logical
 
 
-def cpu_baseline(rates, p_remain, budget_s=9.0):
+class PowerSampler:
+    """Board power / shader clock from the amdgpu hwmon files, sampled by a host thread while the timed region runs
+    (the kernels sit on the 1400 W board cap, so every throughput figure in this file is a figure AT a power / clock
+    state: DESIGN.md 3 K1 point 4).  None of it touches the GPU queues."""
+
+    def __init__(self, period=0.25):
+        import glob
+        self.period, self.samples, self.nodes = period, [], []
+        for d in sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*")):
+            f = {k: f"{d}/{k}" for k in ("power1_average", "power1_input", "power1_cap", "freq1_input")}
+            if self._read(f["power1_average"]) is not None or self._read(f["power1_input"]) is not None:
+                self.nodes.append(f)
+        self._stop = None
+        self._thr = None
+
+    @staticmethod
+    def _read(path):
+        try:
+            with open(path) as fh:
+                return int(fh.read().strip())
+        except Exception:   # noqa: BLE001
+            return None
+
+    def _loop(self):
+        while not self._stop.is_set():
+            best = None
+            for f in self.nodes:      # the busiest card (a box may expose more hwmon nodes than HIP devices)
+                pw = self._read(f["power1_average"])
+                if pw is None:
+                    pw = self._read(f["power1_input"])
+                if pw is not None and (best is None or pw > best[0]):
+                    best = (pw, self._read(f["freq1_input"]) or 0)
+            if best:
+                self.samples.append((best[0] / 1e6, best[1] / 1e6))
+            self._stop.wait(self.period)
+
+    def start(self):
+        import threading
+        if self.nodes:
+            self._stop = threading.Event()
+            self._thr = threading.Thread(target=self._loop, daemon=True)
+            self._thr.start()
+        return self
+
+    def stop(self):
+        if self._thr is not None:
+            self._stop.set()
+            self._thr.join(timeout=2)
+        if not self.samples:
+            return {"available": False, "note": "no amdgpu hwmon power node readable on this box"}
+        pw = sorted(s_[0] for s_ in self.samples)
+        fq = sorted(s_[1] for s_ in self.samples if s_[1] > 0)
+        out = {"available": True, "samples": len(pw), "period_s": self.period,
+               "power_W": {"mean": round(sum(pw) / len(pw), 1), "median": round(pw[len(pw) // 2], 1),
+                           "max": round(pw[-1], 1)},
+               "power_cap_W": (self._read(self.nodes[0]["power1_cap"]) or 0) / 1e6,
+               "source": "amdgpu hwmon power1_average|power1_input / freq1_input over the timed region"}
+        if fq:
+            out["sclk_MHz"] = {"mean": round(sum(fq) / len(fq)), "median": round(fq[len(fq) // 2]), "min": round(fq[0]),
+                               "max": round(fq[-1])}
+        return out
+
+
+HBM_PEAK_GBPS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def _timed(fn, reps=10, warm=2):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+
+def secondary_roofline(dev, S_img=115200, S_txt=256, H=24, C=3072, mlp=12288, top_k=270, p_remain=0.3, nbm=None):
+    """the HBM-bound kernels of the path against 8 TB/s and the GEMM classes against the MFMA peak, at
+    the workload's shapes: HIP events around 10 back-to-back launches on the current stream, AFTER the timed region
+    (isolated launches: the in-loop shares are in profiles/*_kernel_stats.csv).  Bytes / FLOPs are ALGORITHMIC."""
+    from jenga_amd import _capi
+    bf = torch.bfloat16
+    S = S_img + S_txt
+    nb, nimg = S // 128, S_img // 128
+    g = torch.Generator(device=dev).manual_seed(7)
+    rnd = lambda *shape: torch.randn(*shape, generator=g, device=dev, dtype=bf)
+    out = {}
+
+    def hbm(name, ms, nbytes, note):
+        out[name] = {"bound": "hbm", "ms": round(ms, 4), "bytes": int(nbytes), "achieved": round(nbytes / ms / 1e6, 1),
+                     "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(nbytes / ms / 1e6 / HBM_PEAK_GBPS, 4),
+                     "algorithmic_bytes": note}
+
+    x = rnd(1, S_img, C)
+    order = torch.randperm(S_img, generator=g, device=dev)
+    ms = _timed(lambda: _capi.gather_rows(x, order))
+    hbm("gather_rows", ms, 2 * x.numel() * 2 + S_img * 8, "read + write [1,S_img,3072] bf16 + the int64 index")
+    vec = rnd(1, C)
+    ms = _timed(lambda: _capi.ln_modulate(x, vec, vec))
+    hbm("ln_modulate", ms, 2 * x.numel() * 2, "read + write [1,S_img,3072] bf16")
+    del x
+    qkv = rnd(1, S, 3, H, 128)
+    cos = torch.randn(S_img, 128, generator=g, device=dev)
+    sin = torch.randn(S_img, 128, generator=g, device=dev)
+    w = torch.ones(128, device=dev, dtype=bf)
+    q, k = torch.empty((1, S, H, 128), dtype=bf, device=dev), torch.empty((1, S, H, 128), dtype=bf, device=dev)
+    qp, kp = torch.empty((1, H, nimg, 128), dtype=bf, device=dev), torch.empty((1, H, nb, 128), dtype=bf, device=dev)
+    ms = _timed(lambda: _capi.qk_norm_rope_pool(qkv[:, :, 0], qkv[:, :, 1], w, w, cos, sin, q, k, s_rope=S_img, qpool=qp,
+                                                kpool=kp))
+    hbm("qk_norm_rope_pool", ms, 4 * q.numel() * 2 + 2 * cos.numel() * 4 + (qp.numel() + kp.numel()) * 2,
+        "read Q,K + fp32 cos,sin tables, write Q,K + pooled Q,K")
+    ms = _timed(lambda: _capi.pack_v(qkv[:, :, 2], nb))
+    hbm("pack_v", ms, 2 * q.numel() * 2, "read + write V [1,S,24,128] bf16")
+    ms = _timed(lambda: _capi.block_select(qp, kp, nbm, nimg, nb - nimg, top_k, p_remain))
+    lists = H * nimg * nb * 4 + H * nimg * 4
+    out["block_select"] = {"bound": "latency / LDS (one workgroup per (head, query block): 900 dot products, softmax, "
+                                    "bitonic sort, cumulative sum, compaction)", "ms": round(ms, 4),
+                           "bytes": int(lists + (qp.numel() + kp.numel()) * 2),
+                           "achieved": round((lists + (qp.numel() + kp.numel()) * 2) / ms / 1e6, 1), "peak": HBM_PEAK_GBPS,
+                           "unit": "GB/s", "frac": round((lists + (qp.numel() + kp.numel()) * 2) / ms / 1e6 / HBM_PEAK_GBPS, 4),
+                           "algorithmic_bytes": "pooled Q,K in, kept lists idx int32 [24,900,902] + cnt out"}
+    del qkv, q, k, cos, sin
+    # ---- GEMM classes (hipBLASLt; jenga_linear where an epilogue rides along)
+    gem = {}
+    xi = rnd(1, S_img, C)
+
+    def gemm(name, M, N, K, fn):
+        ms_ = _timed(fn, reps=6, warm=2)
+        fl = 2.0 * M * N * K
+        gem[name] = {"M": M, "N": N, "K": K, "ms": round(ms_, 3), "achieved": round(fl / ms_ / 1e9, 1),
+                     "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(fl / ms_ / 1e9 / MFMA_PEAK_TFLOPS, 4)}
+
+    wq = rnd(3 * C, C) * 0.02
+    gemm("qkv (double block, img)", S_img, 3 * C, C, lambda: torch.nn.functional.linear(xi, wq))
+    wp, gate, bias = rnd(C, C) * 0.02, torch.randn(C, generator=g, device=dev), rnd(C)
+    gemm("proj + gate*y + residual epilogue", S_img, C, C, lambda: _capi.linear(xi, wp, bias, gate=gate, res=xi))
+    w1 = rnd(mlp, C) * 0.02
+    b1 = rnd(mlp)
+    hbuf = torch.empty((1, S_img, mlp), dtype=bf, device=dev)
+    gemm("fc1 + tanh-GELU epilogue", S_img, mlp, C, lambda: _capi.linear(xi, w1, b1, act=_capi.ACT_GELU_TANH, out=hbuf))
+    w2 = rnd(C, mlp) * 0.02
+    gemm("fc2 + gate*y + residual epilogue", S_img, C, mlp, lambda: _capi.linear(hbuf, w2, bias, gate=gate, res=xi))
+    del hbuf, w1, w2
+    xs = rnd(1, S, C)
+    cat = torch.empty((1, S, C + mlp), dtype=bf, device=dev)
+    wl = rnd(mlp, C) * 0.02
+    gemm("linear1 MLP half + GELU into linear2's concat buffer", S, mlp, C,
+         lambda: _capi.linear(xs, wl, None, act=_capi.ACT_GELU_TANH, out=cat[..., C:]))
+    w3 = rnd(C, C + mlp) * 0.02
+    gemm("linear2 + gate*y + residual epilogue", S, C, C + mlp, lambda: _capi.linear(cat, w3, bias, gate=gate, res=xs))
+    out["gemm"] = gem
+    out["note"] = ("isolated: 6-10 back-to-back launches per kernel between two HIP events, after the timed region (short "
+                   "runs read a few % high against the power-capped steady state of the loop); in-loop shares: "
+                   "profiles/r04_bench_default_kernel_stats.csv")
+    return out
+
+
+def hy_gemm_flops_per_computed_step(S_img, S_txt, n_double, n_single, C=3072, mlp=12288):
+    """Dense linear algebra of one computed forward (models_mul_block_gc_ha_multigpu.py:852-869 dims): double blocks
+    qkv + proj + fc1 + fc2 on both streams, single blocks linear1 + linear2."""
+    S = S_img + S_txt
+    dbl = 2.0 * S * C * (3 * C + C + 2 * mlp)
+    sgl = 2.0 * S * (C * (3 * C + mlp) + (C + mlp) * C)
+    return n_double * dbl + n_single * sgl
+
+
+def cpu_baseline(rates, p_remain, budget_s=9.0, workload="hy720p"):
     """The reference's PyTorch-CPU eager path (restated in oracle/eager_torch.py: its torch block
     selection + F.scaled_dot_product_attention with the block mask expanded per 128x128 tile), timed on this box's
     host cores on BOUNDED samples and extrapolated linearly, attention + selection only (GEMMs excluded):
-      A  1 head x the full 720p sequence (S = 115456), fp32 and bf16: as many query-block chunks as fit the budget;
-      B  one layer of the 0.5-resolution stage (24 heads, S = 28416), bf16: as many heads as fit the budget."""
+      hy720p  A  1 head x the full 720p sequence (S = 115456), fp32 and bf16: as many query-block chunks as fit the budget;
+              B  one layer of the 0.5-resolution stage (24 heads, S = 28416), bf16: as many heads as fit the budget.
+      wan14b  A  1 head x the 1280x720x81f sequence (S = 75648 = 591 blocks, no text blocks, sliced-Gilbert neighbours,
+                 first_frame_blocks = 28), fp32 and bf16."""
     from oracle import eager_torch as et
     from oracle import gilbert as og
     model, physical, logical = _host_cpu()
@@ -155,36 +335,231 @@ def cpu_baseline(rates, p_remain, budget_s=9.0):
     out = {}
     gen = torch.Generator().manual_seed(1)
 
-    def one(S_img_blocks, grid, heads, dtype, budget):
-        tb = 2
+    def one(S_img_blocks, grid, heads, dtype, budget, tb=2, sliced=False, ffb=0, valid_text=64):
         nb = S_img_blocks + tb
         S = nb * 128
-        nbm = og.gilbert_block_neighbor_mapping(*grid)    # the static Hilbert block adjacency (the oracle's C Gilbert)
+        # the static Hilbert block adjacency (the oracle's C Gilbert)
+        nbm = (og.sliced_gilbert_block_neighbor_mapping if sliced else og.gilbert_block_neighbor_mapping)(*grid)
         q = torch.randn(1, heads, S, 128, generator=gen).to(dtype)
         k = torch.randn(1, heads, S, 128, generator=gen).to(dtype)
         v = torch.randn(1, heads, S, 128, generator=gen).to(dtype)
         top_k = int((1 - rates[0]) * S_img_blocks)
         t0 = time.perf_counter()
-        mask = et.build_block_mask(q[:, :, : S_img_blocks * 128], k, top_k, S_img_blocks, nb, p_remain, tb, nbm)
+        mask = et.build_block_mask(q[:, :, : S_img_blocks * 128], k, top_k, S_img_blocks, nb, p_remain, tb, nbm,
+                                   first_frame_blocks=ffb)
         t_sel = time.perf_counter() - t0
         t0 = time.perf_counter()
-        _, frac = et.masked_attention(q, k, v, mask, S_img_blocks * 128 + 64, S_img_blocks, q_chunk_blocks=16,
-                                      budget_s=budget, clock=time.perf_counter)
+        _, frac = et.masked_attention(q, k, v, mask, S_img_blocks * 128 + (valid_text if tb else 0), S_img_blocks,
+                                      q_chunk_blocks=16, budget_s=budget, clock=time.perf_counter)
         t_att = time.perf_counter() - t0
         return t_sel, t_att / max(frac, 1e-9), frac, float(mask.float().mean())
 
     legs = []
+    if workload == "wan14b":
+        heads_total, shape = 40, dict(S_img_blocks=591, grid=(21, 45, 80), tb=0, sliced=True, ffb=28)
+        tag = "wan720p_1head"
+    else:
+        heads_total, shape = 24, dict(S_img_blocks=900, grid=(32, 45, 80))
+        tag = "full_res_1head"
     for name, dtype in (("fp32", torch.float32), ("bf16", torch.bfloat16)):
-        t_sel, t_att, frac, dens = one(900, (32, 45, 80), 1, dtype, budget_s)
+        t_sel, t_att, frac, dens = one(heads=1, dtype=dtype, budget=budget_s, **shape)
         legs.append((name, t_sel, t_att, frac, dens))
-        out[f"full_res_1head_{name}"] = {"selection_s": round(t_sel, 3), "attention_s_extrapolated": round(t_att, 2),
-                                        "rows_timed_frac": round(frac, 4), "kept_block_frac": round(dens, 3)}
-    t_sel, t_att, frac, dens = one(220, (32, 22, 40), 24, torch.bfloat16, budget_s)
-    out["half_res_layer_24heads_bf16"] = {"selection_s": round(t_sel, 3), "attention_s_extrapolated": round(t_att, 2),
-                                          "rows_timed_frac": round(frac, 4), "kept_block_frac": round(dens, 3)}
+        out[f"{tag}_{name}"] = {"selection_s": round(t_sel, 3), "attention_s_extrapolated": round(t_att, 2),
+                                "rows_timed_frac": round(frac, 4), "kept_block_frac": round(dens, 3)}
+    if workload != "wan14b":
+        t_sel, t_att, frac, dens = one(220, (32, 22, 40), 24, torch.bfloat16, budget_s)
+        out["half_res_layer_24heads_bf16"] = {"selection_s": round(t_sel, 3), "attention_s_extrapolated": round(t_att, 2),
+                                              "rows_timed_frac": round(frac, 4), "kept_block_frac": round(dens, 3)}
     best = min(legs, key=lambda l_: l_[1] + l_[2])
-    per_layer = 24 * (best[1] + best[2])                   # 24 heads, one AttenCarve call
+    per_layer = heads_total * (best[1] + best[2])          # all heads, one AttenCarve call
     return dict(s_per_layer=per_layer, best=best[0], detail=out, cpu_model=model, cores=physical, logical=logical)
+
+
+# ------------------------------------------------------------------------------------------------ Wan2.1 (configs[3])
+WAN_RATE_PRIORITY = [0.7, 0.8, 0.0, 0.571429, 0.285714, 0.428571, 0.142857]   # which step classes a short run samples first
+
+
+def wan_setup(dev, task="t2v-14B", size=(1280, 720), frames=81, qk_gain=4.0, p_remain=0.8, layers=None):
+    """Synthetic-weight Wan2.1 DiT of the real architecture + latents / text of scripts/wan_14B_jenga_base.sh's shape."""
+    from jenga_amd import gilbert as G
+    from jenga_amd.wan_dit import WAN_CONFIGS, WanDiT
+    W, Hh = size
+    F_lat, H_lat, W_lat = (frames - 1) // 4 + 1, Hh // 8, W // 8
+    grid = (F_lat, H_lat // 2, W_lat // 2)
+    L = grid[0] * grid[1] * grid[2]
+    cfg = dict(WAN_CONFIGS[task])
+    if layers:
+        cfg["num_layers"] = layers
+    torch.manual_seed(0)
+    m = WanDiT(dtype=torch.bfloat16, device=dev, **cfg)
+    for p_ in m.parameters():
+        if p_.dim() >= 2:
+            torch.nn.init.normal_(p_, std=0.02)
+    if qk_gain != 1.0:      # random weights give flat pooled scores (the p-remain 0.8 rule would keep ~80 % of the blocks
+        for blk in m.blocks:    # at every drop rate); a gain of 4 makes the block softmax as peaked as a trained model's
+            blk.self_attn.norm_q.weight.data.mul_(qk_gain)
+            blk.self_attn.norm_k.weight.data.mul_(qk_gain)
+    l2h, h2l = G.sliced_gilbert_mapping(*grid, as_tensor=True, device=dev)
+    nbm = G.sliced_gilbert_block_neighbor_mapping(*grid, as_tensor=True, device=dev)
+    m.set_curve(l2h, h2l, nbm)
+    m.p_remain_rates = p_remain
+    g = torch.Generator(device=dev).manual_seed(42)
+    x = [torch.randn(16, F_lat, H_lat, W_lat, generator=g, device=dev)]
+    ctx = [torch.randn(100, 4096, generator=g, device=dev)]
+    m.enable_teacache(50, 0.15, task, use_ret_steps=True, enable=False)
+    return m, x, ctx, L, grid, cfg
+
+
+def wan_gemm_flops_per_forward(L, dim, ffn, layers, text_len=512):
+    """self-attention q,k,v,o + cross-attention q,o (L rows) and k,v (text rows) + ffn, per forward."""
+    per = 2.0 * L * dim * dim * 6 + 2.0 * text_len * dim * dim * 2 + 2.0 * L * dim * ffn * 2
+    return layers * per
+
+
+def wan_main(a, dev):
+    """--workload wan14b: BASELINE.json configs[3] as a standard line.  A step = one scheduler step = two CFG forwards
+    at the step's drop rate (jenga_wan.py:190-206 warm-up ramp, sa-drop 0.7 / 0.8, p-remain 0.8, dense <= 0.25); every
+    forward computed (TeaCache's polynomial is calibrated on the trained time embedding, so its skip count on random
+    weights is not meaningful -- the replayed count is reported beside the value)."""
+    from jenga_amd import _capi
+    from jenga_amd.prores import FlowMatchSchedule
+    from jenga_amd.wan_driver import sa_drop_rate_for_step
+    rates2 = a.rates or [0.7, 0.8]
+    p_remain = a.p_remain if a.p_remain is not None else 0.8
+    layers = a.depth[0] if a.depth else None
+    m, x, ctx, L, grid, cfg = wan_setup(dev, p_remain=p_remain, layers=layers)
+    sched = FlowMatchSchedule(50, shift=8.0)
+    rates = [round(sa_drop_rate_for_step(i, 50, rates2), 6) for i in range(50)]
+    counts = {}
+    for r in rates:
+        counts[r] = counts.get(r, 0) + 1
+    if a.steps >= 50:
+        plan, sampled = [rates[i % 50] for i in range(a.steps)], False
+    else:
+        prio = [r for r in (round(v, 6) for v in WAN_RATE_PRIORITY) if r in counts] + \
+               [r for r in sorted(counts) if r not in [round(v, 6) for v in WAN_RATE_PRIORITY]]
+        plan, sampled = [prio[j % len(prio)] for j in range(a.steps)], True
+
+    def step(rate):
+        for _ in range(2):      # conditional + unconditional stream (jenga_wan.py t2v_generate)
+            y = m(x, sched.timesteps[:1].to(dev), ctx, seq_len=L, sa_drop_rate=rate)[0]
+        return y
+
+    for w in range(a.warmup):
+        step(rates2[w % 2])
+    torch.cuda.synchronize()
+    _capi.ATTN_PROFILE = prof = _capi.AttnProfile()
+    power = PowerSampler().start()
+    evs = []
+    t0 = time.perf_counter()
+    for r in plan:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        y = step(r)
+        e1.record()
+        evs.append((r, e0, e1))
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    pw = power.stop()
+    _capi.ATTN_PROFILE = None
+    finite = bool(torch.isfinite(y).all().item())
+    cls = {}
+    for r, e0, e1 in evs:
+        cls.setdefault(r, []).append(e0.elapsed_time(e1))
+    mean = lambda v: sum(v) / len(v)
+    if sampled:
+        def class_ms(r):        # an unsampled ramp class takes the nearest sampled LOWER rate (slower: conservative)
+            if r in cls:
+                return mean(cls[r])
+            lower = [q_ for q_ in cls if q_ <= r]
+            return mean(cls[max(lower)] if lower else cls[min(cls)])
+        sec = sum(n * class_ms(r) for r, n in counts.items()) / 1e3
+        unsampled = sorted(r for r in counts if r not in cls)
+    else:
+        sec, unsampled = elapsed * 50.0 / len(plan), []
+    ps = prof.summary()
+    flops = ps["pairs"] * FLOPS_PER_PAIR
+    ach = flops / (ps["total_ms"] * 1e-3) / 1e12 if ps["total_ms"] > 0 else 0.0
+    # loop arithmetic over the timed steps: attention FLOPs of the realised lists + the dense linear algebra
+    gemm = wan_gemm_flops_per_forward(L, cfg["dim"], cfg["ffn_dim"], cfg["num_layers"]) * 2 * len(plan)
+    cross = 4.0 * L * 512 * cfg["dim"] * cfg["num_layers"] * 2 * len(plan)
+    res = {
+        "metric": "DiT denoising-loop sec/video (Wan2.1-14B 720p, 81f, 50 steps x 2 CFG forwards)",
+        "value": round(sec, 3), "unit": "s/video", "n_gpus": 1, "steps": a.steps, "warmup": a.warmup,
+        "ms_per_step": round(elapsed * 1e3 / max(len(plan), 1), 3), "higher_is_better": False, "scaling": "strong",
+        "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+        "config": {"workload": f"Wan2.1-14B T2V 1280x720x81f Jenga-Base on 1xMI355X (BASELINE.json configs[3], "
+                               f"scripts/wan_14B_jenga_base.sh): {L} tokens = {-(-L // 128)} blocks of 128, "
+                               f"{cfg['num_layers']} layers, dim {cfg['dim']}, {cfg['num_heads']} heads, ffn {cfg['ffn_dim']}, "
+                               "text context 512, weights resident (no offload)",
+                   "sa_drop_rates": rates2, "p_remain_rates": p_remain, "first_frame_blocks": -(-L // 128) // 21,
+                   "drop_rate_schedule": {str(r): n for r, n in sorted(counts.items())},
+                   "schedule": "full 50-step loop" if not sampled else
+                   f"sampled step classes {plan} (a step = two CFG forwards at that drop rate); sec/video = sum over the "
+                   "drop-rate classes of count x mean step time",
+                   "ms_per_step_by_drop_rate": {str(r): round(mean(v), 1) for r, v in sorted(cls.items())},
+                   "classes_not_sampled": unsampled, "teacache": "off: every forward computed",
+                   "qk_norm_gain": 4.0, "weights": "random init N(0,0.02), seed 0 (norm_q / norm_k weights x 4: peaked "
+                                                   "block softmax, top_k decides as in a trained model)",
+                   "finite_output": finite, "parallelism": "single GPU"},
+        "roofline": {"kernel": "jenga::bsattn_lp_kernel<bf16>", "bound": "mfma", "achieved": round(ach, 1),
+                     "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                     "launches": ps["launches"], "avg_launch_ms": round(ps["total_ms"] / max(ps["launches"], 1), 3),
+                     "kept_block_pairs_per_launch": ps["pairs"] // max(ps["launches"], 1),
+                     "algorithmic_flops": "4*128^3 per kept (128-query, 128-key) block pair, realised lists at 591 blocks x "
+                                          "40 heads (dense-branch launches of the warm-up ramp included)"},
+        "loop": {"flops_timed_steps": flops + gemm + cross, "attention_flops": flops, "gemm_flops": gemm + cross,
+                 "PFLOPs": round((flops + gemm + cross) / max(elapsed, 1e-9) / 1e15, 4),
+                 "frac_of_mfma_peak": round((flops + gemm + cross) / max(elapsed, 1e-9) / 1e12 / MFMA_PEAK_TFLOPS, 4)},
+        "power": pw,
+    }
+    if not a.no_cpu_baseline:
+        cb = cpu_baseline(rates2, p_remain, workload="wan14b")
+        res["cpu_baseline"] = {
+            "value": round(cb["s_per_layer"] * cfg["num_layers"] * 100, 1), "unit": "s/video", "cores": cb["cores"],
+            "kind": "port", "cpu_model": cb["cpu_model"], "logical_cpus": cb["logical"],
+            "sample": "reference PyTorch-CPU eager path restated in torch (oracle/eager_torch.py), one head x S = 75648 "
+                      f"(591 blocks, first_frame_blocks 28, sliced-Gilbert neighbours) in fp32 and bf16, time-capped and "
+                      f"extrapolated linearly in query rows; value = 40 heads x ({cb['best']} leg) x {cfg['num_layers']} layers "
+                      "x 100 forwards, self-attention + selection only",
+            "detail": cb["detail"]}
+    print(json.dumps(res))
+
+
+def wan_extra(dev):
+    """Short configs[3] leg of the default N=1 run (after the timed region): one warm-up + one timed Jenga forward of
+    the full Wan2.1-14B model at each of the two drop rates; sec/video as if all 100 forwards ran at those rates."""
+    from jenga_amd import _capi
+    from jenga_amd.prores import FlowMatchSchedule
+    m, x, ctx, L, grid, cfg = wan_setup(dev)
+    sched = FlowMatchSchedule(50, shift=8.0)
+    t = sched.timesteps[:1].to(dev)
+    m(x, t, ctx, seq_len=L, sa_drop_rate=0.8)
+    out = {}
+    for r in (0.7, 0.8):
+        torch.cuda.synchronize()
+        _capi.ATTN_PROFILE = prof = _capi.AttnProfile()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        m(x, t, ctx, seq_len=L, sa_drop_rate=r)
+        e1.record()
+        torch.cuda.synchronize()
+        _capi.ATTN_PROFILE = None
+        ps = prof.summary()
+        ach = ps["pairs"] * FLOPS_PER_PAIR / (ps["total_ms"] * 1e-3) / 1e12
+        out[str(r)] = {"ms_per_forward": round(e0.elapsed_time(e1), 1), "attention_TFLOPs": round(ach, 1),
+                       "attention_frac_of_peak": round(ach / MFMA_PEAK_TFLOPS, 4),
+                       "attention_avg_launch_ms": round(ps["total_ms"] / max(ps["launches"], 1), 3),
+                       "kept_block_pairs_per_launch": ps["pairs"] // max(ps["launches"], 1)}
+    # 50 steps x 2 forwards: steps 0-4 ramp up (counted at rate[0], slightly optimistic), 5-25 rate[0], 26-49 rate[1]
+    est = (2 * 26 * out["0.7"]["ms_per_forward"] + 2 * 24 * out["0.8"]["ms_per_forward"]) / 1e3
+    del m
+    torch.cuda.empty_cache()
+    return {"workload": f"Wan2.1-14B T2V 1280x720x81f Jenga-Base (BASELINE.json configs[3]): {L} tokens, 40 layers, dim 5120, "
+                        "40 heads, p-remain 0.8, qk-norm gain 4; `python bench.py --workload wan14b` is the full line",
+            "per_drop_rate": out, "s_per_video_two_rate_estimate": round(est, 1),
+            "note": "one timed forward per drop rate after one warm-up forward; estimate = 52 forwards at 0.7 + 48 at 0.8 "
+                    "(the five ramp steps of jenga_wan.py:205-206 counted at 0.7)"}
 
 
 def main():
@@ -277,6 +652,11 @@ def main():
 
     from jenga_amd import _capi, gemm_tuning
     from jenga_amd.dit import NON_SKIP_STEPS, JengaHYVideoDiT
+    if a.workload == "wan14b":
+        if world > 1 or sim > 1:
+            raise SystemExit("--workload wan14b is a single-GPU line (the reference's multi-GPU Wan path is USP / FSDP, not "
+                             "Jenga-aware: SURVEY.md §2)")
+        return wan_main(a, dev)
     gemm_file = None
     if a.gemm_tuning.startswith("record:"):
         gemm_file = gemm_tuning.enable(a.gemm_tuning[len("record:"):], tune=True)
@@ -408,6 +788,13 @@ def main():
     if int(os.environ.get("JENGA_GEMM_CANDIDATES", "1")) > 1:
         for k in range(len(stages)):      # one untimed computed step per stage: every GEMM shape gets its plan here
             run_step(next(i for i in computed_steps if stage_of(i, split) == k))
+        if world > 1:
+            # every rank timed candidates on its own: adopt rank 0's choices everywhere, so that the replicated text stream
+            # sees the same arithmetic on every rank (the imported index replaces each rank's plan; no further timing)
+            rec = _capi.linear_export_choices() if rank == 0 else None
+            box = [rec]
+            dist.broadcast_object_list(box, src=0)
+            _capi.linear_import_choices(box[0])
     for w in range(a.warmup):
         run_step(computed_steps[0] if w % 2 == 0 else computed_steps[-1])   # computed steps: fills previous_residual
     barrier()
@@ -415,6 +802,8 @@ def main():
     if sim_ex is not None:
         sim_ex.sim_us = 0.0
     evs = []
+    pair_marks = []      # cumulative kept block pairs after every timed step (device scalars: no synchronisation)
+    power = PowerSampler().start() if rank == 0 else None
     t0 = time.perf_counter()
     for i in plan:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -422,8 +811,10 @@ def main():
         out = run_step(i)
         e1.record()
         evs.append((i, e0, e1))
+        pair_marks.append(prof.pairs.clone() if prof.pairs is not None else None)
     barrier()
     elapsed = time.perf_counter() - t0
+    power_rec = power.stop() if power is not None else None
     _capi.ATTN_PROFILE = None
     if sim_ex is not None:
         sim_ex.sim_us_timed = sim_ex.sim_us
@@ -500,6 +891,28 @@ def main():
             traffic_tbps = round(traffic / (ps["total_ms"] / ps["launches"] * 1e-3) / 1e12, 3)
     flops = ps["pairs"] * FLOPS_PER_PAIR
     ach = flops / (ps["total_ms"] * 1e-3) / 1e12 if ps["total_ms"] > 0 else 0.0
+    # ---- whole-loop arithmetic: attention FLOPs of the realised lists (this rank's launches) + the dense linear algebra
+    #      of the blocks, per video, over `value`
+    step_pairs, prev = {}, 0
+    for (i, _, _), mk in zip(evs, pair_marks):
+        cur = int(mk.item()) if mk is not None else prev
+        step_pairs.setdefault(klass(i), []).append(cur - prev)
+        prev = cur
+    n_div = max(world, sim, 1)
+    stage_tokens = [(sh[0] * (sh[1] // 2) * (sh[2] // 2)) for sh in shapes]
+    attn_video = gemm_video = 0.0
+    for key, n in counts.items():
+        if key[1] != "c":
+            continue
+        pv = step_pairs.get(key) or [v for kk, vv in step_pairs.items() if kk[1] == "c" for v in vv]
+        attn_video += n * (sum(pv) / max(len(pv), 1)) * FLOPS_PER_PAIR
+        gemm_video += n * hy_gemm_flops_per_computed_step(stage_tokens[key[0]] // n_div, n_txt, len(model.double_blocks),
+                                                          len(model.single_blocks))
+    loop = {"attention_flops_per_video": attn_video, "gemm_flops_per_video": gemm_video,
+            "PFLOPs": round((attn_video + gemm_video) / max(sec_per_video, 1e-9) / 1e15, 4),
+            "frac_of_mfma_peak": round((attn_video + gemm_video) / max(sec_per_video, 1e-9) / 1e12 / MFMA_PEAK_TFLOPS, 4),
+            "note": "per rank: attention FLOPs of the realised kept lists (4*128^3 per pair) + 2*M*N*K of the blocks' linear "
+                    "layers over the computed steps of one video, divided by `value`; dense bf16 MFMA peak 2.5 PFLOP/s"}
     res = {
         "metric": "DiT denoising-loop sec/video (720p,125f,50 steps)",
         "value": round(sec_per_video, 3), "unit": "s/video", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -535,10 +948,11 @@ def main():
         "roofline": {"kernel": "jenga::bsattn_lp_kernel<bf16>" if (_capi.ATTN_DEFAULT_FLAGS & 8) else "jenga::bsattn_fwd_kernel<bf16>", "bound": "mfma", "achieved": round(ach, 1),
                      "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_PEAK_TFLOPS, 4),
                      "traffic": traffic, "traffic_TBps": traffic_tbps,
+                     "traffic_provenance": "derived, not read in this run: a committed per-kept-pair constant x this run's pairs",
                      "traffic_source": f"{pmc_rel}: memory-side bytes per kept block pair from separate rocprofv3 --pmc "
-                                       "passes (FETCH_SIZE / WRITE_SIZE with the guide's gfx950 corrections), x this "
-                                       "run's pairs per launch; traffic_TBps = traffic / avg_launch_ms (the fabric "
-                                       "roof beside the MFMA one: ~8 TB/s)",
+                                       "passes of this kernel on this workload (FETCH_SIZE / WRITE_SIZE with the guide's "
+                                       "gfx950 corrections), x this run's pairs per launch; traffic_TBps = traffic / "
+                                       "avg_launch_ms (the fabric roof beside the MFMA one: ~8 TB/s)",
                      "launches": ps["launches"],
                      "avg_launch_ms": round(ps["total_ms"] / max(ps["launches"], 1), 3),
                      "kept_block_pairs_per_launch": ps["pairs"] // max(ps["launches"], 1),
@@ -559,6 +973,9 @@ def main():
             "simulated_transfer_ms_per_computed_step": round(sim_ex.sim_us_timed / 1e3 / max(n_comp, 1), 2),
             "note": "transfer time posted on the side stream during the timed steps / computed steps; what is NOT hidden "
                     "shows up in value"}
+    res["loop"] = loop
+    if power_rec is not None:
+        res["power"] = power_rec
     if dense_ms is not None:
         res["dense_reference"] = {
             "s_per_video": round(50 * dense_ms / 1e3, 2), "ms_per_dense_step": round(dense_ms, 1),
@@ -566,9 +983,19 @@ def main():
             "note": "one computed step at sa-drop 0.0 (dense branch of the blocks, same kernels, every kv block kept), "
                     "final resolution, measured after the timed region; the dense loop computes all 50 steps "
                     "(no step skipping).  The reference's own ratio on H800: 1625 s / 310 s = 5.24 (README.md:80-82)"}
+    n_layers = len(model.double_blocks) + len(model.single_blocks)
+    if rank == 0 and world == 1 and sim <= 1 and not a.no_secondary:
+        st = stages[-1]
+        res["roofline_secondary"] = secondary_roofline(
+            dev, S_img=st["h2l"].numel(), S_txt=n_txt, top_k=int((1 - a.rates[0]) * (st["h2l"].numel() // 128)),
+            p_remain=a.p_remain, nbm=st["curve"][0][2])
+    if rank == 0 and world == 1 and sim <= 1 and not a.no_wan_extra and a.preset == "base" and not a.depth:
+        del model
+        torch.cuda.empty_cache()
+        res["extra"] = {"wan14b": wan_extra(dev)}
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         cb = cpu_baseline(a.rates, a.p_remain)
-        layers = len(model.double_blocks) + len(model.single_blocks)
+        layers = n_layers
         res["cpu_baseline"] = {
             "value": round(cb["s_per_layer"] * layers * len(computed_steps), 1), "unit": "s/video",
             "cores": cb["cores"], "kind": "port", "cpu_model": cb["cpu_model"], "logical_cpus": cb["logical"],

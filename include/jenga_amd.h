@@ -26,7 +26,8 @@ extern "C" {
 #endif
 
 #define JENGA_ABI_VERSION 3   /* 2: jenga_block_select(flags), jenga_bsattn_fwd(order), jenga_sp_qkv_prologue, jenga_order_by_count, jenga_linear
-                               * 3: jenga_sp_qkv_prologue takes (xq, xk) or xv alone; jenga_stream_delay; jenga_cross_attn_fwd */
+                               * 3: jenga_sp_qkv_prologue takes (xq, xk) or xv alone; jenga_stream_delay; jenga_cross_attn_fwd;
+                               *    jenga_linear_export_choices / _import_choices; jenga_linear refuses a workspace smaller than its plan's */
 
 enum { JENGA_OK = 0, JENGA_EINVAL = 1, JENGA_ELAUNCH = 2, JENGA_EUNSUPPORTED = 3 };
 enum { JENGA_BF16 = 0, JENGA_FP16 = 1 };
@@ -88,7 +89,9 @@ int jenga_rope_complex(void* stream, const void* x, void* out, const double* cos
  *   < s_rope (tables [rows, 64], head_dim 128), one rounding to bf16 -- bit-identical to jenga_rmsnorm_rows
  *   (weight_fp32) followed by jenga_rope_complex (fp32 in, bf16 out), without the two fp32 tensors in between.  The output
  *   row stride lets the rows land in a buffer padded to a multiple of 128 tokens (the op's zero padding,
- *   wan/modules/attention_block_triton_diffres.py:448-451).  cos == sin == NULL: norm + cast only (cross-attention q). */
+ *   wan/modules/attention_block_triton_diffres.py:448-451).  cos == sin == NULL: norm + cast only (cross-attention q).
+ *   The ROW index is the RoPE position: `rows` are ONE sequence (batch 1, as WanSelfAttention runs it); the call is
+ *   rejected when s_rope > rows. */
 int jenga_wan_norm_rope(void* stream, const void* x, void* out, const float* weight, const double* cos,
                         const double* sin, int64_t rows, int64_t C, int64_t x_row_stride, int64_t o_row_stride,
                         int64_t s_rope, float eps, int dtype);
@@ -130,8 +133,8 @@ int jenga_wan_gate_residual(void* stream, const float* x, const void* y, const f
  * row stride, the GELU epilogue into a strided destination, and gate / residual as alpha-vector / C-matrix.
  *     out[m, n] = act( gate[n] * sum_k x[m,k] w[n,k]  +  bias[n]  +  res[m, n] )
  *   x [M,K], w [N,K] (nn.Linear layout), res / out [M,N], all 16-bit `dtype`, row strides in elements (inner stride 1);
- *   bias [N] in dtype or NULL -- added AS GIVEN (when a gate is used the caller passes gate * bias, which is what
- *   apply_gate(linear(x)) means); gate fp32 [N] on the device or NULL (= 1); res NULL = no residual;
+ *   bias [N] in dtype (float32 with JENGA_BIAS_F32 in `act`) or NULL -- added AS GIVEN (when a gate is used the caller
+ *   passes gate * bias, which is what apply_gate(linear(x)) means); gate fp32 [N] on the device or NULL (= 1); res NULL = no residual;
  *   act: JENGA_ACT_GELU_TANH (mlp_act "gelu_tanh"; not together with gate / res) or JENGA_ACT_NONE.
  *   workspace: device scratch the library may use (64 MiB is plenty); fp32 accumulation, ONE rounding to dtype at the
  *   end (the eager reference rounds after the GEMM, after the gate multiply and after the residual add).
@@ -140,10 +143,21 @@ int jenga_wan_gate_residual(void* stream, const float* x, const void* y, const f
  * fc2 and linear2 (:297-315, 500; modulate_layers.py:53-68). */
 #define JENGA_ACT_NONE 0
 #define JENGA_ACT_GELU_TANH 1
+#define JENGA_BIAS_F32 256   /* OR-ed into `act` (ABI 3): bias is float32 [N] -- the gated bias gate * b stays unrounded */
 int jenga_linear(void* stream, const void* x, const void* w, const void* bias, const void* res, const float* gate,
                  void* out, int64_t M, int64_t N, int64_t K, int64_t x_row_stride, int64_t w_row_stride,
                  int64_t res_row_stride, int64_t out_row_stride, int act, void* workspace, int64_t workspace_bytes,
                  int dtype);
+/* Algorithm choices across the ranks of a job (ABI 3).  With JENGA_GEMM_CANDIDATES > 1 jenga_linear times the
+ * heuristic's first candidates when it first meets a shape; ranks timing on their own may choose differently, and the
+ * replicated text stream (models_mul_block_gc_ha_multigpu.py:196-214: every rank computes the same text rows) would then
+ * no longer be bit-identical across ranks.  export: the calling device's plans as records of 12 int64 (M, N, K, x stride,
+ * w stride, ldc, out stride, epilogue, mode, dtype, workspace bytes, index of the chosen algorithm in the heuristic's
+ * list); returns the number of plans (records beyond `capacity` are not written; records may be NULL to count).
+ * import: those choices are used from now on for these shapes on every device of this process, without timing. */
+int64_t jenga_linear_export_choices(int64_t* records, int64_t capacity);
+int jenga_linear_import_choices(const int64_t* records, int64_t n);
+
 
 /* jenga_qk_norm_rope_pool: jenga_rmsnorm_rope for Q AND K plus the two jenga_block_pool passes of a
  * layer in one kernel.  xq, xk [B, n_blocks*128, H, 128] share one set of strides (the q and k slices of a fused QKV

@@ -55,6 +55,8 @@ SIGNATURES = {
     "jenga_ulysses_unpack_heads": (_i32, [_vp, _vp, _vp] + [_i64] * 7),
     "jenga_stream_delay": (_i32, [_vp, ctypes.c_double]),
     "jenga_cross_attn_fwd": (_i32, [_vp] * 5 + [_i64] * 13 + [_f32, _i32]),
+    "jenga_linear_export_choices": (_i64, [_vp, _i64]),
+    "jenga_linear_import_choices": (_i32, [_vp, _i64]),
 }
 
 # the experiments library (libjenga_amd_exp.so, include/jenga_amd.h under JENGA_EXPERIMENTS) adds these
@@ -385,6 +387,10 @@ def wan_norm_rope(x, weight, cos64, sin64, s_rope, eps, out=None):
     `out` may be the first rows of a larger (block-padded) buffer."""
     _need_gpu(x, "wan_norm_rope")
     C = x.shape[-1]
+    if cos64 is not None and x.dim() > 2 and x.shape[:-2].numel() != 1:
+        # the kernel takes the flattened ROW index as the RoPE position: with a batch > 1 only the first s_rope rows would
+        # be rotated, each at the wrong position (the WanSelfAttention call site runs batch 1)
+        raise ValueError("wan_norm_rope: with RoPE tables the input must be one sequence ([S, C] or [1, S, C])")
     x2 = x.reshape(-1, C)
     if x2.stride(-1) != 1:
         x2 = x2.contiguous()
@@ -466,19 +472,38 @@ def gelu_tanh(x, out=None):
 
 
 ACT_NONE, ACT_GELU_TANH = 0, 1
+BIAS_F32 = 256      # OR-ed into jenga_linear's `act`: the bias vector is float32
 _GEMM_WORKSPACE = {}
 
 
 def _gemm_workspace(device):
-    key = str(device)
+    """One 64 MiB scratch buffer per (device, stream): two jenga_linear calls in flight on different streams (the
+    sequence-parallel blocks issue GEMMs beside the exchange stream) must not share split-K scratch."""
+    key = (str(device), torch.cuda.current_stream(device).cuda_stream)
     if key not in _GEMM_WORKSPACE:
         _GEMM_WORKSPACE[key] = torch.empty(64 << 20, dtype=torch.uint8, device=device)
     return _GEMM_WORKSPACE[key]
 
 
+def linear_export_choices():
+    """The current device's jenga_linear algorithm choices as an int64 tensor [n, 12] (CPU)."""
+    n = int(lib().jenga_linear_export_choices(None, 0))
+    rec = torch.zeros((max(n, 1), 12), dtype=torch.int64)
+    n2 = int(lib().jenga_linear_export_choices(ctypes.c_void_p(rec.data_ptr()), n))
+    return rec[: min(n, n2)]
+
+
+def linear_import_choices(records):
+    """records int64 [n, 12] (linear_export_choices of the rank whose choices everybody adopts)."""
+    rec = records.to(device="cpu", dtype=torch.int64).contiguous()
+    if rec.dim() != 2 or rec.shape[1] != 12:
+        raise ValueError("linear_import_choices: records must be int64 [n, 12]")
+    _check(lib().jenga_linear_import_choices(ctypes.c_void_p(rec.data_ptr()), rec.shape[0]), "jenga_linear_import_choices")
+
+
 def linear(x, weight, bias=None, act=ACT_NONE, gate=None, res=None, out=None):
     """out = act(gate * (x @ weight.T) + bias + res) in ONE hipBLASLt call (jenga_linear): x [..., K] with a uniform
-    row stride, weight [N, K] (nn.Linear layout), bias [N] (added as given), gate [N] or [1, N] (per-channel; the
+    row stride, weight [N, K] (nn.Linear layout), bias [N] (added as given; a float32 bias is passed on as float32), gate [N] or [1, N] (per-channel; the
     caller folds it into the bias), res / out [..., N] (may be strided views: the MLP half of the single-stream blocks'
     concat buffer).  fp32 accumulation, one rounding."""
     _need_gpu(x, "linear")
@@ -497,7 +522,11 @@ def linear(x, weight, bias=None, act=ACT_NONE, gate=None, res=None, out=None):
         if Mr != M or Nr != N or res.dtype != x.dtype:
             raise ValueError("linear: res must match out")
     if bias is not None:
-        bias = bias.reshape(-1).to(dtype=x.dtype).contiguous()
+        if bias.dtype == torch.float32:     # (the gated bias of proj / fc2 / linear2: kept unrounded)
+            act = int(act) | BIAS_F32
+            bias = bias.reshape(-1).contiguous()
+        else:
+            bias = bias.reshape(-1).to(dtype=x.dtype).contiguous()
         if bias.numel() != N:
             raise ValueError("linear: bias must have N entries")
     g32 = None

@@ -899,8 +899,9 @@ extern "C" int jenga_wan_norm_rope(void* stream, const void* x, void* out, const
                                    int64_t o_row_stride, int64_t s_rope, float eps, int dtype) {
     if (!x || !out || !weight || rows < 0 || C <= 0 || (C & 7) || C > 8192 || (x_row_stride & 7) || (o_row_stride & 7) ||
         ((uintptr_t)x & 15) || ((uintptr_t)out & 15) || ((uintptr_t)weight & 15) || ((cosT == nullptr) != (sinT == nullptr)) ||
-        s_rope < 0 || (cosT && (C & 127))) {
-        set_error("jenga_wan_norm_rope: bad arguments (C multiple of 8 -- of 128 with RoPE --, <= 8192)");
+        s_rope < 0 || (cosT && (C & 127)) || (cosT && s_rope > rows)) {
+        set_error("jenga_wan_norm_rope: bad arguments (C multiple of 8 -- of 128 with RoPE --, <= 8192; the rows are ONE "
+                  "sequence whose row index is the RoPE position: s_rope <= rows)");
         return JENGA_EINVAL;
     }
     if (dtype != JENGA_BF16 && dtype != JENGA_FP16) {

@@ -331,8 +331,14 @@ class PendingAttenCarve:
         self.w_v = self.ex.all_to_all(self.recvs[2:], self._views((2,)))
 
     def put_text(self, q, k, v, norm_w):
-        self.sp.prologue_fn(q, k, v, norm_w[0], norm_w[1], None, None, [f[:, self.S_img:] for f in self.fulls],
-                            self.Hn, self.r * self.Hn, self.Hn, 0)
+        outs = [f[:, self.S_img:] for f in self.fulls]
+        if v.stride() == q.stride():
+            self.sp.prologue_fn(q, k, v, norm_w[0], norm_w[1], None, None, outs, self.Hn, self.r * self.Hn, self.Hn, 0)
+        else:       # Q|K and V come from two GEMM outputs with different row strides: one launch each
+            self.sp.prologue_fn(q, k, None, norm_w[0], norm_w[1], None, None, [outs[0], outs[1], None], self.Hn,
+                                self.r * self.Hn, self.Hn, 0)
+            self.sp.prologue_fn(None, None, v, None, None, None, None, [None, None, outs[2]], self.Hn,
+                                self.r * self.Hn, self.Hn, 0)
 
     def post_packed(self, query, key, value, jq, jk, jv):
         """The reference-signature path: already normalised / rotated tensors, separate pack kernels."""

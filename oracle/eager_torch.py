@@ -17,7 +17,7 @@ import torch.nn.functional as F
 
 
 def build_block_mask(q_img, k, top_k, text_start_block, num_blocks, prob_threshold, text_blocks, neighbors=None,
-                     block=128):
+                     block=128, first_frame_blocks=0):
     """q_img [B,H,Sq,D], k [B,H,Sk,D] (any float dtype; the reference runs this in the tensor dtype) ->
     bool [B,H,nq,num_blocks].  Follows :216-293 line by line."""
     B, H, Sq, D = q_img.shape
@@ -37,6 +37,8 @@ def build_block_mask(q_img, k, top_k, text_start_block, num_blocks, prob_thresho
     if neighbors is not None:                                                             # :280-289
         nbm = torch.as_tensor(neighbors).bool()[:nq, :text_start_block]
         mask[:, :, :nbm.shape[0], :text_start_block] |= nbm[None, None]
+    if first_frame_blocks > 0:                                  # wan/modules/attention_block_triton_diffres.py:400-406
+        mask[:, :, :first_frame_blocks, :first_frame_blocks] = True
     if text_blocks > 0:                                                                   # :292-293
         mask[..., text_start_block:min(text_start_block + text_blocks, num_blocks)] = True
     return mask

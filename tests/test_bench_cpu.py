@@ -36,3 +36,23 @@ def test_presets_cover_the_reference_scripts_and_dense():
         assert len(p["res"]) == len(p["steps"]) == len(p["rates"]) == len(p["shifts"])
     assert bench.PRESETS["dense"]["rates"] == [0.0, 0.0] and bench.PRESETS["dense"]["skip"] is False
     assert bench.stage_of(25, [25, 50]) == 0 and bench.stage_of(26, [25, 50]) == 1
+
+
+def test_bench_line_helpers_and_keys():
+    """The measurement objects the driver record must carry: the helpers exist, the FLOP
+    model of a computed step matches the hand count, and the source assembles the keys."""
+    import bench
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    for key in ('"roofline_secondary"', '"loop"', '"power"', '"traffic_provenance"', '"cpu_baseline"', '"extra"',
+                '"dense_reference"'):
+        assert f"res[{key}]" in src or f"{key}:" in src, key
+    # one computed forward at the 720p shape: 1.57 PFLOP of GEMMs (SURVEY.md 8 a12)
+    fl = bench.hy_gemm_flops_per_computed_step(115200, 256, 20, 40)
+    assert abs(fl / 1.57e15 - 1) < 0.01, fl
+    ps = bench.PowerSampler(period=0.01).start()
+    rec = ps.stop()
+    assert "available" in rec
+    assert bench.WAN_RATE_PRIORITY[:2] == [0.7, 0.8]
+    # Wan2.1-14B forward: 40 layers x (6 dim^2 + 2 dim*ffn) x 2L flops
+    w = bench.wan_gemm_flops_per_forward(75600, 5120, 13824, 40)
+    assert 1.7e15 < w < 2.0e15, w

@@ -108,19 +108,19 @@ def test_ctypes_signatures_match_the_header_parameter_by_parameter():
     header = open(os.path.join(ROOT, "include", "jenga_amd.h")).read()
     header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
     kinds = {ctypes.c_void_p: "ptr", ctypes.c_char_p: "ptr", ctypes.c_int64: "i64", ctypes.c_int: "int",
-             ctypes.c_float: "float", ctypes.c_size_t: "size"}
+             ctypes.c_float: "float", ctypes.c_size_t: "size", ctypes.c_double: "double"}
 
     def kind_of(param):
         param = param.strip()
         if "*" in param:
             return "ptr"
         t = param.rsplit(" ", 1)[0].replace("const", "").strip()
-        return {"int64_t": "i64", "int": "int", "float": "float", "size_t": "size"}[t]
+        return {"int64_t": "i64", "int": "int", "float": "float", "size_t": "size", "double": "double"}[t]
 
     sigs = dict(_capi.SIGNATURES)
     sigs.update(_capi.EXPERIMENT_SIGNATURES)
     for name, (_res, args) in sigs.items():
-        m = re.search(r"\b(?:int|size_t|const char\s*\*)\s*" + name + r"\s*\(([^;]*?)\)\s*;", header, re.S)
+        m = re.search(r"\b(?:int64_t|int|size_t|const char\s*\*)\s*" + name + r"\s*\(([^;]*?)\)\s*;", header, re.S)
         assert m, f"{name}: declaration not found"
         params = [p_ for p_ in m.group(1).split(",") if p_.strip() and p_.strip() != "void"]
         assert len(params) == len(args), f"{name}: header has {len(params)} parameters, ctypes {len(args)}"

@@ -190,3 +190,42 @@ def test_linear_epilogues_vs_fp32_reference(dev, dt, M, N, K):
     assert float(e_f.mean()) <= float(e_u.mean())        # one rounding is closer to exact than three
     with pytest.raises(_capi.JengaError):
         _capi.linear(x, w, b, act=_capi.ACT_GELU_TANH, res=res)
+
+
+def test_linear_choices_export_import_roundtrip(dev):
+    """jenga_linear_export_choices / _import_choices (rank 0's hipBLASLt choices adopted by every rank: the replicated
+    text stream must see the same arithmetic everywhere): importing a device's own choices reproduces its results bit
+    for bit, and a forced choice is honoured without timing."""
+    from jenga_amd import _capi
+    g = torch.Generator(device=dev).manual_seed(3)
+    x = torch.randn(1, 640, 512, generator=g, device=dev, dtype=torch.bfloat16)
+    w = torch.randn(768, 512, generator=g, device=dev, dtype=torch.bfloat16) * 0.05
+    b = torch.randn(768, generator=g, device=dev, dtype=torch.bfloat16)
+    y0 = _capi.linear(x, w, b, act=_capi.ACT_GELU_TANH)
+    rec = _capi.linear_export_choices()
+    assert rec.dim() == 2 and rec.shape[1] == 12 and rec.shape[0] >= 1
+    mine = [r for r in rec.tolist() if r[0] == 640 and r[1] == 768 and r[2] == 512]
+    assert mine and 0 <= mine[0][11] < 32
+    _capi.linear_import_choices(rec)                     # drops the plans; the next call rebuilds them from the record
+    y1 = _capi.linear(x, w, b, act=_capi.ACT_GELU_TANH)
+    assert torch.equal(y0, y1)
+    assert _capi.linear_export_choices().shape[0] >= 1
+    with pytest.raises(_capi.JengaError):
+        bad = rec.clone()
+        bad[0, 11] = 99
+        _capi.linear_import_choices(bad)
+    with pytest.raises(ValueError):
+        _capi.linear_import_choices(torch.zeros(3, 5, dtype=torch.int64))
+
+
+def test_wan_norm_rope_rejects_a_batch_with_rope_tables(dev):
+    from jenga_amd import _capi
+    x = torch.randn(2, 64, 256, device=dev).to(torch.bfloat16)
+    wgt = torch.ones(256, device=dev)
+    cs = torch.ones(64, 64, dtype=torch.float64, device=dev)
+    with pytest.raises(ValueError):
+        _capi.wan_norm_rope(x, wgt, cs, cs, 64, 1e-6)
+    _capi.wan_norm_rope(x, wgt, None, None, 0, 1e-6)      # norm + cast only: any leading shape
+    with pytest.raises(_capi.JengaError):                 # the C entry: s_rope beyond the rows of the one sequence
+        _capi._check(_capi.lib().jenga_wan_norm_rope(None, _capi._p(x), _capi._p(x), _capi._p(wgt), _capi._p(cs),
+                                                     _capi._p(cs), 32, 256, 256, 256, 64, 1e-6, 0), "jenga_wan_norm_rope")
