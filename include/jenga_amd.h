@@ -265,6 +265,9 @@ int jenga_bsattn_fwd(void* stream, const void* q, const void* k, const void* vt,
                                   8-wave workgroups, MFMA / softmax phases of the two waves per SIMD in anti-phase */
 #define JENGA_ATTN_LP 8        /* same decomposition, in-wave software pipeline (softmax inside the MFMA stream):
                                   csrc/bsattn3.hip, the default of the Python modules (XCD_REMAP | LP) */
+#define JENGA_ATTN_COHORT 32   /* EXPERIMENT (round 4, LP kernel with XCD_REMAP only): the workgroups an XCD runs at a time
+                                  start together (arrival counters, bounded spin) and walk their lists in step: L2 hits
+                                  for fabric bytes; launches with this flag must not overlap on one device */
 /* order (may be NULL): int32 [B,H,nq_img], launch position -> image query block, a permutation per (b, h) -- a
  *   scheduling hint only (every query block is computed exactly once either way, results are bit-identical).
  *   jenga_order_by_count fills it from cnt: inside every segment of `segment` consecutive query blocks the blocks are
@@ -307,9 +310,11 @@ int jenga_bsattn_pair_fwd(void* stream, const void* q, const void* k, const void
  * row attends to ALL nkv_blocks*128 keys, softmax(q.k^T * sm_scale) in fp32, P rounded to dtype before P.V.
  * The same kernel as the text rows of jenga_bsattn_fwd (LP kernel, TEXT mode), with a kv sequence of its own
  * length.  q [B, nq_blocks*128, H, 128] strided (pad the last block; padded rows produce padded output rows),
- * k [B, nkv_blocks*128, H, 128] strided, vt = jenga_pack_v(v, n_blocks = nkv_blocks), o like q. */
+ * k [B, nkv_blocks*128, H, 128] strided, vt = jenga_pack_v(v, n_blocks = nkv_blocks), o like q.  Keys >= kv_len
+ * (kv_len inside the last kv block: the buffers are padded to whole blocks, their contents there are ignored) are
+ * masked out -- the reference's 512-token context needs none, a shorter context does. */
 int jenga_cross_attn_fwd(void* stream, const void* q, const void* k, const void* vt, void* o, int64_t B, int64_t H,
-                         int64_t nq_blocks, int64_t nkv_blocks, int64_t q_sb, int64_t q_ss, int64_t q_sh,
+                         int64_t nq_blocks, int64_t nkv_blocks, int64_t kv_len, int64_t q_sb, int64_t q_ss, int64_t q_sh,
                          int64_t k_sb, int64_t k_ss, int64_t k_sh, int64_t o_sb, int64_t o_ss, int64_t o_sh,
                          float sm_scale, int dtype);
 

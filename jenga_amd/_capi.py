@@ -16,6 +16,7 @@ ATTN_PINGPONG = 2    # experiment: needs libjenga_amd_exp.so (python -m jenga_am
 ATTN_LEGACY = 0      # (readability alias) no kernel bit: the round-1 kernel, one query block per 4-wave workgroup
 ATTN_LP = 8          # round-1 decomposition + in-wave software pipeline (csrc/bsattn3.hip): the default
 ATTN_SORTED = 16     # (Python-side) kept-count-aware launch order: jenga_order_by_count feeds jenga_bsattn_fwd's `order`
+ATTN_COHORT = 32     # experiment (round 4): cohort start barrier per XCD generation (LP kernel + XCD remap)
 ATTN_PAIR = 64       # (Python-side, experiment) route to jenga_bsattn_pair_fwd: the pair kernel; with ATTN_LP the 8-wave
 #                      LP pair (csrc/experiments/); needs libjenga_amd_exp.so
 # default: LP kernel, XCD remap, kept-count-aware order inside every XCD's range (+3.3 % sustained on lists whose counts
@@ -54,7 +55,7 @@ SIGNATURES = {
     "jenga_ulysses_pack_heads": (_i32, [_vp, _vp, _vp] + [_i64] * 7),
     "jenga_ulysses_unpack_heads": (_i32, [_vp, _vp, _vp] + [_i64] * 7),
     "jenga_stream_delay": (_i32, [_vp, ctypes.c_double]),
-    "jenga_cross_attn_fwd": (_i32, [_vp] * 5 + [_i64] * 13 + [_f32, _i32]),
+    "jenga_cross_attn_fwd": (_i32, [_vp] * 5 + [_i64] * 14 + [_f32, _i32]),
     "jenga_linear_export_choices": (_i64, [_vp, _i64]),
     "jenga_linear_import_choices": (_i32, [_vp, _i64]),
 }
@@ -696,7 +697,7 @@ def bsattn_fwd(q, k, vt, seqlens, idx, cnt, nq_img, sm_scale, text_amp, text_blo
             e0.record()
         common = (B, H, n_blocks, nq_img, *_bshd_strides(q), *_bshd_strides(k), *_bshd_strides(out), float(sm_scale),
                   float(text_amp), int(text_block_start), dtype_code(q.dtype))
-        cflags = fl & (ATTN_XCD_REMAP | ATTN_PINGPONG | ATTN_LP)
+        cflags = fl & (ATTN_XCD_REMAP | ATTN_PINGPONG | ATTN_LP | ATTN_COHORT)
         if not pair:
             _check(lib().jenga_bsattn_fwd(_stream(q.device), _p(q), _p(k), _p(vt), _p(out), _p(seqlens), _p(idx),
                                           _p(cnt), _p(order_t), *common, cflags), "jenga_bsattn_fwd")
@@ -716,21 +717,24 @@ def bsattn_fwd(q, k, vt, seqlens, idx, cnt, nq_img, sm_scale, text_amp, text_blo
     return out
 
 
-def cross_attn_fwd(q, k, v, sm_scale=None, out=None):
+def cross_attn_fwd(q, k, v, sm_scale=None, out=None, kv_len=None):
     """Dense cross-attention (WanT2VCrossAttention): q [B,Sq,H,128], k / v [B,Skv,H,128], Sq and Skv multiples of 128
-    (pad the buffers; rows are independent) -> o [B,Sq,H,128]; every query row sees all Skv keys."""
+    (pad the buffers; query rows are independent, keys >= kv_len are masked) -> o [B,Sq,H,128]."""
     _need_gpu(q, "cross_attn_fwd")
     B, Sq, H, D = q.shape
     Skv = k.shape[1]
     if D != 128 or Sq % 128 or Skv % 128 or Sq == 0 or Skv == 0 or tuple(k.shape) != (B, Skv, H, 128) \
             or v.shape != k.shape or k.dtype != q.dtype or v.dtype != q.dtype:
         raise ValueError("cross_attn_fwd: q [B,Sq,H,128], k / v [B,Skv,H,128] of one dtype, Sq and Skv multiples of 128")
+    kv_len = Skv if kv_len is None else int(kv_len)
+    if not (Skv - 128 < kv_len <= Skv):
+        raise ValueError("cross_attn_fwd: kv_len must lie inside the last 128-key block of k / v")
     if out is None:
         out = torch.empty((B, Sq, H, 128), dtype=q.dtype, device=q.device)
     vt = pack_v(v, Skv // 128)
     with torch.cuda.device(q.device):
         _check(lib().jenga_cross_attn_fwd(_stream(q.device), _p(q), _p(k), _p(vt), _p(out), B, H, Sq // 128, Skv // 128,
-                                          *_bshd_strides(q), *_bshd_strides(k), *_bshd_strides(out),
+                                          kv_len, *_bshd_strides(q), *_bshd_strides(k), *_bshd_strides(out),
                                           float(D ** -0.5 if sm_scale is None else sm_scale), dtype_code(q.dtype)),
                "jenga_cross_attn_fwd")
     return out

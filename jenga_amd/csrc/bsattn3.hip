@@ -31,6 +31,8 @@
 // stream is in-order, so each of these took instructions out of the gaps between its MFMAs: MFMA-pipe busy 64 % -> 79 %
 // (profiles/r02_pmc_bsattn_lp*.json).  The first step, the < 6 remainder steps, the tail blocks that need text_amp or
 // the kv-length mask, and the text rows use the generic forms (LP_STEP, lp_slow_tile).
+#include <cstdlib>
+
 #include "lp_core.h"
 
 namespace jenga {
@@ -52,12 +54,15 @@ struct LpParams {
     float text_amp;
     int n_text_q;    // query blocks that run in TEXT mode (all kv blocks, no list, no mask) and the first of them
     int q_text0;
+    int text_kv_len; // > 0 (jenga_cross_attn_fwd): TEXT-mode rows see keys < text_kv_len only (the last tile may be ragged)
     int n_text_wg_pad;
     int img_per_head;
     int xcd_chunk;
 };
 
-template <typename T, bool TEXT>
+// XKV: the cross-attention instantiation (TEXT rows against a kv sequence whose last tile may be ragged); a template
+// parameter so that the product kernel's code (and its register allocation) is exactly what it is without that path
+template <typename T, bool TEXT, bool XKV = false>
 __device__ __forceinline__ void attn_block_lp(const LpParams& P, unsigned char* smem, int b, int h, int m) {
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -210,7 +215,11 @@ __device__ __forceinline__ void attn_block_lp(const LpParams& P, unsigned char* 
     if (!TEXT) {
         while (t_all > 0 && blk_at((t_all - 1) >> 1) * 128 + ((t_all - 1) & 1) * 64 >= seqlen) --t_all;
     }
-    const int t_fast = 2 * n_fast < t_all ? 2 * n_fast : t_all;
+    int t_fast = 2 * n_fast < t_all ? 2 * n_fast : t_all;
+    if (XKV && P.text_kv_len > 0) {     // cross-attention: whole tiles in the pipeline, the ragged one in the slow form
+        t_all = (P.text_kv_len + 63) >> 6;
+        t_fast = P.text_kv_len >> 6;
+    }
 
     f32x16 sA, sB;
     uint4 pfA[2], pfB[2];
@@ -277,15 +286,19 @@ __device__ __forceinline__ void attn_block_lp(const LpParams& P, unsigned char* 
 #undef LP_STEP_C
 #undef LP_PRE0
 #undef LP_PRE1
-    if (!TEXT) {
+    if (!TEXT || (XKV && P.text_kv_len > 0)) {
         for (int t = t_fast; t < t_all; ++t) {
             issue_v(t);
             issue_k(t + 2);
             LP_WAIT_ALL();   // this step reads V^T(t) itself
             __syncthreads();
             const int blk = blk_at(t >> 1);
-            lp_slow_tile<T>(st, kslot(t), vslot(t), blk * 128 + (t & 1) * 64, blk >= P.text_block_start, P.text_amp,
-                            seqlen, hi, k_addr, v_addr);
+            if (TEXT)
+                lp_slow_tile<T, true>(st, kslot(t), vslot(t), blk * 128 + (t & 1) * 64, false, 0.f, P.text_kv_len, hi,
+                                      k_addr, v_addr, P.qk_scale);
+            else
+                lp_slow_tile<T>(st, kslot(t), vslot(t), blk * 128 + (t & 1) * 64, blk >= P.text_block_start, P.text_amp,
+                                seqlen, hi, k_addr, v_addr);
             __syncthreads();
         }
     }
@@ -307,8 +320,21 @@ __device__ __forceinline__ void attn_block_lp(const LpParams& P, unsigned char* 
     }
 }
 
+// JENGA_ATTN_COHORT (round-4 experiment): the workgroups an XCD runs at a time start TOGETHER -- one arrival counter per
+// XCD and per generation of `size` consecutive launch positions, bounded spin -- so that they walk their ascending lists
+// in step and meet in the XCD's L2.  The configuration lives in a device global written on the launch stream, NOT in
+// LpParams: the kernel sits at 256 VGPRs and a longer kernarg block moves spill reloads into the unrolled main loop.
+struct CohortCfg {
+    int* ctr;
+    int size, stride, timeout;   // timeout in wall-clock ticks (100 MHz)
+    int quorum;                  // arrivals a member waits for (<= size): the stragglers of a generation start late
+};
+__device__ CohortCfg g_cohort_cfg;
+
 #define LP_THREADS 256
-template <typename T>
+// VARIANT 0: the product kernel.  1: + the cohort start barrier.  2: dense cross-attention (jenga_cross_attn_fwd):
+// TEXT-mode rows only, kv-length mask on the last tile.  Separate instantiations on purpose (see above).
+template <typename T, int VARIANT>
 __global__ void __launch_bounds__(LP_THREADS, 2) bsattn_lp_kernel(LpParams P) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int n_text = P.n_text_q;
@@ -317,9 +343,10 @@ __global__ void __launch_bounds__(LP_THREADS, 2) bsattn_lp_kernel(LpParams P) {
         if (id >= P.B * P.H * n_text) return;
         const int m = P.q_text0 + id % n_text;
         const int bh = id / n_text;
-        attn_block_lp<T, true>(P, smem, bh / P.H, bh % P.H, m);
+        attn_block_lp<T, true, VARIANT == 2>(P, smem, bh / P.H, bh % P.H, m);
         return;
     }
+    if (VARIANT == 2) return;
     const int li = id - P.n_text_wg_pad;
     const int bh = li / P.img_per_head;
     const int r = li % P.img_per_head;
@@ -330,8 +357,37 @@ __global__ void __launch_bounds__(LP_THREADS, 2) bsattn_lp_kernel(LpParams P) {
     } else {
         m = r;
     }
+    if (VARIANT == 1) {
+        if (threadIdx.x == 0) {
+            const CohortCfg C = g_cohort_cfg;
+            const int x = r & 7, pos = r >> 3;
+            int nv = P.nq_img - x * P.xcd_chunk;                 // valid launch positions of this XCD per (b, h)
+            nv = nv < P.xcd_chunk ? nv : P.xcd_chunk;
+            const int seq = bh * nv + pos, total = P.B * P.H * nv;
+            const int gen = seq / C.size;
+            int members = total - gen * C.size;
+            members = members < C.size ? members : C.size;
+            members = members < C.quorum ? members : C.quorum;
+            int* c = C.ctr + x * C.stride + gen;
+            __hip_atomic_fetch_add(c, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const long long t0 = (long long)wall_clock64();
+            while (__hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < members &&
+                   (long long)wall_clock64() - t0 < C.timeout)
+                __builtin_amdgcn_s_sleep(16);
+        }
+        __syncthreads();
+    }
     if (P.order) m = P.order[(long long)bh * P.nq_img + m];   // kept-count-aware order inside the XCD's range
     attn_block_lp<T, false>(P, smem, bh / P.H, bh % P.H, m);
+}
+
+template <typename T, int VARIANT>
+static hipError_t lp_launch(const LpParams& P, long long grid, hipStream_t stream) {
+    const size_t smem = LP_LDS_BYTES;
+    (void)hipFuncSetAttribute((const void*)bsattn_lp_kernel<T, VARIANT>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)smem);
+    hipLaunchKernelGGL((bsattn_lp_kernel<T, VARIANT>), dim3((unsigned)grid), dim3(LP_THREADS), smem, stream, P);
+    return hipGetLastError();
 }
 
 }  // namespace
@@ -365,6 +421,7 @@ int jenga_bsattn_lp_launch(void* stream, const void* q, const void* k, const voi
     const long long n_text_wg = B * H * n_text;
     P.n_text_q = (int)n_text;
     P.q_text0 = (int)nq_img;
+    P.text_kv_len = 0;
     P.n_text_wg_pad = (int)((n_text_wg + 7) / 8 * 8);
     if ((flags & JENGA_ATTN_XCD_REMAP) && nq_img >= 64) {
         P.xcd_chunk = (int)((nq_img + 7) / 8);
@@ -382,17 +439,38 @@ int jenga_bsattn_lp_launch(void* stream, const void* q, const void* k, const voi
         set_error("jenga_bsattn_fwd: grid size %lld out of range", grid);
         return JENGA_EINVAL;
     }
-    const size_t smem = LP_LDS_BYTES;
-    if (dtype == JENGA_BF16) {
-        (void)hipFuncSetAttribute((const void*)bsattn_lp_kernel<BF16>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)smem);
-        hipLaunchKernelGGL(bsattn_lp_kernel<BF16>, dim3((unsigned)grid), dim3(LP_THREADS), smem, (hipStream_t)stream, P);
-    } else {
-        (void)hipFuncSetAttribute((const void*)bsattn_lp_kernel<FP16>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)smem);
-        hipLaunchKernelGGL(bsattn_lp_kernel<FP16>, dim3((unsigned)grid), dim3(LP_THREADS), smem, (hipStream_t)stream, P);
+    bool cohort = false;
+    if ((flags & JENGA_ATTN_COHORT) && P.xcd_chunk) {
+        // EXPERIMENT: one lazily allocated counter block per device, zeroed on the launch stream in front of every launch,
+        // the configuration written to the device global the same way -- launches with this flag must not overlap on one
+        // device
+        static int* ctr[64] = {nullptr};
+        constexpr int STRIDE = 4096;
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        int size = 64, timeout_us = 300;
+        if (const char* ev = getenv("JENGA_COHORT_SIZE")) size = atoi(ev);
+        if (const char* ev = getenv("JENGA_COHORT_TIMEOUT_US")) timeout_us = atoi(ev);
+        int quorum = size;
+        if (const char* ev = getenv("JENGA_COHORT_QUORUM")) quorum = atoi(ev);
+        if (quorum < 1 || quorum > size) quorum = size;
+        const long long gens = size > 0 ? (B * H * (long long)P.xcd_chunk + size - 1) / size : STRIDE;
+        if (dev >= 0 && dev < 64 && size > 0 && gens < STRIDE) {
+            if (!ctr[dev] && hipMalloc((void**)&ctr[dev], 8 * STRIDE * sizeof(int)) != hipSuccess) ctr[dev] = nullptr;
+            CohortCfg cfg{ctr[dev], size, STRIDE, timeout_us * 100, quorum};
+            if (ctr[dev] && hipMemsetAsync(ctr[dev], 0, 8 * STRIDE * sizeof(int), (hipStream_t)stream) == hipSuccess &&
+                hipMemcpyToSymbolAsync(HIP_SYMBOL(g_cohort_cfg), &cfg, sizeof(cfg), 0, hipMemcpyHostToDevice,
+                                       (hipStream_t)stream) == hipSuccess)
+                cohort = true;
+        }
     }
-    hipError_t e = hipGetLastError();
+    hipError_t e;
+    if (cohort)
+        e = dtype == JENGA_BF16 ? lp_launch<BF16, 1>(P, grid, (hipStream_t)stream)
+                                : lp_launch<FP16, 1>(P, grid, (hipStream_t)stream);
+    else
+        e = dtype == JENGA_BF16 ? lp_launch<BF16, 0>(P, grid, (hipStream_t)stream)
+                                : lp_launch<FP16, 0>(P, grid, (hipStream_t)stream);
     if (e != hipSuccess) {
         set_error("jenga_bsattn_fwd (lp): %s", hipGetErrorString(e));
         return JENGA_ELAUNCH;
@@ -404,15 +482,16 @@ int jenga_bsattn_lp_launch(void* stream, const void* q, const void* k, const voi
 // sm_scale * log2 e, no kv-length mask, no list) against a kv sequence of its OWN length.  Replaces the flash_attention
 // call of WanT2VCrossAttention (wan/modules/model_mul.py:183-205: 512 context tokens, k_lens = None).
 extern "C" int jenga_cross_attn_fwd(void* stream, const void* q, const void* k, const void* vt, void* o, int64_t B,
-                                    int64_t H, int64_t nq_blocks, int64_t nkv_blocks, int64_t q_sb, int64_t q_ss,
+                                    int64_t H, int64_t nq_blocks, int64_t nkv_blocks, int64_t kv_len, int64_t q_sb, int64_t q_ss,
                                     int64_t q_sh, int64_t k_sb, int64_t k_ss, int64_t k_sh, int64_t o_sb, int64_t o_ss,
                                     int64_t o_sh, float sm_scale, int dtype) {
     auto bad8 = [](int64_t a, int64_t b_, int64_t c) { return (a & 7) || (b_ & 7) || (c & 7); };
-    if (!q || !k || !vt || !o || B <= 0 || H <= 0 || nq_blocks <= 0 || nkv_blocks <= 0 || bad8(q_sb, q_ss, q_sh) ||
+    if (!q || !k || !vt || !o || B <= 0 || H <= 0 || nq_blocks <= 0 || nkv_blocks <= 0 || kv_len <= 0 ||
+        kv_len > nkv_blocks * 128 || kv_len <= (nkv_blocks - 1) * 128 || bad8(q_sb, q_ss, q_sh) ||
         bad8(k_sb, k_ss, k_sh) || bad8(o_sb, o_ss, o_sh) || ((uintptr_t)q & 15) || ((uintptr_t)k & 15) ||
         ((uintptr_t)vt & 15) || ((uintptr_t)o & 7) || k_ss < 0 || k_ss >= (1LL << 31)) {
         set_error("jenga_cross_attn_fwd: bad arguments (non-null 16-B aligned pointers, strides multiples of 8 elements, "
-                  "at least one query and one kv block)");
+                  "at least one query block, kv_len inside the last of the nkv_blocks kv blocks)");
         return JENGA_EINVAL;
     }
     if (dtype != JENGA_BF16 && dtype != JENGA_FP16) {
@@ -431,6 +510,7 @@ extern "C" int jenga_cross_attn_fwd(void* stream, const void* q, const void* k, 
     P.text_amp = 0.f;
     P.n_text_q = (int)nq_blocks;
     P.q_text0 = 0;
+    P.text_kv_len = (kv_len == nkv_blocks * 128) ? 0 : (int)kv_len;     // 0: every tile whole, no mask needed
     const long long wg = B * H * nq_blocks;
     P.n_text_wg_pad = (int)((wg + 7) / 8 * 8);
     P.xcd_chunk = 0;
@@ -439,19 +519,8 @@ extern "C" int jenga_cross_attn_fwd(void* stream, const void* q, const void* k, 
         set_error("jenga_cross_attn_fwd: grid size %lld out of range", wg);
         return JENGA_EINVAL;
     }
-    const size_t smem = LP_LDS_BYTES;
-    if (dtype == JENGA_BF16) {
-        (void)hipFuncSetAttribute((const void*)bsattn_lp_kernel<BF16>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)smem);
-        hipLaunchKernelGGL(bsattn_lp_kernel<BF16>, dim3((unsigned)P.n_text_wg_pad), dim3(LP_THREADS), smem,
-                           (hipStream_t)stream, P);
-    } else {
-        (void)hipFuncSetAttribute((const void*)bsattn_lp_kernel<FP16>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)smem);
-        hipLaunchKernelGGL(bsattn_lp_kernel<FP16>, dim3((unsigned)P.n_text_wg_pad), dim3(LP_THREADS), smem,
-                           (hipStream_t)stream, P);
-    }
-    hipError_t e = hipGetLastError();
+    const hipError_t e = dtype == JENGA_BF16 ? lp_launch<BF16, 2>(P, P.n_text_wg_pad, (hipStream_t)stream)
+                                             : lp_launch<FP16, 2>(P, P.n_text_wg_pad, (hipStream_t)stream);
     if (e != hipSuccess) {
         set_error("jenga_cross_attn_fwd: %s", hipGetErrorString(e));
         return JENGA_ELAUNCH;

@@ -248,10 +248,12 @@ __device__ __forceinline__ void lp_bb(LpState& st, const unsigned char* kt, cons
 }
 
 // a whole 64-key tile, unpipelined, with the text_amp add and the kv-length mask (tail of the ascending lists)
-template <typename T>
+// TEXT (dense mode: unscaled Q in the registers, the scale applied to the fp32 scores): the ragged last tile of a
+// cross-attention kv sequence (jenga_cross_attn_fwd with kv_len not a multiple of 64)
+template <typename T, bool TEXT = false>
 __device__ __forceinline__ void lp_slow_tile(LpState& st, const unsigned char* kt, const unsigned char* vt, int key0,
                                              bool amp_on, float text_amp, int seqlen, int hi,
-                                             const int (&k_addr)[8], const int (&v_addr)[4]) {
+                                             const int (&k_addr)[8], const int (&v_addr)[4], float qk_scale = 0.f) {
     if (key0 >= seqlen) return;   // contributes exp2(-inf) = 0
     f32x16 zero16;
 #pragma unroll
@@ -280,7 +282,7 @@ __device__ __forceinline__ void lp_slow_tile(LpState& st, const unsigned char* k
         }
         uint4 pf[2];
         float psum = 0.f;
-        lp_exact<T, false>(st, s, pf, psum, 0.f, nullptr);
+        lp_exact<T, TEXT>(st, s, pf, psum, qk_scale, nullptr);
         st.l += psum;
         uint4 va[2][4];
 #pragma unroll

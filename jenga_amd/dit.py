@@ -92,7 +92,7 @@ GATED_BIAS_F32 = os.environ.get("JENGA_GATED_BIAS", "f32") != "bf16"
 # SP_MLP_TAIL share of the MLP columns is held back and issued behind the attention, under the O exchange.  Double-stream
 # blocks: the Q|K GEMM is followed by the Q, K exchange, the V GEMM and the whole text stream run under it.
 SP_OVERLAP = os.environ.get("JENGA_SP_OVERLAP", "1") != "0"
-SP_MLP_TAIL = float(os.environ.get("JENGA_SP_MLP_TAIL", "0.5"))
+SP_MLP_TAIL = float(os.environ.get("JENGA_SP_MLP_TAIL", "0.375"))
 
 
 def linear_gate_residual(lin, x, gate, res, gate2=None, mask=None):

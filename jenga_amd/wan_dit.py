@@ -61,24 +61,31 @@ class WanT2VCrossAttention(nn.Module):
             raise ValueError("jenga_amd Wan cross-attention: context_lens must be None (the Jenga driver passes None)")
         b, n, d = x.shape[0], self.num_heads, self.head_dim
         L, Lc = x.shape[1], context.shape[1]
-        if b != 1 or d != 128 or Lc % 128 or context.dtype not in (torch.bfloat16, torch.float16):
-            raise ValueError("jenga_amd Wan cross-attention: batch 1, head_dim 128, a 16-bit context whose length is a "
-                             "multiple of 128 (text_len = 512)")
-        v = self.v(context).view(b, Lc, n, d)
+        if b != 1 or d != 128 or Lc == 0 or context.dtype not in (torch.bfloat16, torch.float16):
+            raise ValueError("jenga_amd Wan cross-attention: batch 1, head_dim 128, a non-empty 16-bit context")
+        # q, k, v live in buffers padded to whole 128-row blocks (query rows are independent; keys >= Lc are masked by the
+        # kernel -- the reference's context is always text_len = 512 = four whole blocks)
+        Lp, Lcp = (L + 127) // 128 * 128, (Lc + 127) // 128 * 128
+        dt = context.dtype
+        kv = torch.empty((2, b, Lcp, n * d), dtype=dt, device=x.device)
+        if Lcp > Lc:
+            kv[:, :, Lc:].zero_()
+        kv[1, :, :Lc] = self.v(context)
         # WanRMSNorm with its fp32 weight returns fp32; flash_attention's half() rounds q, k to the 16-bit dtype: norm
-        # (fp32 weight) + the cast in one pass, written into a buffer padded to whole 128-row query blocks
-        Lp = (L + 127) // 128 * 128
-        q = torch.empty((b, Lp, n * d), dtype=v.dtype, device=x.device)
-        if v.dtype == torch.bfloat16:
+        # (fp32 weight) + the cast in one pass
+        q = torch.empty((b, Lp, n * d), dtype=dt, device=x.device)
+        if dt == torch.bfloat16:
             _capi.wan_norm_rope(self.q(x), self.norm_q.weight, None, None, 0, self.norm_q.eps, out=q.view(Lp, n * d))
+            _capi.wan_norm_rope(self.k(context), self.norm_k.weight, None, None, 0, self.norm_k.eps,
+                                out=kv[0].view(Lcp, n * d))
         else:
-            q[:, :L] = self.norm_q(self.q(x)).to(v.dtype)
+            q[:, :L] = self.norm_q(self.q(x)).to(dt)
+            kv[0, :, :Lc] = self.norm_k(self.k(context)).to(dt)
         if Lp > L:
             q[:, L:].zero_()
-        k = self.norm_k(self.k(context)).to(v.dtype).view(b, Lc, n, d)
-        # softmax scale d^-0.5, no mask (flash_attention(k_lens=None)): the LP attention kernel in its dense mode, every
-        # query block against the Lc / 128 context blocks (jenga_cross_attn_fwd)
-        o = _capi.cross_attn_fwd(q.view(b, Lp, n, d), k, v)
+        # softmax scale d^-0.5, no mask beyond the context length (flash_attention(k_lens=None)): the LP attention kernel in
+        # its dense mode, every query block against the context blocks (jenga_cross_attn_fwd)
+        o = _capi.cross_attn_fwd(q.view(b, Lp, n, d), kv[0].view(b, Lcp, n, d), kv[1].view(b, Lcp, n, d), kv_len=Lc)
         return self.o(o[:, :L].flatten(2))
 
 

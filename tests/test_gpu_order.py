@@ -59,3 +59,25 @@ def test_sorted_launch_order_is_bit_identical(dev, flags):
     assert torch.equal(plain, srt) and torch.equal(plain, arb)
     with pytest.raises(ValueError):
         run(flags, order=perm[:, :, :-1].contiguous())
+
+
+@pytest.mark.parametrize("H,nq_img,size", [(3, 72, 64), (2, 200, 7), (1, 130, 64)])
+def test_cohort_start_barrier_is_bit_identical(dev, monkeypatch, H, nq_img, size):
+    """JENGA_ATTN_COHORT (round-4 experiment): the workgroups of an XCD generation wait for each other before they start
+    (arrival counters, bounded spin).  A scheduling device only: every query block is computed exactly once, outputs are
+    bit-identical -- also when a generation is larger than what can be resident at once (the timeout lets it proceed)."""
+    from jenga_amd import _capi
+    monkeypatch.setenv("JENGA_COHORT_SIZE", str(size))
+    monkeypatch.setenv("JENGA_COHORT_TIMEOUT_US", "50")
+    tb = 2
+    q, k, v, mask = _rand_case(91 + nq_img, H, nq_img, tb, "bfloat16", 0.3, 0.0)
+    nb = nq_img + tb
+    idx, cnt = lists_from_mask(mask, dev)
+    vt = _capi.pack_v(v.to(dev), nb)
+    seqlens = torch.tensor([nq_img * 128 + 70], dtype=torch.int32, device=dev)
+    run = lambda fl: _capi.bsattn_fwd(q.to(dev), k.to(dev), vt, seqlens, idx, cnt, nq_img, 128 ** -0.5, 0.3, nq_img, flags=fl)
+    base = run(_capi.ATTN_XCD_REMAP | _capi.ATTN_LP | _capi.ATTN_SORTED)
+    for _ in range(2):       # twice: the counters are zeroed on the stream in front of every launch
+        coh = run(_capi.ATTN_XCD_REMAP | _capi.ATTN_LP | _capi.ATTN_SORTED | _capi.ATTN_COHORT)
+        torch.cuda.synchronize()
+        assert torch.equal(base, coh)

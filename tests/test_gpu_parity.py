@@ -140,9 +140,9 @@ def test_select_vs_reference_golden(golden_dir, dev, index):
         forced[:, :, :ffb, :ffb] = True
     ok, msg = tie_tolerant_mask_equal(mask, ref, probs, n, nb_img, forced)
     ham = int((mask != ref).sum())
-    # pooled means / exp on the GPU may differ from torch-CPU by one dtype ulp on rare elements, which can move a
-    # block across the cutoff: report the Hamming distance and bound it instead of demanding tie-exactness
-    assert ok or ham <= max(2, ref.size // 500), f"{msg}; hamming={ham}/{ref.size}"
+    # every recorded run of rounds 2-3 is tie-exact on all eight cases (profiles/r03_parity_select_hamming.json): the test
+    # demands exactly that -- any differing entry must lie inside a group of equal bf16 probabilities at the cutoff
+    assert ok, f"{msg}; hamming={ham}/{ref.size}"
     # lists agree with the mask
     idx, cnt = idx.cpu().numpy(), cnt.cpu().numpy()
     for h in range(H):
@@ -166,7 +166,16 @@ def test_select_vs_oracle_larger(dev):
     mask, idx, cnt = build_block_index(qf.transpose(1, 2).to(dev), k.transpose(1, 2).to(dev), 10, tb, 0.3,
                                        torch.from_numpy(nbm), want_mask=True)
     ham = int((mask.bool().cpu().numpy() != ref).sum())
-    assert ham <= ref.size // 500, f"hamming {ham}/{ref.size}"
+    # (the oracle pools with numpy's summation order, the kernel with its own: a pooled mean may differ by one bf16 ulp and
+    # move a boundary block; the realised distance goes to gpurun_out/parity_records/, the bound is a tenth of round 3's)
+    try:
+        rec_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "parity_records")
+        os.makedirs(rec_dir, exist_ok=True)
+        import json
+        json.dump({"hamming": ham, "of": int(ref.size)}, open(os.path.join(rec_dir, "select_vs_oracle_larger.json"), "w"))
+    except OSError:
+        pass
+    assert ham <= ref.size // 5000, f"hamming {ham}/{ref.size}"
 
 
 # ----------------------------------------------------------------------------------------------- sparse kernel
@@ -508,6 +517,17 @@ def test_full_size_properties_and_sampled_rows(dev):
         ref = oa.sparse_rows(qq, kk, vv, [n * 128], mask, 128 ** -0.5, "bfloat16", text_amp=0.2, text_block_start=n - tb)
         got = o[0, rows, hh].float().cpu().numpy()
         assert np.abs(got - ref[0, 0]).max() <= 2e-2, (hh, m, np.abs(got - ref[0, 0]).max())
+    # (d) EVERY row of every head: the LP kernel (default launch order) against the round-1 kernel -- two independent
+    #     kernels (different software pipelines, same lists): indexing at 900 blocks x 24 heads, both 64-key halves, the
+    #     list-window reloads, the XCD remap and the count-sorted order.  Same arithmetic contract,
+    #     different summation order of the running sums: a few bf16 ulps at |o| <= 1.
+    o_r1 = _capi.bsattn_fwd(q, k, vt, seqlens, idx, cnt, nimg, 128 ** -0.5, 0.2, nimg,
+                            flags=_capi.ATTN_XCD_REMAP | _capi.ATTN_LEGACY)
+    d_all = (o.float() - o_r1.float()).abs()
+    assert float(d_all.max()) <= 2e-2 and float(d_all.mean()) <= 5e-4, (float(d_all.max()), float(d_all.mean()))
+    per_row = d_all.amax(dim=-1)                     # [1, S, H]: no query row (= no workgroup / wave) is off
+    assert float((per_row > 8e-3).float().mean()) <= 1e-3
+    del o_r1, d_all, per_row
     # text query rows: dense over everything (flash_attn semantics), one head
     ref_t = oa.text_rows(q[:, S_img:, 0:1].transpose(1, 2).float().cpu().numpy(), k[:, :, 0:1].transpose(1, 2).float().cpu().numpy(),
                          v[:, :, 0:1].transpose(1, 2).float().cpu().numpy(), 128 ** -0.5, "bfloat16")

@@ -259,9 +259,10 @@ def test_wan_1p3b_full_model_vs_reference_cpu_forward(dev):
     assert err.max() <= 3e-2 and err.mean() <= 4e-3, (err.max(), err.mean(), np.abs(ref).max(), np.abs(ref).mean())
 
 
-@pytest.mark.parametrize("dt,Sq,Skv,H", [(torch.bfloat16, 384, 512, 3), (torch.float16, 128, 128, 2),
-                                          (torch.bfloat16, 1280, 512, 12)])
-def test_cross_attention_dense_mode_vs_oracle(dev, dt, Sq, Skv, H):
+@pytest.mark.parametrize("dt,Sq,Skv,H,kv_len", [(torch.bfloat16, 384, 512, 3, 512), (torch.float16, 128, 128, 2, 128),
+                                                 (torch.bfloat16, 1280, 512, 12, 512), (torch.bfloat16, 256, 128, 2, 24),
+                                                 (torch.float16, 128, 256, 3, 200), (torch.bfloat16, 128, 384, 2, 320)])
+def test_cross_attention_dense_mode_vs_oracle(dev, dt, Sq, Skv, H, kv_len):
     """jenga_cross_attn_fwd (WanT2VCrossAttention, model_mul.py:183-205: flash_attention over the 512 context tokens,
     k_lens = None) = the LP kernel's text-row mode with a kv sequence of its own length: against the oracle's dense
     rows (oracle.attention.text_rows: fp32 scores x d^-0.5, natural softmax, P rounded to dtype before P.V) and against
@@ -275,11 +276,15 @@ def test_cross_attention_dense_mode_vs_oracle(dev, dt, Sq, Skv, H):
     # strided inputs: q as a slice of a wider buffer
     wide = torch.zeros(1, Sq, H + 1, 128, dtype=dt)
     wide[:, :, :H] = q
-    o = _capi.cross_attn_fwd(wide.to(dev)[:, :, :H], k.to(dev), v.to(dev))
+    # keys >= kv_len (inside the last block) are masked whatever the padded buffers hold there: poison them
+    kd, vd = k.clone(), v.clone()
+    kd[:, kv_len:] = 50.0
+    vd[:, kv_len:] = -1000.0
+    o = _capi.cross_attn_fwd(wide.to(dev)[:, :, :H], kd.to(dev), vd.to(dev), kv_len=kv_len)
     torch.cuda.synchronize()
     name = "bfloat16" if dt == torch.bfloat16 else "float16"
     tr = lambda t: to_np(t).transpose(0, 2, 1, 3)
-    ref = oa.text_rows(tr(q), tr(k), tr(v), 128 ** -0.5, name).transpose(0, 2, 1, 3)
+    ref = oa.text_rows(tr(q), tr(k[:, :kv_len]), tr(v[:, :kv_len]), 128 ** -0.5, name).transpose(0, 2, 1, 3)
     err = np.abs(to_np(o) - ref)
     tol = 2e-2 if dt == torch.bfloat16 else 4e-3
     assert err.max() <= tol, err.max()
@@ -289,7 +294,7 @@ def test_cross_attention_dense_mode_vs_oracle(dev, dt, Sq, Skv, H):
     # the same rows as text rows of the block-sparse entry: [kv | q] sequence, nq_img = Skv / 128 image blocks whose lists
     # are irrelevant here, the q rows as "text" rows that see every key -- only comparable when the key sets agree, i.e.
     # K_all = [k | q-as-keys]; so compare on the reduced problem where the key sequence IS k followed by nothing:
-    if Sq == Skv:
+    if Sq == Skv == kv_len:
         S = Sq
         vt = _capi.pack_v(v.to(dev), S // 128)
         o2 = _capi.bsattn_fwd(q.to(dev), k.to(dev), vt, None, None, None, 0, 128 ** -0.5, 0.0, S // 128)

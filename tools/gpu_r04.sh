@@ -32,4 +32,73 @@ A)
   brief $O/A_*.json
   timeout 1500 python -m pytest tests -q -m gpu --deselect tests/test_gpu_sp_dit.py --deselect tests/test_gpu_rccl.py --deselect tests/test_gpu_fused.py --deselect tests/test_gpu_ulysses.py > $O/A_suite.log 2>&1; tail -8 $O/A_suite.log
   ;;
+B)
+  # the whole suite at ABI 3 (cross-attention entry, choice export / import, RCCL harness), the experiment kernels once
+  # through libjenga_amd_exp.so, the default line with roofline_secondary / loop / power / extra.wan14b, the Wan line,
+  # the overlap runs with the Q|K / V split in the single-stream blocks
+  timeout 1500 python -m pytest tests -q -m gpu -x > $O/B_suite.log 2>&1; tail -12 $O/B_suite.log
+  JENGA_LIB=$PWD/jenga_amd/libjenga_amd_exp.so timeout 900 python -m pytest tests/test_gpu_pair.py tests/test_gpu_parity.py -q -m gpu -k "pair or sparse_kernel_vs_oracle" > $O/B_exp.log 2>&1; tail -5 $O/B_exp.log
+  S="--simulate-ranks 8 --steps 6 --no-cpu-baseline --no-dense-ref"
+  JENGA_SP_OVERLAP=0 run B_s8_ov0_x300 $S --sim-exchange-gbps 300
+  run B_s8_ov1_x300 $S --sim-exchange-gbps 300
+  run B_s8_ov1_x400 $S --sim-exchange-gbps 400
+  run B_s8_ov1_x200 $S --sim-exchange-gbps 200
+  JENGA_SP_MLP_TAIL=0.375 run B_s8_ov1_tail37_x300 $S --sim-exchange-gbps 300
+  run B_s8_ov1_x0 $S
+  run B_default
+  brief $O/B_s8*.json $O/B_default.json
+  timeout 900 python bench.py --workload wan14b > $O/B_wan14b.json 2> $O/B_wan14b.err; tail -c 1500 $O/B_wan14b.json; tail -3 $O/B_wan14b.err
+  ;;
+C)
+  # cross-attention with a ragged context, choice export / import, the cohort experiment (parity, same-box A/B against the
+  # default order on flat and coherent lists, counters), the LDS-flag handoff micro-benchmark
+  timeout 900 python -m pytest tests/test_gpu_wan_dit.py tests/test_gpu_order.py tests/test_gpu_fused.py tests/test_gpu_parity.py -x -q -m gpu > $O/C_tests.log 2>&1; tail -8 $O/C_tests.log
+  for a in "4000 32 0" "4000 32 8" "4000 16 0" "4000 16 6"; do ./tools/micro/lds_flag_handoff $a; done > $O/C_lds_flag_handoff.txt 2>&1; cat $O/C_lds_flag_handoff.txt
+  ba() { tag=$1; shift; timeout 600 python tools/bench_attn.py "$@" > $O/C_attn_$tag.json 2> $O/C_attn_$tag.err; python - $O/C_attn_$tag.json $tag <<'PY'
+import json,sys
+try:
+    d=json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+    print(sys.argv[2], {k: (round(d[k],3) if isinstance(d[k],float) else d[k]) for k in ("attn_ms","attn_TFLOPs","kept_mean","adjacent_shared_frac","flags","finite") if k in d})
+except Exception as e:
+    print(sys.argv[2], "FAILED", e)
+PY
+  }
+  A="--drop 0.7 --iters 100 --attn-only"
+  ba flat_base $A --flags 25
+  ba flat_cohort $A --flags 57
+  JENGA_COHORT_SIZE=32 ba flat_cohort32 $A --flags 57
+  JENGA_COHORT_TIMEOUT_US=1000 ba flat_cohort_t1000 $A --flags 57
+  ba flat_cohort_plainorder $A --flags 41
+  ba flat_base2 $A --flags 25
+  ba coh3_base $A --coherent 3 --gain 2 --flags 25
+  ba coh3_cohort $A --coherent 3 --gain 2 --flags 57
+  ba coh3_cohort_plainorder $A --coherent 3 --gain 2 --flags 41
+  bash tools/pmc_attn2.sh r04_cohort --drop 0.7 --iters 2 --attn-only --flags 57 > $O/C_pmc_cohort.log 2>&1; tail -40 $O/C_pmc_cohort.log
+  ;;
+D)
+  # cohort follow-up: a quorum instead of the full generation (the stragglers start late), shorter timeouts
+  ba() { tag=$1; shift; timeout 600 python tools/bench_attn.py "$@" > $O/D_attn_$tag.json 2> $O/D_attn_$tag.err; python - $O/D_attn_$tag.json $tag <<'PY'
+import json,sys
+try:
+    d=json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+    print(sys.argv[2], {k: (round(d[k],3) if isinstance(d[k],float) else d[k]) for k in ("attn_ms","attn_TFLOPs","kept_mean","adjacent_shared_frac","flags","finite") if k in d})
+except Exception as e:
+    print(sys.argv[2], "FAILED", e)
+PY
+  }
+  A="--drop 0.7 --iters 100 --attn-only"
+  ba flat_base $A --flags 25
+  JENGA_COHORT_QUORUM=48 ba flat_q48 $A --flags 57
+  JENGA_COHORT_QUORUM=32 ba flat_q32 $A --flags 57
+  JENGA_COHORT_QUORUM=16 ba flat_q16 $A --flags 57
+  JENGA_COHORT_QUORUM=48 JENGA_COHORT_TIMEOUT_US=100 ba flat_q48_t100 $A --flags 57
+  JENGA_COHORT_QUORUM=32 JENGA_COHORT_TIMEOUT_US=60 ba flat_q32_t60 $A --flags 57
+  JENGA_COHORT_SIZE=128 JENGA_COHORT_QUORUM=64 ba flat_s128_q64 $A --flags 57
+  ba flat_base2 $A --flags 25
+  JENGA_COHORT_QUORUM=32 ba coh3_q32 $A --coherent 3 --gain 2 --flags 57
+  JENGA_COHORT_QUORUM=32 bash tools/pmc_attn2.sh r04_cohort_q32 --drop 0.7 --iters 2 --attn-only --flags 57 > $O/D_pmc_cohort_q32.log 2>&1; grep -A12 '"derived"' $O/D_pmc_cohort_q32.log | head -30
+  JENGA_SELECT_FLAGS=1 run D_default_device_scan --no-cpu-baseline --no-dense-ref --no-secondary --no-wan-extra
+  run D_default_again --no-cpu-baseline --no-dense-ref --no-secondary --no-wan-extra
+  brief $O/D_default*.json
+  ;;
 esac
