@@ -111,13 +111,17 @@ def parse():
 
 
 
+def _free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
 def launch_command(n_gpus, argv, port=None):
     """The command `python bench.py --gpus N` re-executes itself as when no launcher set WORLD_SIZE."""
     if port is None:
-        import socket
-        with socket.socket() as sk:
-            sk.bind(("127.0.0.1", 0))
-            port = sk.getsockname()[1]
+        port = _free_port()
     return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}",
             "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
 
@@ -581,10 +585,16 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     import torch.distributed as dist
-    if world > 1:
+    # JENGA_BENCH_FORCE_DIST=1: take every multi-rank code path with a world of ONE rank on RCCL (process group, exchange
+    # warm-up, sequence-parallel modules, choice broadcast, max-over-ranks reductions) -- the smoke test of the N > 1 launch
+    # on a one-GPU box; the numbers of such a run are a single-GPU measurement with the sequence-parallel call structure
+    dist_on = world > 1 or os.environ.get("JENGA_BENCH_FORCE_DIST", "0") == "1"
+    if dist_on:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
-    sim = a.simulate_ranks if world == 1 else 0
+        if "MASTER_ADDR" not in os.environ:
+            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    sim = a.simulate_ranks if not dist_on else 0
     if sim > 1:
         from torch.testing._internal.distributed.fake_pg import FakeStore
         dist.init_process_group(backend="fake", rank=0, world_size=sim, store=FakeStore())
@@ -653,7 +663,7 @@ def main():
     from jenga_amd import _capi, gemm_tuning
     from jenga_amd.dit import NON_SKIP_STEPS, JengaHYVideoDiT
     if a.workload == "wan14b":
-        if world > 1 or sim > 1:
+        if dist_on or sim > 1:
             raise SystemExit("--workload wan14b is a single-GPU line (the reference's multi-GPU Wan path is USP / FSDP, not "
                              "Jenga-aware: SURVEY.md §2)")
         return wan_main(a, dev)
@@ -669,7 +679,7 @@ def main():
     if a.depth:
         kw = dict(depth_double=a.depth[0], depth_single=a.depth[1])
     model = JengaHYVideoDiT(dtype=torch.bfloat16, device=dev, **kw).init_synthetic_weights(0.02, seed=0)
-    if world > 1:
+    if dist_on:
         # create the RCCL communicator and its channels now, whatever --warmup says (lazy creation costs seconds)
         w_ = torch.ones(world, 16, device=dev)
         r_ = torch.empty_like(w_)
@@ -679,12 +689,12 @@ def main():
         for step in range(1, world):     # the grouped send/recv the Ulysses exchange uses: create its channels now too
             ops.append(dist.P2POp(dist.isend, w_[(rank + step) % world], (rank + step) % world))
             ops.append(dist.P2POp(dist.irecv, r_[(rank - step) % world], (rank - step) % world))
-        for w__ in dist.batch_isend_irecv(ops):
+        for w__ in (dist.batch_isend_irecv(ops) if ops else []):      # (no peers in a world of one rank)
             w__.wait()
         dist.all_reduce(w_)
         torch.cuda.synchronize()
     sim_ex = _LocalExchange(sim, a.sim_exchange_gbps, a.sim_exchange_latency_us) if sim > 1 else None
-    if world > 1 or sim > 1:
+    if dist_on or sim > 1:
         ulysses.init_sequence_parallel()
         for blk in list(model.double_blocks) + list(model.single_blocks):
             blk.hybrid_seq_parallel_attn = ulysses.UlyssesAttenCarve(exchange=sim_ex)
@@ -776,11 +786,11 @@ def main():
         sampled = True
 
     def barrier():
-        if world > 1:
+        if dist_on:
             dist.barrier()
         torch.cuda.synchronize()
 
-    if world > 1 or sim > 1:
+    if dist_on or sim > 1:
         # per-rank GEMM shapes (M = S_img / N): hipBLASLt's first pick is not its fastest there (profiles/
         # r03_gemm_tunableop.json, r03_gemm_epilogue_ab.json) -- let jenga_linear time its first 16 candidates once per
         # shape, during the untimed priming steps below
@@ -788,7 +798,7 @@ def main():
     if int(os.environ.get("JENGA_GEMM_CANDIDATES", "1")) > 1:
         for k in range(len(stages)):      # one untimed computed step per stage: every GEMM shape gets its plan here
             run_step(next(i for i in computed_steps if stage_of(i, split) == k))
-        if world > 1:
+        if dist_on:
             # every rank timed candidates on its own: adopt rank 0's choices everywhere, so that the replicated text stream
             # sees the same arithmetic on every rank (the imported index replaces each rank's plan; no further timing)
             rec = _capi.linear_export_choices() if rank == 0 else None
@@ -818,7 +828,7 @@ def main():
     _capi.ATTN_PROFILE = None
     if sim_ex is not None:
         sim_ex.sim_us_timed = sim_ex.sim_us
-    if world > 1:
+    if dist_on:
         tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
@@ -830,7 +840,7 @@ def main():
     if not a.no_dense_ref and a.preset != "dense":
         from jenga_amd.modules import attention as _att
         st = stages[-1]
-        if world == 1 and sim <= 1:
+        if not dist_on and sim <= 1:
             _att._dense_lists(dev, 1, model.heads_num, (st["h2l"].numel() + n_txt) // 128)   # built once, outside the timing
         model.curve_sel, model.linear_to_hilbert, model.hilbert_order = st["curve"], st["l2h"], st["h2l"]
         model.cnt, model.sa_drop_rate, model.text_amp, model.start_stage, model.enable_skip = 0, 0.0, 0.0, False, False
@@ -842,7 +852,7 @@ def main():
         e1.record()
         barrier()
         dense_ms = e0.elapsed_time(e1)
-        if world > 1:
+        if dist_on:
             tt = torch.tensor([dense_ms], device=dev, dtype=torch.float64)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             dense_ms = float(tt.item())
@@ -856,7 +866,7 @@ def main():
     for i in range(50):
         counts[klass(i)] = counts.get(klass(i), 0) + 1
     if sampled:
-        if world > 1:   # scale the per-class event times so that they sum to the max-over-ranks wall time
+        if dist_on:   # scale the per-class event times so that they sum to the max-over-ranks wall time
             scale = elapsed * 1e3 / max(sum(e0.elapsed_time(e1) for _, e0, e1 in evs), 1e-9)
         else:
             scale = 1.0
@@ -939,7 +949,7 @@ def main():
                                    + (f" on a side stream behind a delay of {a.sim_exchange_latency_us:g} us + bytes "
                                       f"leaving the rank / {a.sim_exchange_gbps:g} GB/s (the compute stream waits for "
                                       "them as it would for RCCL)" if a.sim_exchange_gbps > 0 else "")
-                                   if sim > 1 else "single GPU" if world == 1 else f"ulysses{world} (RCCL all-to-all)"),
+                                   if sim > 1 else "single GPU" if not dist_on else f"ulysses{world} (RCCL all-to-all)"),
                    "weights": "random init N(0,0.02), seed 0", "finite_output": finite,
                    "gemm_selection": (os.path.relpath(gemm_file, ROOT) + (" (RECORDING: not a measurement)"
                                                                           if a.gemm_tuning.startswith("record:") else
@@ -959,7 +969,7 @@ def main():
                      "adjacent_shared_frac": round(ps.get("adjacent_shared_frac", float("nan")), 3),
                      "algorithmic_flops": "4*128^3 per kept (128-query, 128-key) block pair, realised masks"},
     }
-    if world > 1 or sim > 1:
+    if dist_on or sim > 1:
         from jenga_amd import dit as _dit
         res["config"]["sp_overlap"] = {
             "enabled": _dit.SP_OVERLAP, "mlp_tail_under_o_exchange": _dit.SP_MLP_TAIL,
@@ -984,16 +994,16 @@ def main():
                     "final resolution, measured after the timed region; the dense loop computes all 50 steps "
                     "(no step skipping).  The reference's own ratio on H800: 1625 s / 310 s = 5.24 (README.md:80-82)"}
     n_layers = len(model.double_blocks) + len(model.single_blocks)
-    if rank == 0 and world == 1 and sim <= 1 and not a.no_secondary:
+    if rank == 0 and not dist_on and sim <= 1 and not a.no_secondary:
         st = stages[-1]
         res["roofline_secondary"] = secondary_roofline(
             dev, S_img=st["h2l"].numel(), S_txt=n_txt, top_k=int((1 - a.rates[0]) * (st["h2l"].numel() // 128)),
             p_remain=a.p_remain, nbm=st["curve"][0][2])
-    if rank == 0 and world == 1 and sim <= 1 and not a.no_wan_extra and a.preset == "base" and not a.depth:
+    if rank == 0 and not dist_on and sim <= 1 and not a.no_wan_extra and a.preset == "base" and not a.depth:
         del model
         torch.cuda.empty_cache()
         res["extra"] = {"wan14b": wan_extra(dev)}
-    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+    if rank == 0 and not dist_on and not a.no_cpu_baseline:
         cb = cpu_baseline(a.rates, a.p_remain)
         layers = n_layers
         res["cpu_baseline"] = {
@@ -1009,7 +1019,7 @@ def main():
             "detail": cb["detail"]}
     if rank == 0:
         print(json.dumps(res))
-    if world > 1 or sim > 1:
+    if dist_on or sim > 1:
         dist.destroy_process_group()
 
 

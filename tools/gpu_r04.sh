@@ -101,4 +101,21 @@ PY
   run D_default_again --no-cpu-baseline --no-dense-ref --no-secondary --no-wan-extra
   brief $O/D_default*.json
   ;;
+E)
+  # validation of the round's state: the whole suite, the default line, the overlap efficiency at three exchange rates with
+  # the shipped defaults, the multi-rank launch path with a world of one rank, kernel stats of the default command
+  timeout 1500 python -m pytest tests -q -m gpu > $O/E_suite.log 2>&1; tail -6 $O/E_suite.log
+  S="--simulate-ranks 8 --steps 6 --no-cpu-baseline --no-dense-ref"
+  run E_default
+  run E_s8_x0 $S
+  run E_s8_x300 $S --sim-exchange-gbps 300
+  run E_s8_x400 $S --sim-exchange-gbps 400
+  run E_s8_x200 $S --sim-exchange-gbps 200
+  JENGA_SP_OVERLAP=0 run E_s8_ov0_x300 $S --sim-exchange-gbps 300
+  run E_s8_turbo_x300 $S --sim-exchange-gbps 300 --preset turbo-mgpu
+  JENGA_BENCH_FORCE_DIST=1 run E_force_dist --no-cpu-baseline --no-dense-ref --steps 3
+  brief $O/E_*.json
+  bash tools/prof_bench.sh r04_default --no-dense-ref --no-cpu-baseline --no-secondary --no-wan-extra > $O/E_prof.log 2>&1; tail -3 $O/E_prof.log
+  head -30 gpurun_out/prof_r04_default/kernel_stats.csv
+  ;;
 esac
