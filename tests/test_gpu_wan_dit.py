@@ -299,3 +299,32 @@ def test_cross_attention_dense_mode_vs_oracle(dev, dt, Sq, Skv, H, kv_len):
         vt = _capi.pack_v(v.to(dev), S // 128)
         o2 = _capi.bsattn_fwd(q.to(dev), k.to(dev), vt, None, None, None, 0, 128 ** -0.5, 0.0, S // 128)
         assert torch.equal(o2, o)
+
+
+def test_cross_attention_at_the_wan14b_shape_sampled_rows(dev):
+    """BASELINE.json configs[3]'s cross-attention shape: 75 600 query tokens (padded to 591 blocks) x 40 heads against the
+    512-token context.  Size-independent property: V == 1 -> every output element of every row is 1 (the softmax weights
+    of each of the 3 million rows sum to one); then 64 sampled (row, head) pairs against the oracle's dense rows."""
+    from jenga_amd import _capi
+    from oracle import attention as oa
+    L, Lp, Lc, H = 75600, 75648, 512, 40
+    g = torch.Generator(device=dev).manual_seed(14)
+    q = torch.zeros(1, Lp, H, 128, device=dev, dtype=torch.bfloat16)
+    q[:, :L] = (torch.randn(1, L, H, 128, generator=g, device=dev) * 1.3).to(torch.bfloat16)
+    k = (torch.randn(1, Lc, H, 128, generator=g, device=dev) * 1.3).to(torch.bfloat16)
+    ones = torch.ones(1, Lc, H, 128, device=dev, dtype=torch.bfloat16)
+    o1 = _capi.cross_attn_fwd(q, k, ones)
+    assert torch.all((o1[:, :L].float() - 1).abs() <= 2 ** -7), (o1[:, :L].float() - 1).abs().max().item()
+    del o1, ones
+    v = torch.randn(1, Lc, H, 128, generator=g, device=dev).to(torch.bfloat16)
+    o = _capi.cross_attn_fwd(q, k, v)
+    torch.cuda.synchronize()
+    rows = torch.randint(0, L, (64,), generator=torch.Generator().manual_seed(1)).tolist() + [0, L - 1]
+    heads = [(7 * i) % H for i in range(len(rows))]
+    kk = k.float().cpu().numpy().transpose(0, 2, 1, 3)
+    vv = v.float().cpu().numpy().transpose(0, 2, 1, 3)
+    for r, h in zip(rows, heads):
+        ref = oa.text_rows(q[:, r:r + 1, h:h + 1].float().cpu().numpy().transpose(0, 2, 1, 3), kk[:, h:h + 1],
+                           vv[:, h:h + 1], 128 ** -0.5, "bfloat16")
+        got = o[0, r, h].float().cpu().numpy()
+        assert np.abs(got - ref[0, 0, 0]).max() <= 2e-2, (r, h, np.abs(got - ref[0, 0, 0]).max())

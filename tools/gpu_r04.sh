@@ -118,4 +118,30 @@ E)
   bash tools/prof_bench.sh r04_default --no-dense-ref --no-cpu-baseline --no-secondary --no-wan-extra > $O/E_prof.log 2>&1; tail -3 $O/E_prof.log
   head -30 gpurun_out/prof_r04_default/kernel_stats.csv
   ;;
+F)
+  # smoke of the multi-rank launch path with one rank, wall time of the default command, the wave-per-row LayerNorm+modulate
+  timeout 600 python -m pytest tests/test_gpu_parity.py tests/test_gpu_dit.py tests/test_gpu_sp_dit.py -q -m gpu -x > $O/F_tests.log 2>&1; tail -4 $O/F_tests.log
+  JENGA_BENCH_FORCE_DIST=1 run F_force_dist --no-cpu-baseline --no-dense-ref --steps 3
+  /usr/bin/time -v python bench.py > $O/F_default.json 2> $O/F_default.err; grep -E "Elapsed|Maximum resident" $O/F_default.err
+  brief $O/F_*.json
+  python - $O/F_default.json <<'PY'
+import json,sys
+d=json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+for k,v in d["roofline_secondary"].items():
+    if isinstance(v,dict) and "ms" in v: print(k, v["ms"], v["achieved"], v["frac"])
+PY
+  ;;
+G)
+  # wall time of the default command; the Wan-shape cross-attention test; the default record with the wave-per-row LayerNorm
+  timeout 600 python -m pytest tests/test_gpu_wan_dit.py -q -m gpu -x > $O/G_tests.log 2>&1; grep -E "passed|failed" $O/G_tests.log
+  T0=$(date +%s); python bench.py > $O/G_default.json 2> $O/G_default.err; T1=$(date +%s); echo "default bench wall seconds: $((T1-T0))"
+  brief $O/G_default.json
+  python - $O/G_default.json <<'PY'
+import json,sys
+d=json.loads([l for l in open(sys.argv[1]).read().strip().splitlines() if l.startswith("{")][-1])
+for k,v in d["roofline_secondary"].items():
+    if isinstance(v,dict) and "ms" in v: print(k, v["ms"], v["achieved"], v["frac"])
+print(d["extra"]["wan14b"]["s_per_video_two_rate_estimate"], d["cpu_baseline"]["value"])
+PY
+  ;;
 esac
