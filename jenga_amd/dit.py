@@ -115,6 +115,13 @@ def linear_gate_residual(lin, x, gate, res, gate2=None, mask=None):
     return _capi.linear(x, lin.weight, bias, gate=g, res=res)
 
 
+def _sp_linear(x, w, b):
+    """The plain GEMMs of the sequence-parallel overlap path through jenga_linear (bias epilogue, same arithmetic as
+    F.linear): the per-rank shapes (M = S_img / N, the Q|K / V split) then take part in the candidate timing of
+    JENGA_GEMM_CANDIDATES and in the choice broadcast across ranks, like the epilogue GEMMs beside them."""
+    return _capi.linear(x, w, b)
+
+
 def _select_top_k(sa_drop_rate, img_block_num):
     return int((1 - sa_drop_rate) * img_block_num)  # Python float truncation: (0.8, 900) -> 179 (models_mul...:242)
 
@@ -224,10 +231,10 @@ class MMDoubleStreamBlock(nn.Module):
             # -> Q, K exchange in flight; the V GEMM, its pack and the whole text stream run under it
             C = H * 128
             w, b = self.img_attn_qkv.weight, self.img_attn_qkv.bias
-            qk = F.linear(xm, w[: 2 * C], None if b is None else b[: 2 * C]).view(B, S_img, 2, H, 128)
+            qk = _sp_linear(xm, w[: 2 * C], None if b is None else b[: 2 * C]).view(B, S_img, 2, H, 128)
             pend = sp.begin(B, S_img, H, S_txt, qk.dtype, qk.device)
             pend.post_qk(qk[:, :, 0], qk[:, :, 1], (self.img_attn_q_norm.weight, self.img_attn_k_norm.weight), (cos, sin))
-            pend.post_v(F.linear(xm, w[2 * C:], None if b is None else b[2 * C:]).view(B, S_img, H, 128))
+            pend.post_v(_sp_linear(xm, w[2 * C:], None if b is None else b[2 * C:]).view(B, S_img, H, 128))
         else:
             img_qkv = self.img_attn_qkv(xm).view(B, S_img, 3, H, 128)
             if fused_sp:
@@ -347,9 +354,9 @@ class MMSingleStreamBlock(nn.Module):
             w = (self.q_norm.weight, self.k_norm.weight)
             pend = sp.begin(B, S_img, H, S - S_img, xm.dtype, xm.device)
             if SP_OVERLAP:      # Q|K GEMM -> Q, K exchange posted; the V GEMM already runs under it
-                qk = F.linear(xm, w1[: 2 * C], None if b1 is None else b1[: 2 * C]).unflatten(-1, (2, H, 128))
+                qk = _sp_linear(xm, w1[: 2 * C], None if b1 is None else b1[: 2 * C]).unflatten(-1, (2, H, 128))
                 pend.post_qk(qk[:, :S_img, 0], qk[:, :S_img, 1], w, (cos, sin))
-                v = F.linear(xm, w1[2 * C: 3 * C], None if b1 is None else b1[2 * C: 3 * C]).unflatten(-1, (H, 128))
+                v = _sp_linear(xm, w1[2 * C: 3 * C], None if b1 is None else b1[2 * C: 3 * C]).unflatten(-1, (H, 128))
                 pend.post_v(v[:, :S_img])
                 pend.put_text(qk[:, S_img:, 0], qk[:, S_img:, 1], v[:, S_img:], w)
             else:

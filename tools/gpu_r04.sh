@@ -144,4 +144,15 @@ for k,v in d["roofline_secondary"].items():
 print(d["extra"]["wan14b"]["s_per_video_two_rate_estimate"], d["cpu_baseline"]["value"])
 PY
   ;;
+H)
+  # per-rank GEMMs of the overlap path through jenga_linear (candidate timing): parity, then the three exchange rates again
+  timeout 600 python -m pytest tests/test_gpu_sp_dit.py tests/test_gpu_rccl.py tests/test_gpu_dit.py -q -m gpu -x > $O/H_tests.log 2>&1; grep -E "passed|failed" $O/H_tests.log
+  S="--simulate-ranks 8 --steps 6 --no-cpu-baseline --no-dense-ref"
+  run H_s8_x0 $S
+  run H_s8_x300 $S --sim-exchange-gbps 300
+  run H_s8_x400 $S --sim-exchange-gbps 400
+  run H_s8_x200 $S --sim-exchange-gbps 200
+  run H_default --no-cpu-baseline --no-dense-ref --no-secondary --no-wan-extra
+  brief $O/H_*.json
+  ;;
 esac
