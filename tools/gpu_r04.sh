@@ -155,4 +155,33 @@ H)
   run H_default --no-cpu-baseline --no-dense-ref --no-secondary --no-wan-extra
   brief $O/H_*.json
   ;;
+Z)
+  # the round's final records, one session: suite, smoke, default line, Wan line, the simulated 8-rank job at four rates,
+  # program order, MLP-tail sweep, Turbo
+  timeout 1500 python -m pytest tests -q -m gpu > $O/Z_suite.log 2>&1; grep -E "passed|failed" $O/Z_suite.log
+  python __graft_entry__.py --smoke > $O/Z_smoke.log 2>&1; tail -1 $O/Z_smoke.log
+  run Z_default
+  S="--simulate-ranks 8 --steps 6 --no-cpu-baseline --no-dense-ref"
+  run Z_s8_x0 $S
+  run Z_s8_x300 $S --sim-exchange-gbps 300
+  run Z_s8_x400 $S --sim-exchange-gbps 400
+  run Z_s8_x200 $S --sim-exchange-gbps 200
+  JENGA_SP_OVERLAP=0 run Z_s8_ov0_x300 $S --sim-exchange-gbps 300
+  JENGA_SP_OVERLAP=0 run Z_s8_ov0_x0 $S
+  JENGA_SP_MLP_TAIL=0.25 run Z_s8_tail25_x300 $S --sim-exchange-gbps 300
+  JENGA_SP_MLP_TAIL=0.5 run Z_s8_tail50_x300 $S --sim-exchange-gbps 300
+  run Z_s8_turbo_x300 $S --sim-exchange-gbps 300 --preset turbo-mgpu
+  run Z_turbo --preset turbo --no-cpu-baseline --no-dense-ref --no-secondary --no-wan-extra
+  brief $O/Z_*.json
+  timeout 900 python bench.py --workload wan14b > $O/Z_wan14b.json 2> $O/Z_wan14b.err; tail -c 300 $O/Z_wan14b.json
+  ;;
+Y)
+  # this round's counter passes of the default attention kernel (the file roofline.traffic derives from), the full 50-step
+  # loop, configs[4]'s per-rank work with the replayed exchange
+  bash tools/pmc_attn2.sh r04_lp --drop 0.7 --iters 2 --attn-only --flags 25 > $O/Y_pmc_lp.log 2>&1; grep -A14 '"derived"' $O/Y_pmc_lp.log | head -24
+  run Y_full50 --steps 50 --no-cpu-baseline --no-dense-ref --no-secondary --no-wan-extra
+  run Y_s8_3stage_i2v_x300 --simulate-ranks 8 --steps 6 --no-cpu-baseline --no-dense-ref --sim-exchange-gbps 300 --preset 3stage-mgpu --i2v
+  run Y_3stage_i2v --preset 3stage --i2v --no-cpu-baseline --no-dense-ref --no-secondary --no-wan-extra
+  brief $O/Y_*.json
+  ;;
 esac
