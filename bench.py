@@ -31,7 +31,7 @@ sys.path.insert(0, ROOT)
 
 MFMA_PEAK_TFLOPS = 2500.0  # dense bf16, /opt/skills/guides/MI355X_MICROARCH.md
 FLOPS_PER_PAIR = 4 * 128 ** 3  # one 128x128 query block against one 128-key block, head_dim 128: QK^T + PV
-PMC_FILE = "r03_pmc_bsattn_lp.json"   # the counter passes `roofline.traffic` is derived from (profiles/)
+PMC_FILE = "r04_pmc_bsattn_lp.json"   # the counter passes `roofline.traffic` is derived from (profiles/)
 
 
 PRESETS = {   # scripts/hyvideo_jenga_{base,turbo,flash,3stage}.sh and scripts/hyvideo_multigpu_jenga_*.sh
