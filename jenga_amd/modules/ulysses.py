@@ -23,9 +23,15 @@ The arithmetic contract (the part parity tests pin): rank-major sequence concate
 [r*H/N, (r+1)*H/N), top_k passed through unchanged (the caller already multiplied it by N, models_mul...:249-251),
 cu_seqlens rebuilt as [0, n_valid_text + S_img, S] (:183-184).
 
-The forward is written as local stages (`stage_in`, `local_attention`, `stage_out`) around two exchanges so that
-tests can drive N simulated ranks in one process on one GPU with an exchange that really permutes the chunks
-(tests/test_gpu_ulysses.py), and the world_size-2 gloo test exercises the collectives themselves.
+Round 4: the call is a PENDING object (`UlyssesAttenCarve.begin()` -> `PendingAttenCarve`): the caller posts each
+exchange as soon as its operand exists (`post_qk`, `post_v` / `post_qkv`, `put_text` for the local text slice) and puts
+its own independent GEMMs between posting and `finish()`; `finish(while_out=...)` runs the caller's work under the O
+exchange.  The reference issues everything on one stream (xdit_ring_atten.py:118-131, 212-217).  `forward` (reference
+signature) and `forward_qkv` are begin + post + finish in one call.
+
+The exchange object is injectable (`exchange=`): tests drive N simulated ranks in one process on one GPU with an exchange
+that really permutes the chunks (tests/test_gpu_ulysses.py, test_gpu_sp_dit.py), bench.py --simulate-ranks replays the
+transfers as side-stream delays, the world_size-2 gloo test and tests/test_gpu_rccl.py exercise the collectives themselves.
 """
 import os
 import threading
@@ -189,11 +195,13 @@ class UlyssesAttenCarve(torch.nn.Module):
     """Callable with the signature of xFuserLongContextAttention.forward (xdit_ring_atten.py:61-85); assign an
     instance to `block.hybrid_seq_parallel_attn` exactly as jenga_hyvideo_multigpu.py:181-182 does.
 
-    Two entry points:
+    Entry points:
       forward(...)      the reference's signature: already normalised / rotated q, k, v of the local shard
-      forward_qkv(...)  (jenga_amd.dit's blocks) the RAW q / k / v slices of the QKV GEMM outputs: per-head RMSNorm,
-                        RoPE and the peer-major pack of all three happen in ONE kernel per stream (image | text),
-                        the text call writing this rank's head slice straight into the attention inputs
+      forward_qkv(...)  the RAW q / k / v slices of the QKV GEMM outputs: per-head RMSNorm, RoPE and the peer-major
+                        pack of all three happen in ONE kernel per stream (image | text), the text call writing this
+                        rank's head slice straight into the attention inputs
+      begin(...)        (jenga_amd.dit's blocks) -> PendingAttenCarve: the same steps, posted one by one so that the
+                        caller's GEMMs run while the exchanges are in flight
 
     The local steps are injectable so that the world_size > 1 exchange logic can be exercised on CPU tensors over gloo
     against the oracle (tests/test_ulysses_gloo.py supplies oracle stand-ins); the defaults are the HIP kernels and
