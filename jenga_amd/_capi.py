@@ -139,6 +139,29 @@ def _stream(dev):
     return ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
 
 
+class _Here:
+    """No-op context: the tensor's device is already the current one (the common case: one process per GPU)."""
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        return False
+
+
+_HERE_CTX = _Here()
+_ALWAYS_GUARD = os.environ.get("JENGA_DEVICE_GUARD", "") == "always"     # (A/B switch: round 3's behaviour)
+
+
+def _on(device):
+    """`with torch.cuda.device(device)` only when it would change anything: the guard's two set_device calls cost more
+    host time than the ctypes call they surround (60 layers x ~30 launches per step; the per-rank steps of the
+    low-resolution stages of an 8-rank job are host-bound)."""
+    if not _ALWAYS_GUARD and (device.index is None or device.index == torch.cuda.current_device()):
+        return _HERE_CTX
+    return torch.cuda.device(device)
+
+
 def _need_gpu(t, what):
     if not t.is_cuda:
         raise JengaError(f"{what}: tensors must live on the GPU (got {t.device}); jenga_amd has no CPU path")
@@ -169,7 +192,7 @@ def gilbert_map(t, h, w, sliced, device):
     l2h = torch.empty(n, dtype=torch.int64, device=device)
     h2l = torch.empty(n, dtype=torch.int64, device=device)
     _need_gpu(l2h, "gilbert_map")
-    with torch.cuda.device(l2h.device):
+    with _on(l2h.device):
         _check(lib().jenga_gilbert_map(_stream(l2h.device), t, h, w, int(bool(sliced)), _p(l2h), _p(h2l)),
                "jenga_gilbert_map")
     return l2h, h2l
@@ -180,7 +203,7 @@ def gilbert_neighbors(t, h, w, block, l2h):
     n = t * h * w
     nb = (n + block - 1) // block
     out = torch.zeros((nb, nb), dtype=torch.uint8, device=l2h.device)
-    with torch.cuda.device(l2h.device):
+    with _on(l2h.device):
         _check(lib().jenga_gilbert_neighbors(_stream(l2h.device), t, h, w, block, _p(l2h), _p(out)),
                "jenga_gilbert_neighbors")
     return out.view(torch.bool)
@@ -199,7 +222,7 @@ def gather_rows(src, index, out=None):
     if out is None:
         out = torch.empty((B, M, C), dtype=src.dtype, device=src.device)
     rb = C * src.element_size()
-    with torch.cuda.device(src.device):
+    with _on(src.device):
         _check(lib().jenga_gather_rows(_stream(src.device), _p(src), _p(out), _p(index), B, M, rb, N * rb, M * rb),
                "jenga_gather_rows")
     return out
@@ -226,7 +249,7 @@ def rmsnorm_rope(x, weight, cos, sin, s_rope=None, eps=1e-6, out=None):
             raise ValueError("s_rope exceeds the table / sequence length")
     else:
         s_rope = 0
-    with torch.cuda.device(x.device):
+    with _on(x.device):
         _check(lib().jenga_rmsnorm_rope(_stream(x.device), _p(x), _p(out), _p(weight), _p(cos), _p(sin), B, S, H,
                                         *xs, *os_, s_rope, float(eps), dtype_code(x.dtype)), "jenga_rmsnorm_rope")
     return out
@@ -269,7 +292,7 @@ def qk_norm_rope_pool(xq, xk, wq, wk, cos, sin, out_q, out_k, s_rope=None, qpool
                 or not kpool.is_contiguous() or kpool.dtype != xq.dtype:
             raise ValueError("kpool must be a contiguous [B,H,nk,128] tensor of the input dtype")
         nk = kpool.shape[2]
-    with torch.cuda.device(xq.device):
+    with _on(xq.device):
         _check(lib().jenga_qk_norm_rope_pool(_stream(xq.device), _p(xq), _p(xk), _p(out_q), _p(out_k), _p(wq), _p(wk),
                                              _p(cos), _p(sin), _p(qpool), _p(kpool), B, S // 128, H,
                                              *_bshd_strides(xq), *_bshd_strides(out_q), int(s_rope), int(pool_block0),
@@ -330,7 +353,7 @@ def sp_qkv_prologue(xq, xk, xv, wq, wk, cos, sin, out_q, out_k, out_v, heads_per
             raise ValueError("s_rope exceeds the table / sequence length")
     else:
         s_rope = 0
-    with torch.cuda.device(x0.device):
+    with _on(x0.device):
         _check(lib().jenga_sp_qkv_prologue(_stream(x0.device), _p(xq), _p(xk), _p(xv), _p(out_q), _p(out_k), _p(out_v),
                                            _p(wq), _p(wk), _p(cos), _p(sin), B, S, H, int(head0), int(n_heads), Hn,
                                            *_bshd_strides(x0), int(o_sp), int(o_sb), int(o_ss), int(o_sh),
@@ -342,7 +365,7 @@ def stream_delay(microseconds, stream=None, device=None):
     """Measurement aid (bench.py --simulate-ranks): keep `stream` (default: the current one) busy for that long."""
     dev = torch.device("cuda", torch.cuda.current_device()) if device is None else device
     st = torch.cuda.current_stream(dev) if stream is None else stream
-    with torch.cuda.device(dev):
+    with _on(dev):
         _check(lib().jenga_stream_delay(ctypes.c_void_p(st.cuda_stream), float(microseconds)), "jenga_stream_delay")
 
 
@@ -356,7 +379,7 @@ def rmsnorm_rows(x, weight, eps):
     w32 = weight.dtype == torch.float32
     w = weight.to(device=x.device).contiguous() if w32 else weight.to(device=x.device, dtype=x.dtype).contiguous()
     out = torch.empty(x2.shape, dtype=torch.float32 if w32 else x.dtype, device=x.device)
-    with torch.cuda.device(x.device):
+    with _on(x.device):
         _check(lib().jenga_rmsnorm_rows(_stream(x.device), _p(x2), _p(out), _p(w), x2.shape[0], C, x2.stride(0),
                                         out.stride(0), float(eps), dtype_code(x.dtype), int(w32)),
                "jenga_rmsnorm_rows")
@@ -375,7 +398,7 @@ def rope_complex(x, cos64, sin64, s_rope, out_dtype=torch.float32):
     if x.stride(-1) != 1:
         x = x.contiguous()
     out = torch.empty((B, S, H, D), dtype=out_dtype, device=x.device)
-    with torch.cuda.device(x.device):
+    with _on(x.device):
         _check(lib().jenga_rope_complex(_stream(x.device), _p(x), _p(out), _p(cos64.contiguous()),
                                         _p(sin64.contiguous()), B, S, H, *_bshd_strides(x), *_bshd_strides(out),
                                         int(s_rope), codes[x.dtype], codes[out_dtype]), "jenga_rope_complex")
@@ -408,7 +431,7 @@ def wan_norm_rope(x, weight, cos64, sin64, s_rope, eps, out=None):
         cos64, sin64 = cos64.contiguous(), sin64.contiguous()
     else:
         s_rope = 0
-    with torch.cuda.device(x.device):
+    with _on(x.device):
         _check(lib().jenga_wan_norm_rope(_stream(x.device), _p(x2), _p(o2), _p(w), _p(cos64), _p(sin64), rows, C,
                                          x2.stride(0), o2.stride(0), int(s_rope), float(eps), dtype_code(x.dtype)),
                "jenga_wan_norm_rope")
@@ -436,7 +459,7 @@ def ln_modulate(x, shift, scale, eps=1e-6, shift2=None, scale2=None, mask=None, 
     v = lambda t: None if t is None else t.reshape(-1).to(dtype=x.dtype).contiguous()
     sh, sc, sh2, sc2 = v(shift), v(scale), v(shift2), v(scale2)
     m = None if mask is None else mask.to(torch.uint8).contiguous()
-    with torch.cuda.device(x.device):
+    with _on(x.device):
         _check(lib().jenga_ln_modulate(_stream(x.device), _p(x2), _p(o2), _p(sh), _p(sc), _p(sh2), _p(sc2), _p(m),
                                        rows, C, xrs, ors, float(eps), dtype_code(x.dtype)), "jenga_ln_modulate")
     return out
@@ -453,7 +476,7 @@ def gate_residual(res, y, gate, gate2=None, mask=None, out=None):
     g = gate.reshape(-1).to(dtype=res.dtype).contiguous()
     g2 = None if gate2 is None else gate2.reshape(-1).to(dtype=res.dtype).contiguous()
     m = None if mask is None else mask.to(torch.uint8).contiguous()
-    with torch.cuda.device(res.device):
+    with _on(res.device):
         _check(lib().jenga_gate_residual(_stream(res.device), _p(r2), _p(y2), _p(g), _p(g2), _p(m), _p(o2), rows, C,
                                          rrs, yrs, ors, dtype_code(res.dtype)), "jenga_gate_residual")
     return out
@@ -466,7 +489,7 @@ def gelu_tanh(x, out=None):
     if out is None:
         out = torch.empty(x.shape, dtype=x.dtype, device=x.device)
     o2, _, _, ors = _rows2d(out)
-    with torch.cuda.device(x.device):
+    with _on(x.device):
         _check(lib().jenga_gelu_tanh(_stream(x.device), _p(x2), _p(o2), rows, C, xrs, ors, dtype_code(x.dtype)),
                "jenga_gelu_tanh")
     return out
@@ -536,7 +559,7 @@ def linear(x, weight, bias=None, act=ACT_NONE, gate=None, res=None, out=None):
         if g32.numel() != N:
             raise ValueError("linear: gate must have N entries")
     ws = _gemm_workspace(x.device)
-    with torch.cuda.device(x.device):
+    with _on(x.device):
         _check(lib().jenga_linear(_stream(x.device), _p(x2), _p(weight), _p(bias), _p(r2), _p(g32), _p(o2), M, N, K, xrs,
                                   weight.stride(0), rrs, ors, int(act), _p(ws), ws.numel(), dtype_code(x.dtype)),
                "jenga_linear")
@@ -554,7 +577,7 @@ def wan_ln_modulate(x, weight=None, bias=None, shift=None, scale=None, eps=1e-6,
     o2, _, _, ors = _rows2d(out)
     v = lambda t: None if t is None else t.reshape(-1).to(dtype=torch.float32).contiguous()
     w, b, sh, sc = v(weight), v(bias), v(shift), v(scale)
-    with torch.cuda.device(x.device):
+    with _on(x.device):
         _check(lib().jenga_wan_ln_modulate(_stream(x.device), _p(x2), _p(o2), _p(w), _p(b), _p(sh), _p(sc), rows, C,
                                            xrs, ors, float(eps), dtype_code(out_dtype), int(bool(round_ln))),
                "jenga_wan_ln_modulate")
@@ -572,7 +595,7 @@ def wan_gate_residual(x, y, gate=None, out=None):
         out = torch.empty(x.shape, dtype=torch.float32, device=x.device)
     o2, _, _, ors = _rows2d(out)
     g = None if gate is None else gate.reshape(-1).to(dtype=torch.float32).contiguous()
-    with torch.cuda.device(x.device):
+    with _on(x.device):
         _check(lib().jenga_wan_gate_residual(_stream(x.device), _p(x2), _p(y2), _p(g), _p(o2), rows, C, xrs, yrs, ors,
                                              dtype_code(y.dtype)), "jenga_wan_gate_residual")
     return out
@@ -585,7 +608,7 @@ def block_pool(x, n_blocks):
     if D != 128 or n_blocks * 128 > S:
         raise ValueError("block_pool: head_dim must be 128 and n_blocks*128 <= S")
     out = torch.empty((B, H, n_blocks, 128), dtype=x.dtype, device=x.device)
-    with torch.cuda.device(x.device):
+    with _on(x.device):
         _check(lib().jenga_block_pool(_stream(x.device), _p(x), _p(out), B, H, n_blocks, *_bshd_strides(x),
                                       dtype_code(x.dtype)), "jenga_block_pool")
     return out
@@ -611,7 +634,7 @@ def block_select(qpool, kpool, neighbors, nk_img, text_blocks, top_k, p, first_f
             neighbors = neighbors.view(torch.uint8)
         neighbors = neighbors.to(dev).contiguous()
         nbr, nbc = neighbors.shape
-    with torch.cuda.device(dev):
+    with _on(dev):
         _check(lib().jenga_block_select(_stream(dev), _p(qpool.contiguous()), _p(kpool.contiguous()), _p(neighbors),
                                         nbr, nbc, _p(mask), _p(idx), _p(cnt), B, H, nq, nk_img, text_blocks,
                                         int(top_k), float(p), int(first_frame_blocks), dtype_code(qpool.dtype),
@@ -633,7 +656,7 @@ def pack_v(v, n_blocks=None, out=None, dst_block0=0, dst_blocks_total=None):
         dst_blocks_total = n_blocks if out is None else out.shape[2] // 2
     if out is None:
         out = torch.empty((B, H, dst_blocks_total * 2, 128, 64), dtype=v.dtype, device=v.device)
-    with torch.cuda.device(v.device):
+    with _on(v.device):
         _check(lib().jenga_pack_v(_stream(v.device), _p(v), _p(out), B, H, n_blocks, *_bshd_strides(v),
                                   dst_block0, dst_blocks_total, dtype_code(v.dtype)), "jenga_pack_v")
     return out
@@ -679,7 +702,7 @@ def bsattn_fwd(q, k, vt, seqlens, idx, cnt, nq_img, sm_scale, text_amp, text_blo
         raise JengaError("ATTN_LP | ATTN_PAIR needs text blocks behind the image blocks (masked image blocks in an "
                          "unshared list are not handled by that experiment)")
     prof = ATTN_PROFILE
-    with torch.cuda.device(q.device):
+    with _on(q.device):
         pidx = pcnt = order_t = None
         if pair and nq_img > 0:
             pidx, pcnt = pair_merge(idx, cnt, n_blocks)
@@ -732,7 +755,7 @@ def cross_attn_fwd(q, k, v, sm_scale=None, out=None, kv_len=None):
     if out is None:
         out = torch.empty((B, Sq, H, 128), dtype=q.dtype, device=q.device)
     vt = pack_v(v, Skv // 128)
-    with torch.cuda.device(q.device):
+    with _on(q.device):
         _check(lib().jenga_cross_attn_fwd(_stream(q.device), _p(q), _p(k), _p(vt), _p(out), B, H, Sq // 128, Skv // 128,
                                           kv_len, *_bshd_strides(q), *_bshd_strides(k), *_bshd_strides(out),
                                           float(D ** -0.5 if sm_scale is None else sm_scale), dtype_code(q.dtype)),
@@ -748,7 +771,7 @@ def order_by_count(cnt, segment):
         raise ValueError("order_by_count: cnt must be a contiguous int32 [B,H,nq] tensor")
     B, H, nq = cnt.shape
     order = torch.empty_like(cnt)
-    with torch.cuda.device(cnt.device):
+    with _on(cnt.device):
         _check(lib().jenga_order_by_count(_stream(cnt.device), _p(cnt), B * H, nq, int(segment), _p(order)),
                "jenga_order_by_count")
     return order
@@ -767,7 +790,7 @@ def pair_merge(idx, cnt, n_blocks):
     npair = (nq + 1) // 2
     pidx = torch.empty((B, H, npair, nb), dtype=torch.int32, device=idx.device)
     pcnt = torch.empty((B, H, npair, 4), dtype=torch.int32, device=idx.device)
-    with torch.cuda.device(idx.device):
+    with _on(idx.device):
         _check(lib().jenga_pair_merge(_stream(idx.device), _p(idx.contiguous()), _p(cnt.contiguous()), B, H, nq, nb,
                                       _p(pidx), _p(pcnt)), "jenga_pair_merge")
     return pidx, pcnt
@@ -779,7 +802,7 @@ def ulysses_pack_heads(x, n_ranks, out=None):
     B, S, H, D = x.shape
     if out is None:
         out = torch.empty((n_ranks, B, S, H // n_ranks, D), dtype=x.dtype, device=x.device)
-    with torch.cuda.device(x.device):
+    with _on(x.device):
         _check(lib().jenga_ulysses_pack_heads(_stream(x.device), _p(x), _p(out), B, S, H, n_ranks,
                                               *_bshd_strides(x)), "jenga_ulysses_pack_heads")
     return out
@@ -791,7 +814,7 @@ def ulysses_unpack_heads(recv, n_ranks, out=None):
     N, B, S, Hn, D = recv.shape
     if out is None:
         out = torch.empty((B, S, Hn * N, D), dtype=recv.dtype, device=recv.device)
-    with torch.cuda.device(recv.device):
+    with _on(recv.device):
         _check(lib().jenga_ulysses_unpack_heads(_stream(recv.device), _p(recv.contiguous()), _p(out), B, S, Hn * N, N,
                                                 *_bshd_strides(out)), "jenga_ulysses_unpack_heads")
     return out

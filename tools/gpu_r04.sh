@@ -184,4 +184,15 @@ Y)
   run Y_3stage_i2v --preset 3stage --i2v --no-cpu-baseline --no-dense-ref --no-secondary --no-wan-extra
   brief $O/Y_*.json
   ;;
+I)
+  # host time per launch of the ctypes wrappers with and without the redundant device guard; the host-bound per-rank steps
+  python tools/host_overhead.py > $O/I_host_new.json 2>/dev/null; cat $O/I_host_new.json
+  JENGA_DEVICE_GUARD=always python tools/host_overhead.py > $O/I_host_old.json 2>/dev/null; cat $O/I_host_old.json
+  S="--simulate-ranks 8 --steps 6 --no-cpu-baseline --no-dense-ref --sim-exchange-gbps 300"
+  run I_s8_3stage_i2v_new $S --preset 3stage-mgpu --i2v
+  JENGA_DEVICE_GUARD=always run I_s8_3stage_i2v_old $S --preset 3stage-mgpu --i2v
+  run I_s8_base_new $S
+  JENGA_DEVICE_GUARD=always run I_s8_base_old $S
+  brief $O/I_*.json
+  ;;
 esac
