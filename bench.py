@@ -88,6 +88,9 @@ def parse():
     ap.add_argument("--no-wan-extra", action="store_true",
                     help="skip the short Wan2.1-14B leg (one forward at each drop rate, after the timed region) that puts a "
                          "configs[3] number into the default N=1 record")
+    ap.add_argument("--no-rotate-ref", action="store_true",
+                    help="skip the computed steps re-run after the timed region with JENGA_ATTN_ROTATE (the opt-in, not "
+                         "bit-reproducible launch mode of the attention kernel: rotated list walk on a clock cursor)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-dense-ref", action="store_true",
                     help="skip the ONE dense (sa-drop 0) computed step that is run after the timed region to report "
@@ -862,6 +865,29 @@ def main():
             dense_ms = float(tt.item())
         model.enable_skip = do_skip
 
+    # ---- the opt-in launch mode beside it (NOT in the timed region, not `value`): one computed step per stage with the
+    #      attention kernel's rotated list walk (JENGA_ATTN_ROTATE: every workgroup starts its ascending list at the phase of
+    #      a chip-wide clock cursor, so co-resident workgroups meet in the L2 without waiting; the accumulation order then
+    #      depends on start times -- results equal within fp32 rounding of the running sums, not bit-reproducible)
+    rot_ms, rot_prof = {}, None
+    if not a.no_rotate_ref and not dist_on and sim <= 1 and a.preset != "dense" and (_capi.ATTN_DEFAULT_FLAGS & _capi.ATTN_LP):
+        flags0 = _capi.ATTN_DEFAULT_FLAGS
+        _capi.ATTN_DEFAULT_FLAGS = flags0 | _capi.ATTN_ROTATE
+        _capi.ATTN_PROFILE = rot_prof = _capi.AttnProfile()
+        try:
+            for k in range(len(stages)):
+                i_k = next(i for i in computed_steps if stage_of(i, split) == k and i not in forced)
+                barrier()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                run_step(i_k)
+                e1.record()
+                barrier()
+                rot_ms[k] = e0.elapsed_time(e1)
+        finally:
+            _capi.ATTN_DEFAULT_FLAGS = flags0
+            _capi.ATTN_PROFILE = None
+
     cls = {}
     for i, e0, e1 in evs:
         cls.setdefault(klass(i), []).append(e0.elapsed_time(e1))
@@ -987,6 +1013,21 @@ def main():
             "simulated_transfer_ms_per_computed_step": round(sim_ex.sim_us_timed / 1e3 / max(n_comp, 1), 2),
             "note": "transfer time posted on the side stream during the timed steps / computed steps; what is NOT hidden "
                     "shows up in value"}
+    if rot_ms:
+        rs = rot_prof.summary()
+        r_ach = rs["pairs"] * FLOPS_PER_PAIR / (rs["total_ms"] * 1e-3) / 1e12 if rs["total_ms"] > 0 else 0.0
+        est = sum(n * (rot_ms[key[0]] if key[1] == "c" and key[0] in rot_ms else class_ms(key) if sampled else mean(cls.get(key, [0.0])))
+                  for key, n in counts.items()) / 1e3
+        res.setdefault("extra", {})["attn_rotate"] = {
+            "what": "JENGA_ATTN_ROTATE (JENGA_ATTN_FLAGS=153), opt-in: rotated list walk on a clock cursor, period = the previous "
+                    "launch's workgroup lifetime; NOT bit-reproducible (accumulation order depends on start times) -- not the "
+                    "default, not `value`",
+            "ms_per_computed_step": {f"stage{k}": round(v, 2) for k, v in rot_ms.items()},
+            "s_per_video_estimate": round(est, 3),
+            "attention_TFLOPs": round(r_ach, 1), "attention_frac_of_peak": round(r_ach / MFMA_PEAK_TFLOPS, 4),
+            "attention_avg_launch_ms": round(rs["total_ms"] / max(rs["launches"], 1), 3),
+            "note": "one computed step per stage after the timed region; estimate = the timed run's skipped-step classes + "
+                    "these computed-step times x their counts"}
     res["loop"] = loop
     if power_rec is not None:
         res["power"] = power_rec
@@ -1006,7 +1047,7 @@ def main():
     if rank == 0 and not dist_on and sim <= 1 and not a.no_wan_extra and a.preset == "base" and not a.depth:
         del model
         torch.cuda.empty_cache()
-        res["extra"] = {"wan14b": wan_extra(dev)}
+        res.setdefault("extra", {})["wan14b"] = wan_extra(dev)
     if rank == 0 and not dist_on and not a.no_cpu_baseline:
         cb = cpu_baseline(a.rates, a.p_remain)
         layers = n_layers

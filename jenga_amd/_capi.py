@@ -17,6 +17,7 @@ ATTN_LEGACY = 0      # (readability alias) no kernel bit: the round-1 kernel, on
 ATTN_LP = 8          # round-1 decomposition + in-wave software pipeline (csrc/bsattn3.hip): the default
 ATTN_SORTED = 16     # (Python-side) kept-count-aware launch order: jenga_order_by_count feeds jenga_bsattn_fwd's `order`
 ATTN_COHORT = 32     # experiment (round 4): cohort start barrier per XCD generation (LP kernel + XCD remap)
+ATTN_ROTATE = 128    # experiment (round 4): rotated list walk on a clock cursor (LP kernel); not bit-reproducible
 ATTN_PAIR = 64       # (Python-side, experiment) route to jenga_bsattn_pair_fwd: the pair kernel; with ATTN_LP the 8-wave
 #                      LP pair (csrc/experiments/); needs libjenga_amd_exp.so
 # default: LP kernel, XCD remap, kept-count-aware order inside every XCD's range (+3.3 % sustained on lists whose counts
@@ -720,7 +721,7 @@ def bsattn_fwd(q, k, vt, seqlens, idx, cnt, nq_img, sm_scale, text_amp, text_blo
             e0.record()
         common = (B, H, n_blocks, nq_img, *_bshd_strides(q), *_bshd_strides(k), *_bshd_strides(out), float(sm_scale),
                   float(text_amp), int(text_block_start), dtype_code(q.dtype))
-        cflags = fl & (ATTN_XCD_REMAP | ATTN_PINGPONG | ATTN_LP | ATTN_COHORT)
+        cflags = fl & (ATTN_XCD_REMAP | ATTN_PINGPONG | ATTN_LP | ATTN_COHORT | ATTN_ROTATE)
         if not pair:
             _check(lib().jenga_bsattn_fwd(_stream(q.device), _p(q), _p(k), _p(vt), _p(out), _p(seqlens), _p(idx),
                                           _p(cnt), _p(order_t), *common, cflags), "jenga_bsattn_fwd")

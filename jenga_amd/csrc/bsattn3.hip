@@ -62,8 +62,14 @@ struct LpParams {
 
 // XKV: the cross-attention instantiation (TEXT rows against a kv sequence whose last tile may be ragged); a template
 // parameter so that the product kernel's code (and its register allocation) is exactly what it is without that path
-template <typename T, bool TEXT, bool XKV = false>
-__device__ __forceinline__ void attn_block_lp(const LpParams& P, unsigned char* smem, int b, int h, int m) {
+// ROT (round-4 experiment, JENGA_ATTN_ROTATE): the fast part of the ascending list is walked from a ROTATED start --
+// logical entry j < n_rot is physical entry (j + rot) mod n_rot, rot = phase of a chip-wide wall-clock cursor x n_rot -- so
+// that workgroups started at different times are at the same kv blocks at the same time WITHOUT waiting for each other.
+// The summation order of the online softmax then depends on the start time: results are equal within fp32 rounding of
+// the running sums, not bit-identical from run to run.  rot_period: the cursor's period in wall-clock ticks.
+template <typename T, bool TEXT, bool XKV = false, bool ROT = false>
+__device__ __forceinline__ void attn_block_lp(const LpParams& P, unsigned char* smem, int b, int h, int m,
+                                              int rot_period = 0, int rot_seq = 0) {
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -132,12 +138,20 @@ __device__ __forceinline__ void attn_block_lp(const LpParams& P, unsigned char* 
 
     // kept list, 64 entries at a time in one VGPR (bsattn.hip)
     int lchunk = 0, lbase = -64;
+    int rot = 0, n_rot = 0;
+    auto phys = [&](int j) -> int {
+        if (!ROT || j >= n_rot) return j;
+        const int p_ = j + rot;
+        return p_ >= n_rot ? p_ - n_rot : p_;
+    };
     auto blk_at = [&](int i) -> int {
         if (i >= nkept) i = nkept - 1;   // the last steps stage one (unused) tile more: same piece count every step
         if (TEXT) return i;
         if (i < lbase || i >= lbase + 64) {
             lbase = i & ~63;
-            lchunk = (lbase + lane < nkept) ? list[lbase + lane] : 0;
+            // (ROT: the window lives in LOGICAL index space, every lane fetches its own physical entry -- the rotation's
+            // wrap point needs no special case anywhere else)
+            lchunk = (lbase + lane < nkept) ? list[phys(lbase + lane)] : 0;
             // wait HERE for the (rare) reload: at the join in front of v_readlane hipcc's vmcnt(0) runs every step and
             // drains the whole LDS-DMA prefetch (the hardware counter includes the asm loads)
             __builtin_amdgcn_s_waitcnt(0x0F70);
@@ -167,7 +181,7 @@ __device__ __forceinline__ void attn_block_lp(const LpParams& P, unsigned char* 
         const int first = t >> 1, last = (t + 7) >> 1;
         if (first < lbase || last >= lbase + 64) {
             lbase = first;
-            lchunk = (lbase + lane < nkept) ? list[lbase + lane] : 0;
+            lchunk = (lbase + lane < nkept) ? list[phys(lbase + lane)] : 0;
             __builtin_amdgcn_s_waitcnt(0x0F70);
         }
     };
@@ -216,6 +230,26 @@ __device__ __forceinline__ void attn_block_lp(const LpParams& P, unsigned char* 
         while (t_all > 0 && blk_at((t_all - 1) >> 1) * 128 + ((t_all - 1) & 1) * 64 >= seqlen) --t_all;
     }
     int t_fast = 2 * n_fast < t_all ? 2 * n_fast : t_all;
+    if (ROT && n_fast > 1 && rot_period > 0) {
+        // clock mode: one clock reading for the whole workgroup (its four waves share the tile order)
+        if (tid == 0) {
+            const unsigned long long c = (unsigned long long)wall_clock64() % (unsigned long long)rot_period;
+            *reinterpret_cast<int*>(smem) = (int)((c * (unsigned long long)n_fast) / (unsigned long long)rot_period);
+        }
+        __syncthreads();
+        rot = __builtin_amdgcn_readfirstlane(*reinterpret_cast<const int*>(smem));
+        n_rot = n_fast;
+        lbase = -64;          // (the window holds unrotated entries from the tail scan)
+        __syncthreads();
+    } else if (ROT && n_fast > 1 && rot_period < 0) {
+        // position mode (deterministic): in the steady state an XCD starts S = -rot_period workgroups per mean workgroup
+        // lifetime (work conservation: its S slots are always full), so the rot_seq-th workgroup of the XCD's queue starts
+        // at cursor phase frac(rot_seq / S) -- no clock, no period to know
+        const int S = -rot_period;
+        rot = (int)(((long long)(rot_seq % S) * n_fast) / S);
+        n_rot = n_fast;
+        lbase = -64;
+    }
     if (XKV && P.text_kv_len > 0) {     // cross-attention: whole tiles in the pipeline, the ragged one in the slow form
         t_all = (P.text_kv_len + 63) >> 6;
         t_fast = P.text_kv_len >> 6;
@@ -330,10 +364,15 @@ struct CohortCfg {
     int quorum;                  // arrivals a member waits for (<= size): the stragglers of a generation start late
 };
 __device__ CohortCfg g_cohort_cfg;
+__device__ int g_rot_period_ticks;      // JENGA_ATTN_ROTATE: the cursor's period (wall-clock ticks, 100 MHz)
+__device__ int g_rot_T_est = 87500;     // lifetime of the image workgroup that finished last (ticks): the NEXT launch's period
+                                        // in auto mode (copied device-to-device on the launch stream; 875 us to begin with)
 
 #define LP_THREADS 256
 // VARIANT 0: the product kernel.  1: + the cohort start barrier.  2: dense cross-attention (jenga_cross_attn_fwd):
-// TEXT-mode rows only, kv-length mask on the last tile.  Separate instantiations on purpose (see above).
+// TEXT-mode rows only, kv-length mask on the last tile.  3: rotated list walk (JENGA_ATTN_ROTATE).  Separate
+// instantiations on purpose (see above).  (A fourth, rotation + pacing -- a workgroup ahead of the cursor sleeps -- lost
+// 10 % and is gone: profiles/r04_attn_rotate_ab.json.)
 template <typename T, int VARIANT>
 __global__ void __launch_bounds__(LP_THREADS, 2) bsattn_lp_kernel(LpParams P) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -378,7 +417,24 @@ __global__ void __launch_bounds__(LP_THREADS, 2) bsattn_lp_kernel(LpParams P) {
         __syncthreads();
     }
     if (P.order) m = P.order[(long long)bh * P.nq_img + m];   // kept-count-aware order inside the XCD's range
-    attn_block_lp<T, false>(P, smem, bh / P.H, bh % P.H, m);
+    if (VARIANT == 3) {
+        int seq = li, seq_total = P.B * P.H * P.img_per_head;
+        if (P.xcd_chunk) {      // this workgroup's number in its XCD's queue (launch positions, before the count order)
+            int nv = P.nq_img - (r & 7) * P.xcd_chunk;
+            nv = nv < P.xcd_chunk ? nv : P.xcd_chunk;
+            seq = bh * nv + (r >> 3);
+            seq_total = P.B * P.H * nv;
+        }
+        int period = g_rot_period_ticks;
+        if (period > 0) period = period < 5000 ? 5000 : (period > 1000000 ? 1000000 : period);   // 50 us .. 10 ms
+        const long long t_start = (long long)wall_clock64();
+        attn_block_lp<T, false, false, true>(P, smem, bh / P.H, bh % P.H, m, period, seq);
+        // the next launch's period (auto mode): the lifetime of a workgroup from the MIDDLE of its XCD's queue -- the last
+        // ones run on a draining chip and are faster than the steady state the cursor has to match
+        if (threadIdx.x == 0 && seq * 4 >= seq_total && seq * 4 < 3 * seq_total)
+            g_rot_T_est = (int)((long long)wall_clock64() - t_start);
+    } else
+        attn_block_lp<T, false>(P, smem, bh / P.H, bh % P.H, m);
 }
 
 template <typename T, int VARIANT>
@@ -464,8 +520,39 @@ int jenga_bsattn_lp_launch(void* stream, const void* q, const void* k, const voi
                 cohort = true;
         }
     }
+    int rot_ticks = 0;
+    if ((flags & JENGA_ATTN_ROTATE) && !cohort) {
+        // EXPERIMENT: the period comes from the environment (microseconds; default 875 = the mean workgroup lifetime of the
+        // 720p launch); written to the device global on the launch stream
+        // period of the cursor: JENGA_ROTATE_PERIOD_US=<microseconds>, or (default, "auto") the lifetime of the image
+        // workgroup that finished last in the previous launch with this flag -- copied device to device on the launch
+        // stream, so one launch sees one period and no host synchronisation is involved
+        int us = 0;
+        if (const char* ev = getenv("JENGA_ROTATE_PERIOD_US")) us = atoi(ev);
+        rot_ticks = us > 0 ? us * 100 : 1;
+        bool auto_period = us <= 0;
+        // JENGA_ROTATE_SLOTS=S: position mode with S workgroups resident per XCD (64 = 32 CUs x 2); deterministic
+        if (const char* ev = getenv("JENGA_ROTATE_SLOTS")) {
+            const int slots = atoi(ev);
+            if (slots > 0) rot_ticks = -slots;
+        }
+        if (rot_ticks < 0) auto_period = false;
+        if (auto_period) {
+            void *dst = nullptr, *src = nullptr;
+            if (hipGetSymbolAddress(&dst, HIP_SYMBOL(g_rot_period_ticks)) != hipSuccess ||
+                hipGetSymbolAddress(&src, HIP_SYMBOL(g_rot_T_est)) != hipSuccess ||
+                hipMemcpyAsync(dst, src, sizeof(int), hipMemcpyDeviceToDevice, (hipStream_t)stream) != hipSuccess)
+                rot_ticks = 0;
+        } else if (rot_ticks != 0 && hipMemcpyToSymbolAsync(HIP_SYMBOL(g_rot_period_ticks), &rot_ticks, sizeof(int), 0,
+                                                           hipMemcpyHostToDevice, (hipStream_t)stream) != hipSuccess) {
+            rot_ticks = 0;
+        }
+    }
     hipError_t e;
-    if (cohort)
+    if (rot_ticks != 0)
+        e = dtype == JENGA_BF16 ? lp_launch<BF16, 3>(P, grid, (hipStream_t)stream)
+                                : lp_launch<FP16, 3>(P, grid, (hipStream_t)stream);
+    else if (cohort)
         e = dtype == JENGA_BF16 ? lp_launch<BF16, 1>(P, grid, (hipStream_t)stream)
                                 : lp_launch<FP16, 1>(P, grid, (hipStream_t)stream);
     else

@@ -81,3 +81,55 @@ def test_cohort_start_barrier_is_bit_identical(dev, monkeypatch, H, nq_img, size
         coh = run(_capi.ATTN_XCD_REMAP | _capi.ATTN_LP | _capi.ATTN_SORTED | _capi.ATTN_COHORT)
         torch.cuda.synchronize()
         assert torch.equal(base, coh)
+
+
+@pytest.mark.parametrize("period_us", [1, 37, 5000])
+def test_rotated_list_walk_equals_the_ascending_walk_within_rounding(dev, monkeypatch, period_us):
+    """JENGA_ATTN_ROTATE (round-4 experiment): every workgroup walks the unmasked part of its ascending list from a start
+    rotated by the phase of a wall-clock cursor.  The set of (query block, kv block) pairs is unchanged; only the order of
+    the online-softmax accumulation differs, so the result equals the ascending walk's within fp32 rounding of the running
+    sums (the bound of the two-kernel comparison), and V == 1 still gives exactly-one rows."""
+    from jenga_amd import _capi
+    monkeypatch.setenv("JENGA_ROTATE_PERIOD_US", str(period_us))
+    H, nq_img, tb = 3, 150, 2
+    q, k, v, mask = _rand_case(1234, H, nq_img, tb, "bfloat16", 0.35, 0.0)
+    nb = nq_img + tb
+    idx, cnt = lists_from_mask(mask, dev)
+    vt = _capi.pack_v(v.to(dev), nb)
+    seqlens = torch.tensor([nq_img * 128 + 70], dtype=torch.int32, device=dev)
+    base_fl = _capi.ATTN_XCD_REMAP | _capi.ATTN_LP | _capi.ATTN_SORTED
+    run = lambda fl, vt_: _capi.bsattn_fwd(q.to(dev), k.to(dev), vt_, seqlens, idx, cnt, nq_img, 128 ** -0.5, 0.3, nq_img, flags=fl)
+    ref = run(base_fl, vt)
+    rot = run(base_fl | _capi.ATTN_ROTATE, vt)
+    torch.cuda.synchronize()
+    d = (ref.float() - rot.float()).abs()
+    assert float(d.max()) <= 2e-2 and float(d.mean()) <= 5e-4, (float(d.max()), float(d.mean()))
+    ones = _capi.pack_v(torch.ones_like(v).to(dev), nb)
+    o1 = run(base_fl | _capi.ATTN_ROTATE, ones)
+    valid_rows = nq_img * 128 + 70
+    assert torch.all((o1[:, :valid_rows].float() - 1).abs() <= 2 ** -7)
+
+
+@pytest.mark.parametrize("slots", [64, 7])
+def test_rotated_walk_position_mode_is_deterministic(dev, monkeypatch, slots):
+    """JENGA_ROTATE_SLOTS (the deterministic form of JENGA_ATTN_ROTATE): the rotation of a workgroup is a pure function of
+    its position in its XCD's launch queue -- two runs give the same bits; the result equals the ascending walk's within
+    fp32 rounding of the running sums."""
+    from jenga_amd import _capi
+    monkeypatch.setenv("JENGA_ROTATE_SLOTS", str(slots))
+    H, nq_img, tb = 2, 200, 2
+    q, k, v, mask = _rand_case(4321, H, nq_img, tb, "bfloat16", 0.3, 0.0)
+    nb = nq_img + tb
+    idx, cnt = lists_from_mask(mask, dev)
+    vt = _capi.pack_v(v.to(dev), nb)
+    seqlens = torch.tensor([nq_img * 128 + 70], dtype=torch.int32, device=dev)
+    base_fl = _capi.ATTN_XCD_REMAP | _capi.ATTN_LP | _capi.ATTN_SORTED
+    run = lambda fl: _capi.bsattn_fwd(q.to(dev), k.to(dev), vt, seqlens, idx, cnt, nq_img, 128 ** -0.5, 0.3, nq_img, flags=fl)
+    ref = run(base_fl)
+    r1 = run(base_fl | _capi.ATTN_ROTATE)
+    r2 = run(base_fl | _capi.ATTN_ROTATE)
+    torch.cuda.synchronize()
+    assert torch.equal(r1, r2)
+    assert not torch.equal(r1, ref)                      # (the order of accumulation really differs)
+    d = (ref.float() - r1.float()).abs()
+    assert float(d.max()) <= 2e-2 and float(d.mean()) <= 5e-4, (float(d.max()), float(d.mean()))

@@ -195,4 +195,127 @@ I)
   JENGA_DEVICE_GUARD=always run I_s8_base_old $S
   brief $O/I_*.json
   ;;
+J)
+  # rotated list walk (JENGA_ATTN_ROTATE = 128): parity, then the period sweep against the default order on one box
+  timeout 600 python -m pytest tests/test_gpu_order.py tests/test_gpu_parity.py -q -m gpu -x > $O/J_tests.log 2>&1; grep -E "passed|failed" $O/J_tests.log; grep -E "^E " $O/J_tests.log | head -5
+  ba() { tag=$1; shift; timeout 600 python tools/bench_attn.py "$@" > $O/J_attn_$tag.json 2> $O/J_attn_$tag.err; python - $O/J_attn_$tag.json $tag <<'PY'
+import json,sys
+try:
+    d=json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+    print(sys.argv[2], {k: (round(d[k],3) if isinstance(d[k],float) else d[k]) for k in ("attn_ms","attn_TFLOPs","kept_mean","adjacent_shared_frac","flags","finite") if k in d})
+except Exception as e:
+    print(sys.argv[2], "FAILED", e)
+PY
+  }
+  A="--drop 0.7 --iters 60 --attn-only"
+  ba flat_base $A --flags 25
+  for P in 500 700 800 875 950 1100 1500; do JENGA_ROTATE_PERIOD_US=$P ba flat_rot$P $A --flags 153; done
+  ba flat_base2 $A --flags 25
+  JENGA_ROTATE_PERIOD_US=875 ba coh3_rot875 $A --coherent 3 --gain 2 --flags 153
+  ba coh3_base $A --coherent 3 --gain 2 --flags 25
+  ;;
+K)
+  # rotated walk: the deterministic position mode against the clock mode and the default order; counters; the whole loop
+  timeout 600 python -m pytest tests/test_gpu_order.py -q -m gpu -x > $O/K_tests.log 2>&1; grep -E "passed|failed" $O/K_tests.log; grep -E "^E " $O/K_tests.log | head -5
+  ba() { tag=$1; shift; timeout 600 python tools/bench_attn.py "$@" > $O/K_attn_$tag.json 2> $O/K_attn_$tag.err; python - $O/K_attn_$tag.json $tag <<'PY'
+import json,sys
+try:
+    d=json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+    print(sys.argv[2], {k: (round(d[k],3) if isinstance(d[k],float) else d[k]) for k in ("attn_ms","attn_TFLOPs","kept_mean","adjacent_shared_frac","flags","finite") if k in d})
+except Exception as e:
+    print(sys.argv[2], "FAILED", e)
+PY
+  }
+  A="--drop 0.7 --iters 60 --attn-only"
+  ba flat_base $A --flags 25
+  JENGA_ROTATE_PERIOD_US=875 ba flat_clock875 $A --flags 153
+  for S in 48 56 64 72 96 128; do JENGA_ROTATE_SLOTS=$S ba flat_pos$S $A --flags 153; done
+  ba flat_base2 $A --flags 25
+  JENGA_ROTATE_SLOTS=64 ba coh3_pos64 $A --coherent 3 --gain 2 --flags 153
+  ba coh3_base $A --coherent 3 --gain 2 --flags 25
+  JENGA_ROTATE_SLOTS=64 ba n8_pos64 --heads 3 --drop 0.75 --iters 200 --attn-only --flags 153
+  ba n8_base --heads 3 --drop 0.75 --iters 200 --attn-only --flags 25
+  JENGA_ROTATE_PERIOD_US=875 bash tools/pmc_attn2.sh r04_rot_clock --drop 0.7 --iters 2 --attn-only --flags 153 > $O/K_pmc_clock.log 2>&1; grep -A12 '"derived"' $O/K_pmc_clock.log | grep -E "per_kept_pair|l2_hit|mfma_busy|effective_clock"
+  JENGA_ROTATE_SLOTS=64 bash tools/pmc_attn2.sh r04_rot_pos --drop 0.7 --iters 2 --attn-only --flags 153 > $O/K_pmc_pos.log 2>&1; grep -A12 '"derived"' $O/K_pmc_pos.log | grep -E "per_kept_pair|l2_hit|mfma_busy|effective_clock"
+  B="--no-cpu-baseline --no-dense-ref --no-secondary --no-wan-extra"
+  run K_default $B
+  JENGA_ATTN_FLAGS=153 JENGA_ROTATE_SLOTS=64 run K_rot_pos64 $B
+  JENGA_ATTN_FLAGS=153 JENGA_ROTATE_PERIOD_US=875 run K_rot_clock875 $B
+  brief $O/K_default.json $O/K_rot_*.json
+  ;;
+L)
+  # rotated walk, clock mode: automatic period (the previous launch's workgroup lifetime) vs fixed periods, pacing, the loop
+  timeout 600 python -m pytest tests/test_gpu_order.py -q -m gpu -x > $O/L_tests.log 2>&1; grep -E "passed|failed" $O/L_tests.log; grep -E "^E " $O/L_tests.log | head -5
+  ba() { tag=$1; shift; timeout 600 python tools/bench_attn.py "$@" > $O/L_attn_$tag.json 2> $O/L_attn_$tag.err; python - $O/L_attn_$tag.json $tag <<'PY'
+import json,sys
+try:
+    d=json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+    print(sys.argv[2], {k: (round(d[k],3) if isinstance(d[k],float) else d[k]) for k in ("attn_ms","attn_TFLOPs","kept_mean","adjacent_shared_frac","flags","finite") if k in d})
+except Exception as e:
+    print(sys.argv[2], "FAILED", e)
+PY
+  }
+  A="--drop 0.7 --iters 60 --attn-only"
+  ba flat_base $A --flags 25
+  ba flat_auto $A --flags 153
+  JENGA_ROTATE_PERIOD_US=875 ba flat_875 $A --flags 153
+  for PC in 10 25 50 100; do JENGA_ROTATE_PERIOD_US=875 JENGA_ROTATE_PACE_US=$PC ba flat_875_pace$PC $A --flags 153; done
+  ba flat_base2 $A --flags 25
+  ba d80_base --drop 0.8 --iters 60 --attn-only --flags 25
+  ba d80_auto --drop 0.8 --iters 60 --attn-only --flags 153
+  JENGA_ROTATE_PERIOD_US=875 ba d80_875 --drop 0.8 --iters 60 --attn-only --flags 153
+  ba n8_base --heads 3 --drop 0.75 --iters 200 --attn-only --flags 25
+  ba n8_auto --heads 3 --drop 0.75 --iters 200 --attn-only --flags 153
+  ba coh3_base $A --coherent 3 --gain 2 --flags 25
+  ba coh3_auto $A --coherent 3 --gain 2 --flags 153
+  B="--no-cpu-baseline --no-dense-ref --no-secondary --no-wan-extra"
+  run L_default $B
+  JENGA_ATTN_FLAGS=153 run L_rot_auto $B
+  run L_default2 $B
+  JENGA_ATTN_FLAGS=153 run L_rot_auto2 $B
+  brief $O/L_default*.json $O/L_rot_*.json
+  ;;
+M)
+  # rotated walk with the mid-queue period estimate: attention A/B, then the default command with its attn_rotate leg
+  timeout 600 python -m pytest tests/test_gpu_order.py -q -m gpu -x > $O/M_tests.log 2>&1; grep -E "passed|failed" $O/M_tests.log; grep -E "^E " $O/M_tests.log | head -5
+  ba() { tag=$1; shift; timeout 600 python tools/bench_attn.py "$@" > $O/M_attn_$tag.json 2> $O/M_attn_$tag.err; python - $O/M_attn_$tag.json $tag <<'PY'
+import json,sys
+try:
+    d=json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+    print(sys.argv[2], {k: (round(d[k],3) if isinstance(d[k],float) else d[k]) for k in ("attn_ms","attn_TFLOPs","kept_mean","adjacent_shared_frac","flags","finite") if k in d})
+except Exception as e:
+    print(sys.argv[2], "FAILED", e)
+PY
+  }
+  A="--drop 0.7 --iters 60 --attn-only"
+  ba flat_base $A --flags 25
+  ba flat_auto $A --flags 153
+  JENGA_ROTATE_PERIOD_US=875 ba flat_875 $A --flags 153
+  ba flat_auto2 $A --flags 153
+  ba flat_base2 $A --flags 25
+  ba n8_base --heads 3 --drop 0.75 --iters 200 --attn-only --flags 25
+  ba n8_auto --heads 3 --drop 0.75 --iters 200 --attn-only --flags 153
+  bash tools/pmc_attn2.sh r04_rot_auto --drop 0.7 --iters 3 --attn-only --flags 153 > $O/M_pmc_auto.log 2>&1; grep -A12 '"derived"' $O/M_pmc_auto.log | grep -E "per_kept_pair|l2_hit|mfma_busy|effective_clock"
+  run M_default --no-cpu-baseline --no-wan-extra --no-secondary
+  brief $O/M_default.json
+  python - $O/M_default.json <<'PY'
+import json,sys
+d=json.loads([l for l in open(sys.argv[1]).read().strip().splitlines() if l.startswith("{")][-1])
+print(d["extra"]["attn_rotate"])
+PY
+  ;;
+N)
+  # the oracle-level parity tests with the rotated walk as the default flags (which tests hold, which bit-exactness claims
+  # do not), then the final default record with the attn_rotate leg, then the full suite at HEAD
+  JENGA_ATTN_FLAGS=153 timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_dit.py tests/test_gpu_wan_dit.py tests/test_gpu_select.py tests/test_gpu_fused.py -q -m gpu > $O/N_rotate_parity.log 2>&1; grep -E "passed|failed" $O/N_rotate_parity.log; grep -E "^FAILED" $O/N_rotate_parity.log | head -20
+  JENGA_ATTN_FLAGS=153 timeout 900 python -m pytest tests/test_gpu_sp_dit.py tests/test_gpu_ulysses.py tests/test_gpu_rccl.py -q -m gpu > $O/N_rotate_sp.log 2>&1; grep -E "passed|failed" $O/N_rotate_sp.log; grep -E "^FAILED" $O/N_rotate_sp.log | head -20
+  run N_default
+  brief $O/N_default.json
+  python - $O/N_default.json <<'PY'
+import json,sys
+d=json.loads([l for l in open(sys.argv[1]).read().strip().splitlines() if l.startswith("{")][-1])
+print(d["extra"]["attn_rotate"]["ms_per_computed_step"], d["extra"]["attn_rotate"]["s_per_video_estimate"], d["extra"]["attn_rotate"]["attention_frac_of_peak"])
+PY
+  timeout 1500 python -m pytest tests -q -m gpu > $O/N_suite.log 2>&1; grep -E "passed|failed" $O/N_suite.log
+  ;;
 esac
