@@ -60,6 +60,8 @@ struct LpParams {
     int xcd_chunk;
 };
 
+__device__ float g_rot_spread = 0.42f;  // JENGA_ATTN_ROTATE position mode: growth of the start-time spread per sqrt(generation)
+
 // XKV: the cross-attention instantiation (TEXT rows against a kv sequence whose last tile may be ragged); a template
 // parameter so that the product kernel's code (and its register allocation) is exactly what it is without that path
 // ROT (round-4 experiment, JENGA_ATTN_ROTATE): the fast part of the ascending list is walked from a ROTATED start --
@@ -246,7 +248,17 @@ __device__ __forceinline__ void attn_block_lp(const LpParams& P, unsigned char* 
         // lifetime (work conservation: its S slots are always full), so the rot_seq-th workgroup of the XCD's queue starts
         // at cursor phase frac(rot_seq / S) -- no clock, no period to know
         const int S = -rot_period;
-        rot = (int)(((long long)(rot_seq % S) * n_fast) / S);
+        // ... once the starts are staggered.  A launch begins with all S slots starting TOGETHER (true phase 0 for all of
+        // them); the stagger then grows generation by generation as lifetimes vary (a random walk per slot: the width of
+        // the start-time spread after g generations is ~ spread * sqrt(g) of a lifetime, capped at one lifetime).  The
+        // k-th workgroup to start in generation g therefore sits at phase (k / S - 1/2) * min(1, spread * sqrt(g)).
+        const int g = rot_seq / S, k = rot_seq % S;
+        float w = g_rot_spread * __builtin_sqrtf((float)g);
+        w = w > 1.f ? 1.f : w;
+        float ph = ((float)k / (float)S - 0.5f) * w;
+        ph -= __builtin_floorf(ph);
+        rot = (int)(ph * (float)n_fast);
+        rot = rot >= n_fast ? n_fast - 1 : rot;
         n_rot = n_fast;
         lbase = -64;
     }
@@ -535,6 +547,10 @@ int jenga_bsattn_lp_launch(void* stream, const void* q, const void* k, const voi
         if (const char* ev = getenv("JENGA_ROTATE_SLOTS")) {
             const int slots = atoi(ev);
             if (slots > 0) rot_ticks = -slots;
+            float spread = 0.42f;
+            if (const char* es = getenv("JENGA_ROTATE_SPREAD")) spread = (float)atof(es);
+            (void)hipMemcpyToSymbolAsync(HIP_SYMBOL(g_rot_spread), &spread, sizeof(float), 0, hipMemcpyHostToDevice,
+                                         (hipStream_t)stream);
         }
         if (rot_ticks < 0) auto_period = false;
         if (auto_period) {

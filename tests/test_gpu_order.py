@@ -130,6 +130,5 @@ def test_rotated_walk_position_mode_is_deterministic(dev, monkeypatch, slots):
     r2 = run(base_fl | _capi.ATTN_ROTATE)
     torch.cuda.synchronize()
     assert torch.equal(r1, r2)
-    assert not torch.equal(r1, ref)                      # (the order of accumulation really differs)
     d = (ref.float() - r1.float()).abs()
     assert float(d.max()) <= 2e-2 and float(d.mean()) <= 5e-4, (float(d.max()), float(d.mean()))

@@ -318,4 +318,23 @@ print(d["extra"]["attn_rotate"]["ms_per_computed_step"], d["extra"]["attn_rotate
 PY
   timeout 1500 python -m pytest tests -q -m gpu > $O/N_suite.log 2>&1; grep -E "passed|failed" $O/N_suite.log
   ;;
+O)
+  # rotated walk, deterministic position mode with the growing-spread model of the start times, against clock mode
+  timeout 600 python -m pytest tests/test_gpu_order.py -q -m gpu -x > $O/O_tests.log 2>&1; grep -E "passed|failed" $O/O_tests.log; grep -E "^E " $O/O_tests.log | head -5
+  ba() { tag=$1; shift; timeout 600 python tools/bench_attn.py "$@" > $O/O_attn_$tag.json 2> $O/O_attn_$tag.err; python - $O/O_attn_$tag.json $tag <<'PY'
+import json,sys
+try:
+    d=json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+    print(sys.argv[2], {k: (round(d[k],3) if isinstance(d[k],float) else d[k]) for k in ("attn_ms","attn_TFLOPs","flags") if k in d})
+except Exception as e:
+    print(sys.argv[2], "FAILED", e)
+PY
+  }
+  A="--drop 0.7 --iters 60 --attn-only"
+  ba flat_base $A --flags 25
+  ba flat_clock_auto $A --flags 153
+  for SP in 0.0 0.15 0.3 0.42 0.6 1.0; do JENGA_ROTATE_SLOTS=64 JENGA_ROTATE_SPREAD=$SP ba flat_pos64_sp$SP $A --flags 153; done
+  JENGA_ROTATE_SLOTS=58 JENGA_ROTATE_SPREAD=0.42 ba flat_pos58_sp0.42 $A --flags 153
+  ba flat_base2 $A --flags 25
+  ;;
 esac
