@@ -337,4 +337,26 @@ PY
   JENGA_ROTATE_SLOTS=58 JENGA_ROTATE_SPREAD=0.42 ba flat_pos58_sp0.42 $A --flags 153
   ba flat_base2 $A --flags 25
   ;;
+P)
+  # final records at HEAD: suite, smoke, the default command (with its attn_rotate and Wan legs), the Wan line in both modes
+  timeout 1500 python -m pytest tests -q -m gpu > $O/P_suite.log 2>&1; grep -E "passed|failed" $O/P_suite.log
+  python __graft_entry__.py --smoke > $O/P_smoke.log 2>&1; tail -1 $O/P_smoke.log
+  T0=$(date +%s); python bench.py > $O/P_default.json 2> $O/P_default.err; T1=$(date +%s); echo "default bench wall seconds: $((T1-T0))"
+  brief $O/P_default.json
+  python - $O/P_default.json <<'PY'
+import json,sys
+d=json.loads([l for l in open(sys.argv[1]).read().strip().splitlines() if l.startswith("{")][-1])
+print(d["extra"]["attn_rotate"]["ms_per_computed_step"], d["extra"]["attn_rotate"]["s_per_video_estimate"], d["extra"]["attn_rotate"]["attention_frac_of_peak"], d["extra"]["wan14b"]["s_per_video_two_rate_estimate"])
+PY
+  timeout 900 python bench.py --workload wan14b --no-cpu-baseline > $O/P_wan14b.json 2> $O/P_wan14b.err; python - $O/P_wan14b.json <<'PY'
+import json,sys
+d=json.loads([l for l in open(sys.argv[1]).read().strip().splitlines() if l.startswith("{")][-1])
+print("wan default", d["value"], d["roofline"]["frac"])
+PY
+  JENGA_ATTN_FLAGS=153 timeout 900 python bench.py --workload wan14b --no-cpu-baseline > $O/P_wan14b_rotate.json 2> $O/P_wan14b_rotate.err; python - $O/P_wan14b_rotate.json <<'PY'
+import json,sys
+d=json.loads([l for l in open(sys.argv[1]).read().strip().splitlines() if l.startswith("{")][-1])
+print("wan rotate", d["value"], d["roofline"]["frac"])
+PY
+  ;;
 esac
