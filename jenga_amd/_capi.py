@@ -23,6 +23,22 @@ ATTN_PAIR = 64       # (Python-side, experiment) route to jenga_bsattn_pair_fwd:
 # default: LP kernel, XCD remap, kept-count-aware order inside every XCD's range (+3.3 % sustained on lists whose counts
 # vary, neutral on constant counts: profiles/r03_attn_order_ab.json)
 ATTN_DEFAULT_FLAGS = int(os.environ.get("JENGA_ATTN_FLAGS", str(ATTN_XCD_REMAP | ATTN_LP | ATTN_SORTED)))
+
+
+def set_attention_mode(mode):
+    """"deterministic" (default: ascending list walk; bit-reproducible, the N-rank sequence-parallel forward equals the
+    single-rank one bit for bit) or "throughput" (JENGA_ATTN_ROTATE: rotated list walk on a clock cursor, -2..3 % loop time,
+    results equal within fp32 rounding of the running sums but not bit-reproducible).  Same as JENGA_ATTN_FLAGS=25 / 153."""
+    global ATTN_DEFAULT_FLAGS
+    if mode == "deterministic":
+        ATTN_DEFAULT_FLAGS &= ~ATTN_ROTATE
+    elif mode == "throughput":
+        ATTN_DEFAULT_FLAGS |= ATTN_ROTATE
+    else:
+        raise ValueError("attention mode must be 'deterministic' or 'throughput'")
+    return ATTN_DEFAULT_FLAGS
+
+
 SELECT_DEVICE_SCAN = 1   # jenga_block_select flags: torch's DEVICE cumsum semantics for the kept-count rule
 SELECT_DEFAULT_FLAGS = int(os.environ.get("JENGA_SELECT_FLAGS", "0"))
 
