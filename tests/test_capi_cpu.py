@@ -126,3 +126,19 @@ def test_ctypes_signatures_match_the_header_parameter_by_parameter():
         assert len(params) == len(args), f"{name}: header has {len(params)} parameters, ctypes {len(args)}"
         for i, (p_, a_) in enumerate(zip(params, args)):
             assert kind_of(p_) == kinds[a_], f"{name}: parameter {i} ({p_.strip()!r}) bound as {a_.__name__}"
+
+
+def test_attention_mode_switch():
+    """_capi.set_attention_mode: the deterministic default (ascending list walk) and the opt-in throughput mode
+    (JENGA_ATTN_ROTATE) differ in exactly that flag."""
+    from jenga_amd import _capi
+    before = _capi.ATTN_DEFAULT_FLAGS
+    try:
+        assert _capi.set_attention_mode("throughput") & _capi.ATTN_ROTATE
+        assert not (_capi.set_attention_mode("deterministic") & _capi.ATTN_ROTATE)
+        assert _capi.ATTN_DEFAULT_FLAGS == before & ~_capi.ATTN_ROTATE
+        import pytest
+        with pytest.raises(ValueError):
+            _capi.set_attention_mode("fast")
+    finally:
+        _capi.ATTN_DEFAULT_FLAGS = before

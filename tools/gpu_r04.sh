@@ -359,4 +359,11 @@ d=json.loads([l for l in open(sys.argv[1]).read().strip().splitlines() if l.star
 print("wan rotate", d["value"], d["roofline"]["frac"])
 PY
   ;;
+Q)
+  # the full 50-step loop, measured, in both launch modes on one box
+  B="--steps 50 --no-cpu-baseline --no-dense-ref --no-secondary --no-wan-extra --no-rotate-ref"
+  run Q_full50_default $B
+  JENGA_ATTN_FLAGS=153 run Q_full50_rotate $B
+  brief $O/Q_*.json
+  ;;
 esac
