@@ -383,8 +383,9 @@ __device__ int g_rot_T_est = 87500;     // lifetime of the image workgroup that 
 #define LP_THREADS 256
 // VARIANT 0: the product kernel.  1: + the cohort start barrier.  2: dense cross-attention (jenga_cross_attn_fwd):
 // TEXT-mode rows only, kv-length mask on the last tile.  3: rotated list walk (JENGA_ATTN_ROTATE).  Separate
-// instantiations on purpose (see above).  (A fourth, rotation + pacing -- a workgroup ahead of the cursor sleeps -- lost
-// 10 % and is gone: profiles/r04_attn_rotate_ab.json.)
+// instantiations on purpose (see above).  (Two more were measured and removed: rotation + pacing -- a workgroup ahead of the
+// cursor sleeps -- lost 10 %; rotation + whole heads per XCD got the L2 hit rate to 47 % and 35.5 KB per kept pair but ran
+// 2 % behind plain rotation: eight heads in flight overflow the Infinity Cache.  profiles/r04_attn_rotate_ab.json.)
 template <typename T, int VARIANT>
 __global__ void __launch_bounds__(LP_THREADS, 2) bsattn_lp_kernel(LpParams P) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];

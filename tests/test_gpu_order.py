@@ -132,3 +132,4 @@ def test_rotated_walk_position_mode_is_deterministic(dev, monkeypatch, slots):
     assert torch.equal(r1, r2)
     d = (ref.float() - r1.float()).abs()
     assert float(d.max()) <= 2e-2 and float(d.mean()) <= 5e-4, (float(d.max()), float(d.mean()))
+

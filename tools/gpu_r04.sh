@@ -366,4 +366,25 @@ Q)
   JENGA_ATTN_FLAGS=153 run Q_full50_rotate $B
   brief $O/Q_*.json
   ;;
+R)
+  # rotated walk with whole heads per XCD against the default partition
+  timeout 600 python -m pytest tests/test_gpu_order.py -q -m gpu -x > $O/R_tests.log 2>&1; grep -E "passed|failed" $O/R_tests.log; grep -E "^E " $O/R_tests.log | head -5
+  ba() { tag=$1; shift; timeout 600 python tools/bench_attn.py "$@" > $O/R_attn_$tag.json 2> $O/R_attn_$tag.err; python - $O/R_attn_$tag.json $tag <<'PY'
+import json,sys
+try:
+    d=json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+    print(sys.argv[2], {k: (round(d[k],3) if isinstance(d[k],float) else d[k]) for k in ("attn_ms","attn_TFLOPs","flags") if k in d})
+except Exception as e:
+    print(sys.argv[2], "FAILED", e)
+PY
+  }
+  A="--drop 0.7 --iters 60 --attn-only"
+  ba flat_base $A --flags 25
+  ba flat_rot $A --flags 153
+  JENGA_ROTATE_HEADMAP=1 ba flat_rot_headmap $A --flags 153
+  JENGA_ROTATE_HEADMAP=1 JENGA_ROTATE_PERIOD_US=875 ba flat_rot_headmap_875 $A --flags 153
+  ba flat_rot2 $A --flags 153
+  ba flat_base2 $A --flags 25
+  JENGA_ROTATE_HEADMAP=1 bash tools/pmc_attn2.sh r04_rot_headmap --drop 0.7 --iters 3 --attn-only --flags 153 > $O/R_pmc.log 2>&1; grep -A12 '"derived"' $O/R_pmc.log | grep -E "per_kept_pair|l2_hit|mfma_busy|effective_clock"
+  ;;
 esac
