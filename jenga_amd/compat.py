@@ -6,7 +6,7 @@
 
 `compat/` (repo root) holds one small re-export file per reference module on the path:
 hyvideo/modules/{attention_block_triton_diffres, attenion, posemb_layers, norm_layers, xdit_ring_atten}.py, their
-hyvideo_i2v / wan counterparts, gilbert.py and xfuser/core/distributed.py.  With the reference checkout on sys.path its
+hyvideo_i2v / wan counterparts, gilbert.py and xfuser/core/{distributed, long_ctx_attention}.py.  With the reference checkout on sys.path its
 packages (`hyvideo`, `wan`, ...) are regular packages and win over any directory added later, so a plain PYTHONPATH entry
 cannot replace single submodules; install() therefore puts a finder in front of sys.meta_path that serves exactly the
 names listed in ALIASES from compat/ and leaves every other import alone.  Parent packages that cannot be imported at
@@ -35,7 +35,8 @@ ALIASES = {
     "wan.modules.attention_block_triton_diffres": "wan/modules/attention_block_triton_diffres.py",
 }
 # served only when the real package is absent (xfuser is a third-party dependency of the reference)
-OPTIONAL_ALIASES = {"xfuser.core.distributed": "xfuser/core/distributed.py"}
+OPTIONAL_ALIASES = {"xfuser.core.distributed": "xfuser/core/distributed.py",
+                    "xfuser.core.long_ctx_attention": "xfuser/core/long_ctx_attention.py"}
 
 
 class _AliasFinder(importlib.abc.MetaPathFinder):

@@ -74,6 +74,28 @@ def init_sequence_parallel(group=None):
     return _SP_GROUP
 
 
+def init_distributed_environment(rank=None, world_size=None, **_ignored):
+    """xfuser.core.distributed.init_distributed_environment as hyvideo/inference.py:176 calls it, after
+    dist.init_process_group("nccl"): nothing to set up beyond checking that the process group is the one described."""
+    if not dist.is_initialized():
+        raise RuntimeError("call torch.distributed.init_process_group('nccl') first (hyvideo/inference.py:171)")
+    if rank is not None and rank != dist.get_rank() or world_size is not None and world_size != dist.get_world_size():
+        raise ValueError("init_distributed_environment: rank / world_size disagree with the process group")
+
+
+def initialize_model_parallel(sequence_parallel_degree=None, ring_degree=1, ulysses_degree=None, **_ignored):
+    """xfuser.core.distributed.initialize_model_parallel as hyvideo/inference.py:178-182 calls it: Jenga's sequence-parallel
+    path is Ulysses only (the reference's ring attention is dead code for it): the whole world is one
+    sequence-parallel group."""
+    if ring_degree not in (None, 1):
+        raise ValueError("jenga_amd: ring_degree must be 1 (Ulysses sequence parallelism only)")
+    n = dist.get_world_size()
+    for name, v in (("sequence_parallel_degree", sequence_parallel_degree), ("ulysses_degree", ulysses_degree)):
+        if v is not None and v != n:
+            raise ValueError(f"jenga_amd: {name}={v} must equal the world size {n}")
+    return init_sequence_parallel()
+
+
 def set_thread_sp_group(group_like):
     """Per-thread override of the sequence-parallel group: an object with .size(), .rank(), .all_gather(x, dim).
     tests/test_gpu_sp_dit.py runs N simulated ranks as N threads of one process, each with its own in-process group;

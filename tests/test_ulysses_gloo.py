@@ -58,7 +58,11 @@ def _worker(rank, world, port, ret, mode):
     try:
         from jenga_amd.modules import ulysses
         from jenga_amd.modules.attention import my_parallel_attention
-        ulysses.init_sequence_parallel()
+        # the way hyvideo/inference.py:171-182 sets the group up (through compat/xfuser/core/distributed.py)
+        ulysses.init_distributed_environment(rank=rank, world_size=world)
+        ulysses.initialize_model_parallel(sequence_parallel_degree=world, ring_degree=1, ulysses_degree=world)
+        with pytest.raises(ValueError):
+            ulysses.initialize_model_parallel(sequence_parallel_degree=world, ring_degree=2, ulysses_degree=1)
         assert ulysses.get_sequence_parallel_world_size() == world and ulysses.get_sequence_parallel_rank() == rank
         q, k, v, nbm, nimg, tb = _make_case()
         S_img = nimg * 128
