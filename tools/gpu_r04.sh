@@ -387,4 +387,11 @@ PY
   ba flat_base2 $A --flags 25
   JENGA_ROTATE_HEADMAP=1 bash tools/pmc_attn2.sh r04_rot_headmap --drop 0.7 --iters 3 --attn-only --flags 153 > $O/R_pmc.log 2>&1; grep -A12 '"derived"' $O/R_pmc.log | grep -E "per_kept_pair|l2_hit|mfma_busy|effective_clock"
   ;;
+S)
+  # HEAD check: suite, smoke, a short default run
+  timeout 1500 python -m pytest tests -q -m gpu > $O/S_suite.log 2>&1; grep -E "passed|failed" $O/S_suite.log
+  python __graft_entry__.py --smoke > $O/S_smoke.log 2>&1; tail -1 $O/S_smoke.log
+  run S_default --no-cpu-baseline --no-wan-extra --no-secondary --no-dense-ref
+  brief $O/S_default.json
+  ;;
 esac
