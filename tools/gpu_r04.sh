@@ -394,4 +394,25 @@ S)
   run S_default --no-cpu-baseline --no-wan-extra --no-secondary --no-dense-ref
   brief $O/S_default.json
   ;;
+T)
+  # rotated walk + laggard jumps against plain rotation and the default order
+  timeout 600 python -m pytest tests/test_gpu_order.py -q -m gpu -x > $O/T_tests.log 2>&1; grep -E "passed|failed" $O/T_tests.log; grep -E "^E " $O/T_tests.log | head -5
+  ba() { tag=$1; shift; timeout 600 python tools/bench_attn.py "$@" > $O/T_attn_$tag.json 2> $O/T_attn_$tag.err; python - $O/T_attn_$tag.json $tag <<'PY'
+import json,sys
+try:
+    d=json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+    print(sys.argv[2], {k: (round(d[k],3) if isinstance(d[k],float) else d[k]) for k in ("attn_ms","attn_TFLOPs","flags","finite") if k in d})
+except Exception as e:
+    print(sys.argv[2], "FAILED", e)
+PY
+  }
+  A="--drop 0.7 --iters 60 --attn-only"
+  ba flat_base $A --flags 25
+  ba flat_rot $A --flags 153
+  JENGA_ROTATE_JUMP=1 ba flat_rot_jump $A --flags 153
+  JENGA_ROTATE_JUMP=1 JENGA_ROTATE_PERIOD_US=875 ba flat_rot_jump_875 $A --flags 153
+  ba flat_rot2 $A --flags 153
+  ba flat_base2 $A --flags 25
+  JENGA_ROTATE_JUMP=1 bash tools/pmc_attn2.sh r04_rot_jump --drop 0.7 --iters 3 --attn-only --flags 153 > $O/T_pmc.log 2>&1; grep -A12 '"derived"' $O/T_pmc.log | grep -E "per_kept_pair|l2_hit|mfma_busy|effective_clock"
+  ;;
 esac

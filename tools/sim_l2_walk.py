@@ -8,10 +8,11 @@ run workgroups back to back, each walks a random 31.6 % list of 900 kv blocks at
   none   ascending walk from entry 0 (the deterministic default)
   clock  start rotated to the phase of a clock cursor whose period is the nominal lifetime (JENGA_ATTN_ROTATE)
   jump   clock + every CHECK entries a workgroup that lags the cursor by more than 3*DELTA kv blocks moves the entries the
-         cursor has already passed to the END of its walk and continues at the cursor (no waiting; not built in the kernel)
+         cursor has already passed to the END of its walk and continues at the cursor (no waiting)
 
 Model vs counters at CV = 0.10: none 8.5 % (measured 23.8 %: every head change re-aligns the real workgroups), clock 35 %
-(measured 41.8 %), jump 55-60 % -- where the next step of this lever is, if bit-reproducibility is given up anyway."""
+(measured 41.8 %), jump 55-60 % (built in round 4 and measured at 29 %: the model's pack runs at the cursor's speed by
+construction, the real one does not -- DESIGN.md §3)."""
 import collections
 import heapq
 import sys
