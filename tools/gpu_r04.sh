@@ -367,7 +367,8 @@ Q)
   brief $O/Q_*.json
   ;;
 R)
-  # rotated walk with whole heads per XCD against the default partition
+  # rotated walk with whole heads per XCD against the default partition (variant removed after this session: the
+  # JENGA_ROTATE_HEADMAP switch exists in commit 'Rotated walk with whole heads per XCD measured' only)
   timeout 600 python -m pytest tests/test_gpu_order.py -q -m gpu -x > $O/R_tests.log 2>&1; grep -E "passed|failed" $O/R_tests.log; grep -E "^E " $O/R_tests.log | head -5
   ba() { tag=$1; shift; timeout 600 python tools/bench_attn.py "$@" > $O/R_attn_$tag.json 2> $O/R_attn_$tag.err; python - $O/R_attn_$tag.json $tag <<'PY'
 import json,sys
@@ -395,7 +396,8 @@ S)
   brief $O/S_default.json
   ;;
 T)
-  # rotated walk + laggard jumps against plain rotation and the default order
+  # rotated walk + laggard jumps against plain rotation and the default order (variant removed after these sessions: the
+  # JENGA_ROTATE_JUMP switch never reached a commit; profiles/r04_attn_rotate_ab.json holds what it measured)
   timeout 600 python -m pytest tests/test_gpu_order.py -q -m gpu -x > $O/T_tests.log 2>&1; grep -E "passed|failed" $O/T_tests.log; grep -E "^E " $O/T_tests.log | head -5
   ba() { tag=$1; shift; timeout 600 python tools/bench_attn.py "$@" > $O/T_attn_$tag.json 2> $O/T_attn_$tag.err; python - $O/T_attn_$tag.json $tag <<'PY'
 import json,sys
