@@ -396,8 +396,8 @@ S)
   brief $O/S_default.json
   ;;
 T)
-  # rotated walk + laggard jumps against plain rotation and the default order (variant removed after these sessions: the
-  # JENGA_ROTATE_JUMP switch never reached a commit; profiles/r04_attn_rotate_ab.json holds what it measured)
+  # rotated walk + laggard jumps against plain rotation and the default order (variant removed after these sessions: its
+  # source is the commit 'EXPERIMENT (reverted by the next commit): rotated walk + laggard jumps'; profiles/r04_attn_rotate_ab.json)
   timeout 600 python -m pytest tests/test_gpu_order.py -q -m gpu -x > $O/T_tests.log 2>&1; grep -E "passed|failed" $O/T_tests.log; grep -E "^E " $O/T_tests.log | head -5
   ba() { tag=$1; shift; timeout 600 python tools/bench_attn.py "$@" > $O/T_attn_$tag.json 2> $O/T_attn_$tag.err; python - $O/T_attn_$tag.json $tag <<'PY'
 import json,sys
