@@ -69,14 +69,9 @@ __device__ float g_rot_spread = 0.42f;  // JENGA_ATTN_ROTATE position mode: grow
 // that workgroups started at different times are at the same kv blocks at the same time WITHOUT waiting for each other.
 // The summation order of the online softmax then depends on the start time: results are equal within fp32 rounding of
 // the running sums, not bit-identical from run to run.  rot_period: the cursor's period in wall-clock ticks.
-// JUMP (on top of ROT, clock mode; experiment): at every reload of its list window a workgroup that LAGS the cursor moves the entries
-// the cursor has already passed to the end of its walk ("deferred arcs") and continues at the cursor -- the pack of
-// co-resident workgroups stays tight although their speeds differ by +-10 % (tools/sim_l2_walk.py).  No waiting.
-#define LP_JUMP_MIN 4
-#define LP_JUMP_ARCS 8
-template <typename T, bool TEXT, bool XKV = false, bool ROT = false, bool JUMP = false>
+template <typename T, bool TEXT, bool XKV = false, bool ROT = false>
 __device__ __forceinline__ void attn_block_lp(const LpParams& P, unsigned char* smem, int b, int h, int m,
-                                              int rot_period = 0, int rot_seq = 0, int* jump_word = nullptr) {
+                                              int rot_period = 0, int rot_seq = 0) {
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -146,34 +141,9 @@ __device__ __forceinline__ void attn_block_lp(const LpParams& P, unsigned char* 
     // kept list, 64 entries at a time in one VGPR (bsattn.hip)
     int lchunk = 0, lbase = -64;
     int rot = 0, n_rot = 0;
-    // JUMP: entries skipped so far (all / before the latest jump), the logical position of the latest jump, the logical end
-    // of the rotated middle region (behind it: the deferred arcs, walked in the order they were deferred)
-    int jshift = 0, jshift_prev = 0, jc_last = 0, n_mid = 0, n_arcs = 0;
-    int arc_s[LP_JUMP_ARCS], arc_l[LP_JUMP_ARCS];
-#pragma unroll
-    for (int a_ = 0; a_ < LP_JUMP_ARCS; ++a_) arc_s[a_] = arc_l[a_] = 0;
     auto phys = [&](int j) -> int {
         if (!ROT || j >= n_rot) return j;
-        int p_;
-        if (JUMP && j >= n_mid) {
-            int off = j - n_mid;
-            p_ = 0;
-            bool found = false;
-#pragma unroll
-            for (int a_ = 0; a_ < LP_JUMP_ARCS; ++a_) {
-                if (!found && a_ < n_arcs) {
-                    if (off < arc_l[a_]) {
-                        p_ = arc_s[a_] + off;
-                        found = true;
-                    } else {
-                        off -= arc_l[a_];
-                    }
-                }
-            }
-        } else {
-            p_ = j + rot + (JUMP ? (j >= jc_last ? jshift : jshift_prev) : 0);
-        }
-        if (JUMP && p_ >= 2 * n_rot) p_ -= 2 * n_rot;
+        const int p_ = j + rot;
         return p_ >= n_rot ? p_ - n_rot : p_;
     };
     auto blk_at = [&](int i) -> int {
@@ -212,51 +182,9 @@ __device__ __forceinline__ void attn_block_lp(const LpParams& P, unsigned char* 
         if (TEXT) return;
         const int first = t >> 1, last = (t + 7) >> 1;
         if (first < lbase || last >= lbase + 64) {
-            int c_ = 0;
-            const bool may_jump = JUMP && rot_period > 0 && n_arcs < LP_JUMP_ARCS && first + 2 * LP_JUMP_MIN + 12 < n_mid;
-            if (may_jump) {
-                // the jump decision rides on the window reload (once per ~60 entries): ONE clock reading for the workgroup,
-                // through a global word (the LDS is full), its four waves share the tile order
-                if (tid == 0)
-                    __hip_atomic_store(jump_word, (int)((unsigned long long)wall_clock64() % (unsigned long long)rot_period),
-                                       __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-                __syncthreads();
-                c_ = __hip_atomic_load(jump_word, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
-            }
             lbase = first;
             lchunk = (lbase + lane < nkept) ? list[phys(lbase + lane)] : 0;
             __builtin_amdgcn_s_waitcnt(0x0F70);
-            if (may_jump) {
-                // entries first and first + 1 (lanes 0, 1) are staged or about to be under the mapping in force; which of
-                // the entries behind them has the cursor already passed?
-                c_ = __builtin_amdgcn_readfirstlane(c_);
-                const int nimg = P.text_block_start;
-                const int ckv = (int)(((long long)c_ * nimg) / rot_period);
-                int d_ = ckv - lchunk;
-                d_ = d_ < 0 ? d_ + nimg : d_;
-                const bool behind = lane >= 2 && (lbase + lane < n_mid) && d_ > 0 && d_ < (nimg >> 1);
-                const unsigned long long msk = __builtin_amdgcn_ballot_w64(behind) >> 2;
-                int skip = (~msk == 0ull) ? 62 : __builtin_ctzll(~msk);       // the run of passed entries behind lane 1
-                const int jc = first + 2, room = n_mid - jc - 8;
-                skip = skip > 62 ? 62 : skip;
-                skip = skip > room ? room : skip;
-                if (skip >= LP_JUMP_MIN) {
-                    const int first_phys = phys(jc);
-#pragma unroll
-                    for (int a_ = 0; a_ < LP_JUMP_ARCS; ++a_)
-                        if (a_ == n_arcs) {
-                            arc_s[a_] = first_phys;
-                            arc_l[a_] = skip;
-                        }
-                    ++n_arcs;
-                    jshift_prev = jshift;
-                    jshift += skip;
-                    jc_last = jc;
-                    n_mid -= skip;
-                    lchunk = (lbase + lane < nkept) ? list[phys(lbase + lane)] : 0;      // the window under the new mapping
-                    __builtin_amdgcn_s_waitcnt(0x0F70);
-                }
-            }
         }
     };
     auto blk_fast = [&](int i) -> int {
@@ -313,7 +241,6 @@ __device__ __forceinline__ void attn_block_lp(const LpParams& P, unsigned char* 
         __syncthreads();
         rot = __builtin_amdgcn_readfirstlane(*reinterpret_cast<const int*>(smem));
         n_rot = n_fast;
-        n_mid = n_fast;
         lbase = -64;          // (the window holds unrotated entries from the tail scan)
         __syncthreads();
     } else if (ROT && n_fast > 1 && rot_period < 0) {
@@ -450,7 +377,6 @@ struct CohortCfg {
 };
 __device__ CohortCfg g_cohort_cfg;
 __device__ int g_rot_period_ticks;      // JENGA_ATTN_ROTATE: the cursor's period (wall-clock ticks, 100 MHz)
-__device__ int g_rot_jump_words[65536]; // JUMP: one word per workgroup for the clock reading its four waves share
 __device__ int g_rot_T_est = 87500;     // lifetime of the image workgroup that finished last (ticks): the NEXT launch's period
                                         // in auto mode (copied device-to-device on the launch stream; 875 us to begin with)
 
@@ -504,7 +430,7 @@ __global__ void __launch_bounds__(LP_THREADS, 2) bsattn_lp_kernel(LpParams P) {
         __syncthreads();
     }
     if (P.order) m = P.order[(long long)bh * P.nq_img + m];   // kept-count-aware order inside the XCD's range
-    if (VARIANT == 3 || VARIANT == 4) {
+    if (VARIANT == 3) {
         int seq = li, seq_total = P.B * P.H * P.img_per_head;
         if (P.xcd_chunk) {      // this workgroup's number in its XCD's queue (launch positions, before the count order)
             int nv = P.nq_img - (r & 7) * P.xcd_chunk;
@@ -515,11 +441,7 @@ __global__ void __launch_bounds__(LP_THREADS, 2) bsattn_lp_kernel(LpParams P) {
         int period = g_rot_period_ticks;
         if (period > 0) period = period < 5000 ? 5000 : (period > 1000000 ? 1000000 : period);   // 50 us .. 10 ms
         const long long t_start = (long long)wall_clock64();
-        if (VARIANT == 4)
-            attn_block_lp<T, false, false, true, true>(P, smem, bh / P.H, bh % P.H, m, period, seq,
-                                                       g_rot_jump_words + (blockIdx.x & 65535));
-        else
-            attn_block_lp<T, false, false, true>(P, smem, bh / P.H, bh % P.H, m, period, seq);
+        attn_block_lp<T, false, false, true>(P, smem, bh / P.H, bh % P.H, m, period, seq);
         // the next launch's period (auto mode): the lifetime of a workgroup from the MIDDLE of its XCD's queue -- the last
         // ones run on a draining chip and are faster than the steady state the cursor has to match
         if (threadIdx.x == 0 && seq * 4 >= seq_total && seq * 4 < 3 * seq_total)
@@ -612,9 +534,7 @@ int jenga_bsattn_lp_launch(void* stream, const void* q, const void* k, const voi
         }
     }
     int rot_ticks = 0;
-    bool jump = false;
     if ((flags & JENGA_ATTN_ROTATE) && !cohort) {
-        if (const char* ev = getenv("JENGA_ROTATE_JUMP")) jump = atoi(ev) != 0;
         // EXPERIMENT: the period comes from the environment (microseconds; default 875 = the mean workgroup lifetime of the
         // 720p launch); written to the device global on the launch stream
         // period of the cursor: JENGA_ROTATE_PERIOD_US=<microseconds>, or (default, "auto") the lifetime of the image
@@ -646,10 +566,7 @@ int jenga_bsattn_lp_launch(void* stream, const void* q, const void* k, const voi
         }
     }
     hipError_t e;
-    if (rot_ticks > 0 && jump)
-        e = dtype == JENGA_BF16 ? lp_launch<BF16, 4>(P, grid, (hipStream_t)stream)
-                                : lp_launch<FP16, 4>(P, grid, (hipStream_t)stream);
-    else if (rot_ticks != 0)
+    if (rot_ticks != 0)
         e = dtype == JENGA_BF16 ? lp_launch<BF16, 3>(P, grid, (hipStream_t)stream)
                                 : lp_launch<FP16, 3>(P, grid, (hipStream_t)stream);
     else if (cohort)
