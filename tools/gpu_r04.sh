@@ -417,4 +417,21 @@ PY
   ba flat_base2 $A --flags 25
   JENGA_ROTATE_JUMP=1 bash tools/pmc_attn2.sh r04_rot_jump --drop 0.7 --iters 3 --attn-only --flags 153 > $O/T_pmc.log 2>&1; grep -A12 '"derived"' $O/T_pmc.log | grep -E "per_kept_pair|l2_hit|mfma_busy|effective_clock"
   ;;
+U)
+  # the rotated walk where every list is the whole sequence (the dense model's launches) and at sa-drop 0.8 / 0.85
+  ba() { tag=$1; shift; timeout 600 python tools/bench_attn.py "$@" > $O/U_attn_$tag.json 2> $O/U_attn_$tag.err; python - $O/U_attn_$tag.json $tag <<'PY'
+import json,sys
+try:
+    d=json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+    print(sys.argv[2], {k: (round(d[k],3) if isinstance(d[k],float) else d[k]) for k in ("attn_ms","attn_TFLOPs","kept_mean","flags","finite") if k in d})
+except Exception as e:
+    print(sys.argv[2], "FAILED", e)
+PY
+  }
+  ba dense_base --drop 0.0 --p 1.0 --iters 20 --attn-only --flags 25
+  ba dense_rot --drop 0.0 --p 1.0 --iters 20 --attn-only --flags 153
+  ba peaky_d85_base --drop 0.85 --p 0.3 --peaky 8 --iters 100 --attn-only --flags 25
+  ba peaky_d85_rot --drop 0.85 --p 0.3 --peaky 8 --iters 100 --attn-only --flags 153
+  ba dense_base2 --drop 0.0 --p 1.0 --iters 20 --attn-only --flags 25
+  ;;
 esac
