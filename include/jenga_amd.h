@@ -263,6 +263,13 @@ int jenga_bsattn_fwd(void* stream, const void* q, const void* k, const void* vt,
 #define JENGA_ATTN_XCD_REMAP 1 /* contiguous q-block ranges per XCD (L2 locality); 0 = plain head-major order */
 #define JENGA_ATTN_PINGPONG 2  /* EXPERIMENT (libraries built with JENGA_EXPERIMENTS only; else JENGA_EUNSUPPORTED):
                                   8-wave workgroups, MFMA / softmax phases of the two waves per SIMD in anti-phase */
+#define JENGA_ATTN_BALANCE 4   /* (round 4, LP kernel with XCD_REMAP; part of the Python modules' default) every workgroup DRAWS
+                                  its query block: a ticket from the queue of the XCD it runs on (the same contiguous range
+                                  and order as the static mapping) and, once that is empty, from the fullest other queue; the
+                                  grid is oversubscribed by 1/8.  Evens out the speed differences between the 8 XCDs of a
+                                  chip (3-8 % in workgroup lifetime).  Bit-identical results.  Every launch in flight has its
+                                  own ticket counters (64 sets per device, reused behind an event); a capturing stream gets
+                                  the static mapping */
 #define JENGA_ATTN_LP 8        /* same decomposition, in-wave software pipeline (softmax inside the MFMA stream):
                                   csrc/bsattn3.hip, the default of the Python modules (XCD_REMAP | LP) */
 #define JENGA_ATTN_COHORT 32   /* EXPERIMENT (round 4, LP kernel with XCD_REMAP only): the workgroups an XCD runs at a time

@@ -13,6 +13,8 @@ JENGA_BF16, JENGA_FP16 = 0, 1
 # jenga_bsattn_fwd flags (include/jenga_amd.h).  No kernel bit = the round-1 kernel, exactly as in the C header.
 ATTN_XCD_REMAP = 1
 ATTN_PINGPONG = 2    # experiment: needs libjenga_amd_exp.so (python -m jenga_amd.build --experiments; JENGA_LIB=...)
+ATTN_BALANCE = 4     # round 4: query blocks DRAWN from per-XCD queues on an oversubscribed grid (LP kernel + XCD remap): evens out
+#                      the speed differences between the XCDs of a chip; bit-identical; in the default since round 4
 ATTN_LEGACY = 0      # (readability alias) no kernel bit: the round-1 kernel, one query block per 4-wave workgroup
 ATTN_LP = 8          # round-1 decomposition + in-wave software pipeline (csrc/bsattn3.hip): the default
 ATTN_SORTED = 16     # (Python-side) kept-count-aware launch order: jenga_order_by_count feeds jenga_bsattn_fwd's `order`
@@ -21,14 +23,15 @@ ATTN_ROTATE = 128    # experiment (round 4): rotated list walk on a clock cursor
 ATTN_PAIR = 64       # (Python-side, experiment) route to jenga_bsattn_pair_fwd: the pair kernel; with ATTN_LP the 8-wave
 #                      LP pair (csrc/experiments/); needs libjenga_amd_exp.so
 # default: LP kernel, XCD remap, kept-count-aware order inside every XCD's range (+3.3 % sustained on lists whose counts
-# vary, neutral on constant counts: profiles/r03_attn_order_ab.json)
-ATTN_DEFAULT_FLAGS = int(os.environ.get("JENGA_ATTN_FLAGS", str(ATTN_XCD_REMAP | ATTN_LP | ATTN_SORTED)))
+# vary, neutral on constant counts: profiles/r03_attn_order_ab.json), cross-XCD balancing (+2.6 % on flat lists, +4.4 % on
+# clustered ones, -1.7 % loop time: profiles/r04_attn_balance_ab.json).  25 = the round-3 default (static mapping).
+ATTN_DEFAULT_FLAGS = int(os.environ.get("JENGA_ATTN_FLAGS", str(ATTN_XCD_REMAP | ATTN_BALANCE | ATTN_LP | ATTN_SORTED)))
 
 
 def set_attention_mode(mode):
     """"deterministic" (default: ascending list walk; bit-reproducible, the N-rank sequence-parallel forward equals the
     single-rank one bit for bit) or "throughput" (JENGA_ATTN_ROTATE: rotated list walk on a clock cursor, -2..3 % loop time,
-    results equal within fp32 rounding of the running sums but not bit-reproducible).  Same as JENGA_ATTN_FLAGS=25 / 153."""
+    results equal within fp32 rounding of the running sums but not bit-reproducible).  Same as JENGA_ATTN_FLAGS=29 / 157."""
     global ATTN_DEFAULT_FLAGS
     if mode == "deterministic":
         ATTN_DEFAULT_FLAGS &= ~ATTN_ROTATE
@@ -737,7 +740,7 @@ def bsattn_fwd(q, k, vt, seqlens, idx, cnt, nq_img, sm_scale, text_amp, text_blo
             e0.record()
         common = (B, H, n_blocks, nq_img, *_bshd_strides(q), *_bshd_strides(k), *_bshd_strides(out), float(sm_scale),
                   float(text_amp), int(text_block_start), dtype_code(q.dtype))
-        cflags = fl & (ATTN_XCD_REMAP | ATTN_PINGPONG | ATTN_LP | ATTN_COHORT | ATTN_ROTATE)
+        cflags = fl & (ATTN_XCD_REMAP | ATTN_PINGPONG | ATTN_BALANCE | ATTN_LP | ATTN_COHORT | ATTN_ROTATE)
         if not pair:
             _check(lib().jenga_bsattn_fwd(_stream(q.device), _p(q), _p(k), _p(vt), _p(out), _p(seqlens), _p(idx),
                                           _p(cnt), _p(order_t), *common, cflags), "jenga_bsattn_fwd")

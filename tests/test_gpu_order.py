@@ -133,3 +133,101 @@ def test_rotated_walk_position_mode_is_deterministic(dev, monkeypatch, slots):
     d = (ref.float() - r1.float()).abs()
     assert float(d.max()) <= 2e-2 and float(d.mean()) <= 5e-4, (float(d.max()), float(d.mean()))
 
+
+
+@pytest.mark.parametrize("H,nq_img,extra", [(3, 72, "12"), (2, 200, "0"), (1, 130, "100"), (5, 67, "12")])
+def test_balanced_launch_is_bit_identical(dev, monkeypatch, H, nq_img, extra):
+    """JENGA_ATTN_BALANCE (round 4): a workgroup DRAWS its query block -- a ticket from the queue of the XCD it runs on,
+    then from the fullest other queue -- on an oversubscribed grid.  Which workgroup computes a block does not enter the
+    result: every block exactly once, outputs bit-identical to the static mapping; also without oversubscription, with
+    twice the grid, with ragged last ranges (nq_img not a multiple of 8), and over more launches than there are counter
+    sets (the sets are reused in turn behind an event)."""
+    from jenga_amd import _capi
+    monkeypatch.setenv("JENGA_BALANCE_EXTRA_PCT", extra)
+    tb = 2
+    q, k, v, mask = _rand_case(191 + nq_img, H, nq_img, tb, "bfloat16", 0.3, 0.0)
+    nb = nq_img + tb
+    idx, cnt = lists_from_mask(mask, dev)
+    vt = _capi.pack_v(v.to(dev), nb)
+    seqlens = torch.tensor([nq_img * 128 + 70], dtype=torch.int32, device=dev)
+    qd, kd = q.to(dev), k.to(dev)
+    run = lambda fl, out=None: _capi.bsattn_fwd(qd, kd, vt, seqlens, idx, cnt, nq_img, 128 ** -0.5, 0.3, nq_img, flags=fl,
+                                                out=out)
+    base_fl = _capi.ATTN_XCD_REMAP | _capi.ATTN_LP | _capi.ATTN_SORTED
+    base = run(base_fl, torch.full((1, nb * 128, H, 128), 777.0, dtype=torch.bfloat16, device=dev))
+    for i in range(70 if extra == "12" and H == 3 else 3):
+        out = torch.full_like(base, 777.0)      # a block nobody draws would keep the fill value
+        run(base_fl | _capi.ATTN_BALANCE, out)
+        if i % 23 == 0 or i < 3:
+            torch.cuda.synchronize()
+            assert torch.equal(base, out), i
+    torch.cuda.synchronize()
+    assert torch.equal(base, out)
+
+
+def test_balanced_launches_from_concurrent_threads_and_streams(dev):
+    """Ranks simulated by threads launch on one device at the same time, each on its own stream: every launch in flight has
+    its own ticket counters, so no launch can draw from another's queue (a shared set would leave blocks uncomputed)."""
+    import threading
+    from jenga_amd import _capi
+    H, nq_img, tb = 2, 136, 2
+    nb = nq_img + tb
+    base_fl = _capi.ATTN_XCD_REMAP | _capi.ATTN_LP | _capi.ATTN_SORTED
+    seqlens = torch.tensor([nq_img * 128 + 70], dtype=torch.int32, device=dev)
+    cases = []
+    for s in range(4):
+        q, k, v, mask = _rand_case(700 + s, H, nq_img, tb, "bfloat16", 0.3, 0.0)
+        idx, cnt = lists_from_mask(mask, dev)
+        c = dict(q=q.to(dev), k=k.to(dev), vt=_capi.pack_v(v.to(dev), nb), idx=idx, cnt=cnt)
+        c["want"] = _capi.bsattn_fwd(c["q"], c["k"], c["vt"], seqlens, idx, cnt, nq_img, 128 ** -0.5, 0.3, nq_img, flags=base_fl,
+                                     out=torch.full((1, nb * 128, H, 128), 777.0, dtype=torch.bfloat16, device=dev))
+        cases.append(c)
+    torch.cuda.synchronize()
+    errors = []
+
+    def worker(c):
+        try:
+            torch.cuda.set_device(dev)
+            st = torch.cuda.Stream(device=dev)
+            with torch.cuda.stream(st):
+                for i in range(40):
+                    out = torch.full_like(c["want"], 777.0)
+                    _capi.bsattn_fwd(c["q"], c["k"], c["vt"], seqlens, c["idx"], c["cnt"], nq_img, 128 ** -0.5, 0.3, nq_img,
+                                     flags=base_fl | _capi.ATTN_BALANCE, out=out)
+                    if i % 13 == 0:
+                        st.synchronize()
+                        if not torch.equal(out, c["want"]):
+                            errors.append(i)
+                st.synchronize()
+                if not torch.equal(out, c["want"]):
+                    errors.append(-1)
+        except Exception as e:      # noqa: BLE001
+            errors.append(repr(e))
+
+    ts = [threading.Thread(target=worker, args=(c,)) for c in cases]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errors, errors
+
+
+def test_balanced_and_rotated_walk_together(dev, monkeypatch):
+    """BALANCE | ROTATE: the drawn query block's list is walked from the clock cursor (the throughput mode's kernel); same
+    pairs, another summation order -- the rotated walk's bound against the ascending one."""
+    from jenga_amd import _capi
+    monkeypatch.setenv("JENGA_ROTATE_PERIOD_US", "37")
+    H, nq_img, tb = 3, 150, 2
+    q, k, v, mask = _rand_case(4321, H, nq_img, tb, "bfloat16", 0.35, 0.0)
+    nb = nq_img + tb
+    idx, cnt = lists_from_mask(mask, dev)
+    vt = _capi.pack_v(v.to(dev), nb)
+    seqlens = torch.tensor([nq_img * 128 + 70], dtype=torch.int32, device=dev)
+    base_fl = _capi.ATTN_XCD_REMAP | _capi.ATTN_LP | _capi.ATTN_SORTED
+    run = lambda fl: _capi.bsattn_fwd(q.to(dev), k.to(dev), vt, seqlens, idx, cnt, nq_img, 128 ** -0.5, 0.3, nq_img, flags=fl)
+    ref = run(base_fl)
+    both = run(base_fl | _capi.ATTN_BALANCE | _capi.ATTN_ROTATE)
+    torch.cuda.synchronize()
+    d = (ref.float() - both.float()).abs()
+    assert float(d.max()) <= 2e-2 and float(d.mean()) <= 5e-4, (float(d.max()), float(d.mean()))
+    assert not torch.equal(ref, both) or float(d.max()) == 0.0

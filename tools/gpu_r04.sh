@@ -434,4 +434,18 @@ PY
   ba peaky_d85_rot --drop 0.85 --p 0.3 --peaky 8 --iters 100 --attn-only --flags 153
   ba dense_base2 --drop 0.0 --p 1.0 --iters 20 --attn-only --flags 25
   ;;
+X)
+  # cross-XCD balancing (JENGA_ATTN_BALANCE): parity of the ticket kernel, same-box A/B at the kernel level (static vs
+  # balanced, with and without the rotated walk), then the loop: the default line at flags 25 / 29 / 153 / 157
+  timeout 900 python -m pytest tests/test_gpu_order.py -x -q -m gpu > $O/X_order.log 2>&1; tail -5 $O/X_order.log
+  timeout 500 python tools/balance_ab.py --coherent --dump $O/X_times > $O/X_balance.json 2> $O/X_balance.err; cat $O/X_balance.json; tail -2 $O/X_balance.err
+  L="--steps 6 --no-cpu-baseline --no-dense-ref --no-secondary --no-wan-extra --no-rotate-ref"
+  JENGA_ATTN_FLAGS=25 run X_loop_25 $L
+  JENGA_ATTN_FLAGS=29 run X_loop_29 $L
+  JENGA_ATTN_FLAGS=157 run X_loop_157 $L
+  JENGA_ATTN_FLAGS=153 run X_loop_153 $L
+  JENGA_ATTN_FLAGS=29 run X_loop_29b $L
+  JENGA_ATTN_FLAGS=25 run X_loop_25b $L
+  brief $O/X_loop_*.json
+  ;;
 esac

@@ -1,0 +1,113 @@
+#!/usr/bin/env python3
+"""Experiment (round 4, K1): can the rotated list walk keep its L2 alignment WITHOUT reading the clock?
+
+JENGA_ATTN_ROTATE starts every workgroup's ascending list walk at the phase of a wall-clock cursor, which is what makes
+co-resident workgroups meet at the same kv blocks -- and what makes the summation order depend on timing.  Here a
+clock-mode launch RECORDS the phase every workgroup started at (JENGA_ROTATE_REPLAY=record, a per-device table indexed by
+launch position) and later launches REPLAY it (=replay): deterministic given the table.  Questions, at the HunyuanVideo
+720p shape (900 + 2 blocks, 24 heads, flat lists):
+  1. replay on the SAME lists the table was recorded on: is the gain of the clock mode kept?  (upper bound)
+  2. replay on OTHER lists of the same shape (another seed; another drop rate): does a table transfer?  (what a product
+     would need: the lists differ in every layer and step)
+Prints one JSON line.   python tools/rotate_replay.py [--iters 40]"""
+import argparse
+import json
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from jenga_amd import _capi, gilbert as G  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--iters", type=int, default=40)
+    ap.add_argument("--heads", type=int, default=24)
+    ap.add_argument("--dump", default="", help="directory: write the recorded tables (+ start / end ticks, kept counts)")
+    a = ap.parse_args()
+    dev = torch.device("cuda:0")
+    t, h, w = 32, 45, 80
+    S_img, tb = t * h * w, 2
+    nimg, nb = S_img // 128, S_img // 128 + tb
+    S, H = nb * 128, a.heads
+    nbm = G.gilbert_block_neighbor_mapping(t, h, w, as_tensor=True)
+    seqlens = torch.tensor([S_img + 64], dtype=torch.int32, device=dev)
+
+    def case(seed, drop):
+        g = torch.Generator(device=dev).manual_seed(seed)
+        q, k, v = (torch.randn(1, S, H, 128, device=dev, dtype=torch.bfloat16, generator=g) for _ in range(3))
+        qp, kp = _capi.block_pool(q, nimg), _capi.block_pool(k, nb)
+        _, idx, cnt = _capi.block_select(qp, kp, nbm, nimg, tb, int((1 - drop) * nimg), 0.3)
+        vt = _capi.pack_v(v, nb)
+        pairs = int(cnt.sum().item()) + H * tb * nb
+        return dict(q=q, k=k, vt=vt, idx=idx, cnt=cnt, pairs=pairs)
+
+    def run(c, flags, mode=None, iters=None, warm=3):
+        iters = iters or a.iters
+        if mode:
+            os.environ["JENGA_ROTATE_REPLAY"] = mode
+        else:
+            os.environ.pop("JENGA_ROTATE_REPLAY", None)
+        fn = lambda: _capi.bsattn_fwd(c["q"], c["k"], c["vt"], seqlens, c["idx"], c["cnt"], nimg, 128 ** -0.5, 0.0, nimg,
+                                      flags=flags)
+        for _ in range(warm):
+            o = fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            o = fn()
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / iters
+        return round(4 * 128 ** 3 * c["pairs"] / (ms * 1e-3) / 1e12, 1), o
+
+    def dump(c, tag):
+        if not a.dump:
+            return
+        os.makedirs(a.dump, exist_ok=True)
+        os.environ["JENGA_ROTATE_TABLE_DUMP"] = os.path.join(a.dump, tag + ".u16")
+        run(c, rot, "record", iters=2, warm=0)      # (the times buffer is allocated with the table: first sized here)
+        run(c, rot, "replay", iters=1, warm=0)
+        os.environ.pop("JENGA_ROTATE_TABLE_DUMP")
+        import numpy as np
+        np.save(os.path.join(a.dump, tag + "_cnt.npy"), c["cnt"].cpu().numpy())
+
+    base, rot = _capi.ATTN_DEFAULT_FLAGS, _capi.ATTN_DEFAULT_FLAGS | _capi.ATTN_ROTATE
+    res = {"iters": a.iters, "unit": "TFLOP/s"}
+    A = case(0, 0.7)
+    res["A_default"], oA = run(A, base)
+    res["A_clock"], _ = run(A, rot)
+    res["A_record"], _ = run(A, rot, "record", iters=10)
+    res["A_replay_own_table"], o1 = run(A, rot, "replay")
+    dump(A, "A70")
+    _, o2 = run(A, rot, "replay", iters=3, warm=0)
+    res["replay_bit_reproducible"] = bool(torch.equal(o1, o2))
+    res["replay_vs_default_max_abs"] = float((o1.float() - oA.float()).abs().max().item())
+    res["A_default_again"], _ = run(A, base)
+    del oA, o1, o2
+    B = case(1, 0.7)
+    res["B_default"], _ = run(B, base)
+    res["B_clock"], _ = run(B, rot)
+    res["B_replay_table_of_A"], _ = run(B, rot, "replay")
+    run(B, rot, "record", iters=10)
+    res["B_replay_own_table"], _ = run(B, rot, "replay")
+    del B
+    C = case(0, 0.8)
+    res["C80_default"], _ = run(C, base)
+    res["C80_clock"], _ = run(C, rot)
+    res["C80_replay_table_of_B70"], _ = run(C, rot, "replay")
+    run(C, rot, "record", iters=10)
+    res["C80_replay_own_table"], _ = run(C, rot, "replay")
+    # a second recording of the same case: does the table itself repeat?  (replay with table 2 vs table 1 above)
+    run(C, rot, "record", iters=10)
+    res["C80_replay_own_table_2"], _ = run(C, rot, "replay")
+    dump(C, "C80")
+    res["C80_default_again"], _ = run(C, base)
+    print(json.dumps(res))
+
+
+if __name__ == "__main__":
+    main()
