@@ -31,7 +31,7 @@ sys.path.insert(0, ROOT)
 
 MFMA_PEAK_TFLOPS = 2500.0  # dense bf16, /opt/skills/guides/MI355X_MICROARCH.md
 FLOPS_PER_PAIR = 4 * 128 ** 3  # one 128x128 query block against one 128-key block, head_dim 128: QK^T + PV
-PMC_FILE = "r04_pmc_bsattn_lp.json"   # the counter passes `roofline.traffic` is derived from (profiles/)
+PMC_FILE = "r04_pmc_bsattn_lp_balance.json"   # the counter passes `roofline.traffic` is derived from (profiles/)
 
 
 PRESETS = {   # scripts/hyvideo_jenga_{base,turbo,flash,3stage}.sh and scripts/hyvideo_multigpu_jenga_*.sh
@@ -1019,7 +1019,7 @@ def main():
         est = sum(n * (rot_ms[key[0]] if key[1] == "c" and key[0] in rot_ms else class_ms(key) if sampled else mean(cls.get(key, [0.0])))
                   for key, n in counts.items()) / 1e3
         res.setdefault("extra", {})["attn_rotate"] = {
-            "what": "JENGA_ATTN_ROTATE (JENGA_ATTN_FLAGS=153), opt-in: rotated list walk on a clock cursor, period = the previous "
+            "what": "JENGA_ATTN_ROTATE (JENGA_ATTN_FLAGS=157 = the default | 128), opt-in: rotated list walk on a clock cursor, period = the previous "
                     "launch's workgroup lifetime; NOT bit-reproducible (accumulation order depends on start times) -- not the "
                     "default, not `value`",
             "ms_per_computed_step": {f"stage{k}": round(v, 2) for k, v in rot_ms.items()},

@@ -448,4 +448,22 @@ X)
   JENGA_ATTN_FLAGS=25 run X_loop_25b $L
   brief $O/X_loop_*.json
   ;;
+AA)
+  # the balanced kernel (the new default): counter passes (the file roofline.traffic derives from), per-XCD finish times of
+  # the static vs the balanced launch, rocprofv3 kernel stats of the default command
+  bash tools/pmc_attn2.sh r04_lp_balance --drop 0.7 --iters 2 --attn-only --flags 29 > $O/AA_pmc.log 2>&1; grep -A14 '"derived"' $O/AA_pmc.log | head -24
+  bash tools/prof_bench.sh r04_default --no-cpu-baseline --no-dense-ref --no-wan-extra --no-secondary > $O/AA_prof.log 2>&1; head -8 gpurun_out/prof_r04_default/kernel_stats.csv | cut -c1-200
+  ;;
+AB)
+  # final records at the new default: suite, smoke, the default command, the 8-rank job (simulated exchange), the Wan line
+  timeout 1500 python -m pytest tests -q -m gpu > $O/AB_suite.log 2>&1; grep -E "passed|failed" $O/AB_suite.log
+  python __graft_entry__.py --smoke > $O/AB_smoke.log 2>&1; tail -1 $O/AB_smoke.log
+  T0=$(date +%s); python bench.py > $O/AB_default.json 2> $O/AB_default.err; T1=$(date +%s); echo "default bench wall seconds: $((T1-T0))"
+  S="--simulate-ranks 8 --steps 6 --no-cpu-baseline --no-dense-ref"
+  run AB_s8_x0 $S
+  run AB_s8_x300 $S --sim-exchange-gbps 300
+  run AB_s8_x400 $S --sim-exchange-gbps 400
+  brief $O/AB_default.json $O/AB_s8_*.json
+  timeout 900 python bench.py --workload wan14b --no-cpu-baseline > $O/AB_wan14b.json 2> $O/AB_wan14b.err; tail -c 300 $O/AB_wan14b.json
+  ;;
 esac
