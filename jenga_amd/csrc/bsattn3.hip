@@ -762,6 +762,13 @@ int jenga_bsattn_lp_launch(void* stream, const void* q, const void* k, const voi
         set_error("jenga_bsattn_fwd: grid size %lld out of range", grid);
         return JENGA_EINVAL;
     }
+    // the launch modes below keep per-device state that is written on the launch stream from host variables or ordered by
+    // events: none of that can be recorded into a HIP graph, so a capturing stream gets the plain static launch
+    if (flags & (JENGA_ATTN_COHORT | JENGA_ATTN_ROTATE | JENGA_ATTN_BALANCE)) {
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing((hipStream_t)stream, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone)
+            flags &= ~(JENGA_ATTN_COHORT | JENGA_ATTN_ROTATE | JENGA_ATTN_BALANCE);
+    }
     bool cohort = false;
     if ((flags & JENGA_ATTN_COHORT) && P.xcd_chunk) {
         // EXPERIMENT: one lazily allocated counter block per device, zeroed on the launch stream in front of every launch,
@@ -789,11 +796,9 @@ int jenga_bsattn_lp_launch(void* stream, const void* q, const void* k, const voi
     }
     int rot_ticks = 0;
     if ((flags & JENGA_ATTN_ROTATE) && !cohort) {
-        // EXPERIMENT: the period comes from the environment (microseconds; default 875 = the mean workgroup lifetime of the
-        // 720p launch); written to the device global on the launch stream
-        // period of the cursor: JENGA_ROTATE_PERIOD_US=<microseconds>, or (default, "auto") the lifetime of the image
-        // workgroup that finished last in the previous launch with this flag -- copied device to device on the launch
-        // stream, so one launch sees one period and no host synchronisation is involved
+        // period of the cursor: JENGA_ROTATE_PERIOD_US=<microseconds>, or (default, "auto") the lifetime of a mid-queue image
+        // workgroup of the previous launch with this flag -- copied device to device on the launch stream, so one launch
+        // sees one period and no host synchronisation is involved
         int us = 0;
         if (const char* ev = getenv("JENGA_ROTATE_PERIOD_US")) us = atoi(ev);
         rot_ticks = us > 0 ? us * 100 : 1;

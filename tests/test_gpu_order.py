@@ -231,3 +231,32 @@ def test_balanced_and_rotated_walk_together(dev, monkeypatch):
     d = (ref.float() - both.float()).abs()
     assert float(d.max()) <= 2e-2 and float(d.mean()) <= 5e-4, (float(d.max()), float(d.mean()))
     assert not torch.equal(ref, both) or float(d.max()) == 0.0
+
+
+def test_balanced_launch_under_stream_capture_falls_back_to_the_static_mapping(dev):
+    """A capturing stream gets no ticket counters (an event recorded inside a capture cannot order the set against launches
+    outside it): the launch inside a HIP graph runs the static mapping, the graph replays, and every replay equals the
+    eager (balanced) result bit for bit."""
+    from jenga_amd import _capi
+    H, nq_img, tb = 2, 136, 2
+    nb = nq_img + tb
+    q, k, v, mask = _rand_case(77, H, nq_img, tb, "bfloat16", 0.3, 0.0)
+    idx, cnt = lists_from_mask(mask, dev)
+    qd, kd = q.to(dev), k.to(dev)
+    vt = _capi.pack_v(v.to(dev), nb)
+    seqlens = torch.tensor([nq_img * 128 + 70], dtype=torch.int32, device=dev)
+    fl = _capi.ATTN_XCD_REMAP | _capi.ATTN_LP | _capi.ATTN_SORTED | _capi.ATTN_BALANCE
+    order = _capi.order_by_count(cnt, (nq_img + 7) // 8)
+    want = _capi.bsattn_fwd(qd, kd, vt, seqlens, idx, cnt, nq_img, 128 ** -0.5, 0.3, nq_img, flags=fl, order=order)
+    out = torch.zeros_like(want)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    side = torch.cuda.Stream(device=dev)
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(g, stream=side):
+            _capi.bsattn_fwd(qd, kd, vt, seqlens, idx, cnt, nq_img, 128 ** -0.5, 0.3, nq_img, flags=fl, order=order, out=out)
+    for _ in range(3):
+        out.fill_(777.0)
+        g.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(out, want)

@@ -466,4 +466,20 @@ AB)
   brief $O/AB_default.json $O/AB_s8_*.json
   timeout 900 python bench.py --workload wan14b --no-cpu-baseline > $O/AB_wan14b.json 2> $O/AB_wan14b.err; tail -c 300 $O/AB_wan14b.json
   ;;
+AE)
+  # HEAD after the capture fallback: suite, smoke, the full 50-step loop and the other presets at the new default, Wan A/B
+  timeout 1500 python -m pytest tests -q -m gpu > $O/AE_suite.log 2>&1; grep -E "passed|failed" $O/AE_suite.log
+  python __graft_entry__.py --smoke > $O/AE_smoke.log 2>&1; tail -1 $O/AE_smoke.log
+  L="--no-cpu-baseline --no-dense-ref --no-secondary --no-wan-extra"
+  run AE_full50 --steps 50 $L
+  run AE_turbo --preset turbo $L
+  run AE_3stage_i2v --preset 3stage --i2v $L
+  brief $O/AE_*.json
+  for f in 25 29; do JENGA_ATTN_FLAGS=$f timeout 900 python bench.py --workload wan14b --no-cpu-baseline > $O/AE_wan14b_$f.json 2> $O/AE_wan14b_$f.err; python - $O/AE_wan14b_$f.json $f <<'PY'
+import json,sys
+d=json.loads([l for l in open(sys.argv[1]).read().strip().splitlines() if l.startswith("{")][-1])
+print("wan flags", sys.argv[2], d["value"], d["roofline"]["frac"])
+PY
+  done
+  ;;
 esac
