@@ -795,9 +795,10 @@ def main():
 
     if dist_on or sim > 1:
         # per-rank GEMM shapes (M = S_img / N): hipBLASLt's first pick is not its fastest there (profiles/
-        # r03_gemm_tunableop.json, r03_gemm_epilogue_ab.json) -- let jenga_linear time its first 16 candidates once per
-        # shape, during the untimed priming steps below
-        os.environ.setdefault("JENGA_GEMM_CANDIDATES", "16")
+        # r03_gemm_tunableop.json, r03_gemm_epilogue_ab.json) -- let jenga_linear time its first 32 candidates once per
+        # shape, during the untimed priming steps below (32 against 16: -0.6 % per rank-step, profiles/r04_gemm_candidates_ab.json;
+        # on one GPU the first pick is the fastest: 77.16 vs 77.33 s/video with 16 timed)
+        os.environ.setdefault("JENGA_GEMM_CANDIDATES", "32")
     if int(os.environ.get("JENGA_GEMM_CANDIDATES", "1")) > 1:
         for k in range(len(stages)):      # one untimed computed step per stage: every GEMM shape gets its plan here
             run_step(next(i for i in computed_steps if stage_of(i, split) == k))

@@ -482,4 +482,15 @@ print("wan flags", sys.argv[2], d["value"], d["roofline"]["frac"])
 PY
   done
   ;;
+AF)
+  # hipBLASLt candidate timing: 16 (the N > 1 default) vs 32 for one rank of eight; 1 (the N = 1 default) vs 16 on one GPU
+  S="--simulate-ranks 8 --steps 6 --no-cpu-baseline --no-dense-ref --no-secondary"
+  L="--steps 6 --no-cpu-baseline --no-dense-ref --no-secondary --no-wan-extra --no-rotate-ref"
+  run AF_s8_c16 $S
+  JENGA_GEMM_CANDIDATES=32 run AF_s8_c32 $S
+  run AF_one_c1 $L
+  JENGA_GEMM_CANDIDATES=16 run AF_one_c16 $L
+  run AF_s8_c16b $S
+  brief $O/AF_*.json
+  ;;
 esac
