@@ -272,13 +272,15 @@ int jenga_bsattn_fwd(void* stream, const void* q, const void* k, const void* vt,
                                   the static mapping */
 #define JENGA_ATTN_LP 8        /* same decomposition, in-wave software pipeline (softmax inside the MFMA stream):
                                   csrc/bsattn3.hip, the default of the Python modules (XCD_REMAP | LP) */
-#define JENGA_ATTN_COHORT 32   /* EXPERIMENT (round 4, LP kernel with XCD_REMAP only): the workgroups an XCD runs at a time
-                                  start together (arrival counters, bounded spin) and walk their lists in step: L2 hits
-                                  for fabric bytes; launches with this flag must not overlap on one device */
-#define JENGA_ATTN_ROTATE 128  /* EXPERIMENT (round 4, LP kernel): every workgroup walks its list from a start rotated by the
-                                  phase of a chip-wide clock cursor (period JENGA_ROTATE_PERIOD_US): co-resident workgroups
-                                  meet in the L2 without waiting.  Results equal within fp32 rounding of the running
-                                  sums, NOT bit-identical from run to run */
+#define JENGA_ATTN_COHORT 32   /* EXPERIMENT (libraries built with JENGA_EXPERIMENTS only; else JENGA_EUNSUPPORTED; round 4,
+                                  LP kernel with XCD_REMAP): the workgroups an XCD runs at a time start together (arrival
+                                  counters, bounded spin) and walk their lists in step: L2 hits for fabric bytes, slower */
+#define JENGA_ATTN_ROTATE 128  /* opt-in (round 4, LP kernel): every workgroup walks its list from a start rotated by the
+                                  phase of a chip-wide clock cursor (period: the previous launch's workgroup lifetime, or
+                                  JENGA_ROTATE_PERIOD_US): co-resident workgroups meet in the L2 without waiting.  Results
+                                  equal within fp32 rounding of the running sums, NOT bit-identical from run to run.  (The
+                                  experiments library adds a position mode and a record / replay mode of the start phases
+                                  and a per-workgroup tick dump: JENGA_ROTATE_SLOTS, JENGA_ROTATE_REPLAY, JENGA_LP_TIMES_DUMP) */
 /* order (may be NULL): int32 [B,H,nq_img], launch position -> image query block, a permutation per (b, h) -- a
  *   scheduling hint only (every query block is computed exactly once either way, results are bit-identical).
  *   jenga_order_by_count fills it from cnt: inside every segment of `segment` consecutive query blocks the blocks are

@@ -18,7 +18,7 @@ ATTN_BALANCE = 4     # round 4: query blocks DRAWN from per-XCD queues on an ove
 ATTN_LEGACY = 0      # (readability alias) no kernel bit: the round-1 kernel, one query block per 4-wave workgroup
 ATTN_LP = 8          # round-1 decomposition + in-wave software pipeline (csrc/bsattn3.hip): the default
 ATTN_SORTED = 16     # (Python-side) kept-count-aware launch order: jenga_order_by_count feeds jenga_bsattn_fwd's `order`
-ATTN_COHORT = 32     # experiment (round 4): cohort start barrier per XCD generation (LP kernel + XCD remap)
+ATTN_COHORT = 32     # experiment (round 4; experiments library only): cohort start barrier per XCD generation
 ATTN_ROTATE = 128    # experiment (round 4): rotated list walk on a clock cursor (LP kernel); not bit-reproducible
 ATTN_PAIR = 64       # (Python-side, experiment) route to jenga_bsattn_pair_fwd: the pair kernel; with ATTN_LP the 8-wave
 #                      LP pair (csrc/experiments/); needs libjenga_amd_exp.so
@@ -713,8 +713,8 @@ def bsattn_fwd(q, k, vt, seqlens, idx, cnt, nq_img, sm_scale, text_amp, text_blo
     if not xcd_remap:
         fl &= ~ATTN_XCD_REMAP
     pair = bool(fl & ATTN_PAIR)
-    if (pair or (fl & ATTN_PINGPONG)) and not has_experiments():
-        raise JengaError("the pair / ping-pong attention kernels are experiments: build libjenga_amd_exp.so with "
+    if (pair or (fl & (ATTN_PINGPONG | ATTN_COHORT))) and not has_experiments():
+        raise JengaError("the pair / ping-pong / cohort attention launches are experiments: build libjenga_amd_exp.so with "
                          "`python -m jenga_amd.build --experiments` and set JENGA_LIB to it")
     if pair and (fl & ATTN_LP) and n_blocks == nq_img:
         # the 8-wave LP pair takes no masked image block in an unshared list (csrc/experiments/bsattn4.hip): without

@@ -66,16 +66,25 @@ struct LpParams {
     int bal_set;     // JENGA_ATTN_BALANCE: which of the LP_BAL_SETS ticket-counter sets this launch draws from
 };
 
+// LP_EXP: the measured-and-rejected launch modes (cohort start barrier; position / replay modes of the rotated walk;
+// per-workgroup tick dump) are compiled into libjenga_amd_exp.so only (python -m jenga_amd.build --experiments)
+#ifdef JENGA_EXPERIMENTS
+#define LP_EXP 1
+#else
+#define LP_EXP 0
+#endif
+#if LP_EXP
 #define LP_ROT_REPLAY (-1000000000)   // rot_period value selecting the replay branch
 __device__ unsigned short* g_rot_table;   // JENGA_ROTATE_REPLAY: one start phase (16-bit fraction of a turn) per image workgroup
 __device__ unsigned* g_rot_times;          // record mode: [start, end] wall-clock ticks (low 32 bits) per launch position
 __device__ int g_rot_table_mode;          // 0 off, 1 record (clock mode writes the phase it used), 2 replay (read instead of the clock)
 __device__ float g_rot_spread = 0.42f;  // JENGA_ATTN_ROTATE position mode: growth of the start-time spread per sqrt(generation)
+#endif
 
 // XKV: the cross-attention instantiation (TEXT rows against a kv sequence whose last tile may be ragged); a template
 // parameter so that the product kernel's code (and its register allocation) is exactly what it is without that path
-// ROT (round 4, JENGA_ATTN_ROTATE; 1 = clock / replay / position modes, 2 = clock mode only -- the balanced launch, whose
-// main loop keeps its DMA offsets in registers only without the other modes' code): the fast part of the ascending list is walked from a ROTATED start --
+// ROT (round 4, JENGA_ATTN_ROTATE; 2 = clock mode, 1 = clock / replay / position modes in the experiments library -- a separate
+// instantiation: the balanced launch's main loop keeps its DMA offsets in registers only without the other modes' code): the fast part of the ascending list is walked from a ROTATED start --
 // logical entry j < n_rot is physical entry (j + rot) mod n_rot, rot = phase of a chip-wide wall-clock cursor x n_rot -- so
 // that workgroups started at different times are at the same kv blocks at the same time WITHOUT waiting for each other.
 // The summation order of the online softmax then depends on the start time: results are equal within fp32 rounding of
@@ -248,14 +257,17 @@ __device__ __forceinline__ void attn_block_lp(const LpParams& P, unsigned char* 
         if (tid == 0) {
             const unsigned long long c = (unsigned long long)wall_clock64() % (unsigned long long)rot_period;
             *reinterpret_cast<int*>(smem) = (int)((c * (unsigned long long)n_fast) / (unsigned long long)rot_period);
+#if LP_EXP
             if (ROT == 1 && g_rot_table_mode == 1)      // record: the phase this workgroup started at (rot_seq = its launch position)
                 g_rot_table[rot_seq] = (unsigned short)((c << 16) / (unsigned long long)rot_period);
+#endif
         }
         __syncthreads();
         rot = __builtin_amdgcn_readfirstlane(*reinterpret_cast<const int*>(smem));
         n_rot = n_fast;
         lbase = -64;          // (the window holds unrotated entries from the tail scan)
         __syncthreads();
+#if LP_EXP
     } else if (ROT == 1 && n_fast > 1 && rot_period == LP_ROT_REPLAY) {
         // replay (deterministic): the start phase a clock-mode launch of this shape recorded for this launch position
         rot = (int)(((unsigned)g_rot_table[rot_seq] * (unsigned)n_fast) >> 16);
@@ -279,6 +291,7 @@ __device__ __forceinline__ void attn_block_lp(const LpParams& P, unsigned char* 
         rot = rot >= n_fast ? n_fast - 1 : rot;
         n_rot = n_fast;
         lbase = -64;
+#endif
     }
     if (XKV && P.text_kv_len > 0) {     // cross-attention: whole tiles in the pipeline, the ragged one in the slow form
         t_all = (P.text_kv_len + 63) >> 6;
@@ -384,6 +397,7 @@ __device__ __forceinline__ void attn_block_lp(const LpParams& P, unsigned char* 
     }
 }
 
+#if LP_EXP
 // JENGA_ATTN_COHORT (round-4 experiment): the workgroups an XCD runs at a time start TOGETHER -- one arrival counter per
 // XCD and per generation of `size` consecutive launch positions, bounded spin -- so that they walk their ascending lists
 // in step and meet in the XCD's L2.  The configuration lives in a device global written on the launch stream, NOT in
@@ -394,6 +408,7 @@ struct CohortCfg {
     int quorum;                  // arrivals a member waits for (<= size): the stragglers of a generation start late
 };
 __device__ CohortCfg g_cohort_cfg;
+#endif
 __device__ int g_rot_period_ticks;      // JENGA_ATTN_ROTATE: the cursor's period (wall-clock ticks, 100 MHz)
 #define LP_BAL_SETS 64
 __device__ int g_balance_ctr[LP_BAL_SETS][8];   // JENGA_ATTN_BALANCE: tickets drawn from each XCD's queue, one set per launch in
@@ -401,13 +416,15 @@ __device__ int g_balance_ctr[LP_BAL_SETS][8];   // JENGA_ATTN_BALANCE: tickets d
 __device__ int g_rot_T_est = 87500;     // lifetime of the image workgroup that finished last (ticks): the NEXT launch's period
                                         // in auto mode (copied device-to-device on the launch stream; 875 us to begin with)
 
-// instrumentation of the experiment variants (JENGA_LP_TIMES_DUMP): [start, end] of every image workgroup
+// instrumentation (experiments library, JENGA_LP_TIMES_DUMP): [start, end] of every image workgroup of the rotated variants
 __device__ __forceinline__ void lp_record_times(int li, long long t_start, long long t_end) {
+#if LP_EXP
     unsigned* tm = g_rot_times;
     if (tm) {
         tm[2 * li] = (unsigned)t_start;
         tm[2 * li + 1] = (unsigned)t_end;
     }
+#endif
 }
 
 // JENGA_ATTN_BALANCE: thread 0 draws (queue y, ticket t) -- own queue first, then the fullest other one, at most 8 attempts --
@@ -516,6 +533,7 @@ __global__ void __launch_bounds__(LP_THREADS, 2) bsattn_lp_kernel(LpParams P) {
     } else {
         m = r;
     }
+#if LP_EXP
     if (VARIANT == 1) {
         if (threadIdx.x == 0) {
             const CohortCfg C = g_cohort_cfg;
@@ -536,6 +554,7 @@ __global__ void __launch_bounds__(LP_THREADS, 2) bsattn_lp_kernel(LpParams P) {
         }
         __syncthreads();
     }
+#endif
     if (P.order) m = P.order[(long long)bh * P.nq_img + m];   // kept-count-aware order inside the XCD's range
     if (VARIANT == 3 || VARIANT == 5) {
         int seq = li, seq_total = P.B * P.H * P.img_per_head;
@@ -551,13 +570,15 @@ __global__ void __launch_bounds__(LP_THREADS, 2) bsattn_lp_kernel(LpParams P) {
         const bool mid_queue = seq * 4 >= seq_total && seq * 4 < 3 * seq_total;
         int period = g_rot_period_ticks;
         if (period > 0) period = period < 5000 ? 5000 : (period > 1000000 ? 1000000 : period);   // 50 us .. 10 ms
+#if LP_EXP
         if (VARIANT == 3) {
             const int table_mode = g_rot_table_mode;
             if (table_mode == 2) period = LP_ROT_REPLAY;
             if (table_mode) seq = li;        // the table is indexed by launch position
         }
+#endif
         const long long t_start = (long long)wall_clock64();
-        attn_block_lp<T, false, false, VARIANT == 5 ? 2 : 1>(P, smem, bh / P.H, bh % P.H, m, period, seq);
+        attn_block_lp<T, false, false, (LP_EXP && VARIANT == 3) ? 1 : 2>(P, smem, bh / P.H, bh % P.H, m, period, seq);
         // the next launch's period (auto mode): the lifetime of a workgroup from the MIDDLE of its XCD's queue -- the last
         // ones run on a draining chip and are faster than the steady state the cursor has to match
         if (threadIdx.x == 0) {
@@ -580,6 +601,7 @@ static hipError_t lp_launch(const LpParams& P, long long grid, hipStream_t strea
 
 // ---- host side of the experiment variants (state per device; launches carrying these flags must not overlap on one device)
 
+#if LP_EXP
 // JENGA_LP_TIMES_DUMP=<file>: the rotate / balance variants write [start, end] wall-clock ticks (100 MHz, low 32 bits) of
 // every image workgroup, indexed by launch position; the file holds the launch BEFORE the current one (written in front of
 // the next launch with the variable set, after a stream synchronisation) as raw uint32 pairs.
@@ -615,6 +637,7 @@ void lp_times_hook(long long grid, hipStream_t stream) {
     (void)hipMemcpyToSymbolAsync(HIP_SYMBOL(g_rot_times), &ptr, sizeof(ptr), 0, hipMemcpyHostToDevice, stream);
     armed[dev] = ptr != nullptr;
 }
+#endif
 
 // JENGA_ATTN_BALANCE: the ticket counters of a launch.  LP_BAL_SETS sets per device, handed out in turn under a mutex (ranks
 // simulated by threads launch concurrently on one device); a set is zeroed on the launch stream in front of the kernel, and
@@ -668,6 +691,7 @@ void lp_balance_release(int k, hipStream_t stream) {
     S.busy[k] = false;
 }
 
+#if LP_EXP
 // JENGA_ROTATE_REPLAY=record|replay: a clock-mode launch writes every workgroup's start phase to a per-device table
 // (16-bit fraction of a turn per launch position); later launches of the same grid read it instead of the clock --
 // deterministic given the table.  JENGA_ROTATE_TABLE_DUMP=<file> writes the table in front of every replay launch,
@@ -711,6 +735,7 @@ void lp_replay_table(long long grid, hipStream_t stream) {
     }
     (void)hipMemcpyToSymbolAsync(HIP_SYMBOL(g_rot_table_mode), &mode, sizeof(int), 0, hipMemcpyHostToDevice, stream);
 }
+#endif
 
 }  // namespace
 }  // namespace jenga
@@ -770,6 +795,12 @@ int jenga_bsattn_lp_launch(void* stream, const void* q, const void* k, const voi
             flags &= ~(JENGA_ATTN_COHORT | JENGA_ATTN_ROTATE | JENGA_ATTN_BALANCE);
     }
     bool cohort = false;
+#if !LP_EXP
+    if (flags & JENGA_ATTN_COHORT) {
+        set_error("jenga_bsattn_fwd: the cohort start barrier is an experiment (build with JENGA_EXPERIMENTS)");
+        return JENGA_EUNSUPPORTED;
+    }
+#else
     if ((flags & JENGA_ATTN_COHORT) && P.xcd_chunk) {
         // EXPERIMENT: one lazily allocated counter block per device, zeroed on the launch stream in front of every launch,
         // the configuration written to the device global the same way -- launches with this flag must not overlap on one
@@ -794,6 +825,7 @@ int jenga_bsattn_lp_launch(void* stream, const void* q, const void* k, const voi
                 cohort = true;
         }
     }
+#endif
     int rot_ticks = 0;
     if ((flags & JENGA_ATTN_ROTATE) && !cohort) {
         // period of the cursor: JENGA_ROTATE_PERIOD_US=<microseconds>, or (default, "auto") the lifetime of a mid-queue image
@@ -803,6 +835,7 @@ int jenga_bsattn_lp_launch(void* stream, const void* q, const void* k, const voi
         if (const char* ev = getenv("JENGA_ROTATE_PERIOD_US")) us = atoi(ev);
         rot_ticks = us > 0 ? us * 100 : 1;
         bool auto_period = us <= 0;
+#if LP_EXP
         // JENGA_ROTATE_SLOTS=S: position mode with S workgroups resident per XCD (64 = 32 CUs x 2); deterministic
         if (const char* ev = getenv("JENGA_ROTATE_SLOTS")) {
             const int slots = atoi(ev);
@@ -814,6 +847,7 @@ int jenga_bsattn_lp_launch(void* stream, const void* q, const void* k, const voi
         }
         if (rot_ticks < 0) auto_period = false;
         if (rot_ticks > 0) lp_replay_table(grid, (hipStream_t)stream);
+#endif
         if (auto_period) {
             void *dst = nullptr, *src = nullptr;
             if (hipGetSymbolAddress(&dst, HIP_SYMBOL(g_rot_period_ticks)) != hipSuccess ||
@@ -830,8 +864,12 @@ int jenga_bsattn_lp_launch(void* stream, const void* q, const void* k, const voi
     // by launch position and stay with the static mapping.
     long long grid_bal = 0;
     int bal_slot = -1;
-    if ((flags & JENGA_ATTN_BALANCE) && P.xcd_chunk && !cohort && rot_ticks >= 0 && !getenv("JENGA_ROTATE_REPLAY") &&
-        (P.n_text_wg_pad & 7) == 0 && (P.img_per_head & 7) == 0) {
+    bool static_only = cohort || rot_ticks < 0;
+#if LP_EXP
+    static_only = static_only || getenv("JENGA_ROTATE_REPLAY") != nullptr;
+#endif
+    if ((flags & JENGA_ATTN_BALANCE) && P.xcd_chunk && !static_only && (P.n_text_wg_pad & 7) == 0 &&
+        (P.img_per_head & 7) == 0) {
         int pct = 12;
         if (const char* ev = getenv("JENGA_BALANCE_EXTRA_PCT")) pct = atoi(ev);
         pct = pct < 0 ? 0 : (pct > 100 ? 100 : pct);
@@ -845,7 +883,9 @@ int jenga_bsattn_lp_launch(void* stream, const void* q, const void* k, const voi
             }
         }
     }
+#if LP_EXP
     if (rot_ticks != 0 || grid_bal) lp_times_hook(grid_bal ? grid_bal : grid, (hipStream_t)stream);
+#endif
     hipError_t e;
     if (grid_bal && rot_ticks > 0)
         e = dtype == JENGA_BF16 ? lp_launch<BF16, 5>(P, grid_bal, (hipStream_t)stream)
@@ -856,9 +896,11 @@ int jenga_bsattn_lp_launch(void* stream, const void* q, const void* k, const voi
     else if (rot_ticks != 0)
         e = dtype == JENGA_BF16 ? lp_launch<BF16, 3>(P, grid, (hipStream_t)stream)
                                 : lp_launch<FP16, 3>(P, grid, (hipStream_t)stream);
+#if LP_EXP
     else if (cohort)
         e = dtype == JENGA_BF16 ? lp_launch<BF16, 1>(P, grid, (hipStream_t)stream)
                                 : lp_launch<FP16, 1>(P, grid, (hipStream_t)stream);
+#endif
     else
         e = dtype == JENGA_BF16 ? lp_launch<BF16, 0>(P, grid, (hipStream_t)stream)
                                 : lp_launch<FP16, 0>(P, grid, (hipStream_t)stream);

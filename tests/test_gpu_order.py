@@ -67,6 +67,8 @@ def test_cohort_start_barrier_is_bit_identical(dev, monkeypatch, H, nq_img, size
     (arrival counters, bounded spin).  A scheduling device only: every query block is computed exactly once, outputs are
     bit-identical -- also when a generation is larger than what can be resident at once (the timeout lets it proceed)."""
     from jenga_amd import _capi
+    if not _capi.has_experiments():
+        pytest.skip("the cohort start barrier is part of the experiments library (JENGA_LIB=libjenga_amd_exp.so)")
     monkeypatch.setenv("JENGA_COHORT_SIZE", str(size))
     monkeypatch.setenv("JENGA_COHORT_TIMEOUT_US", "50")
     tb = 2
@@ -116,6 +118,8 @@ def test_rotated_walk_position_mode_is_deterministic(dev, monkeypatch, slots):
     its position in its XCD's launch queue -- two runs give the same bits; the result equals the ascending walk's within
     fp32 rounding of the running sums."""
     from jenga_amd import _capi
+    if not _capi.has_experiments():
+        pytest.skip("the position mode of the rotated walk is part of the experiments library")
     monkeypatch.setenv("JENGA_ROTATE_SLOTS", str(slots))
     H, nq_img, tb = 2, 200, 2
     q, k, v, mask = _rand_case(4321, H, nq_img, tb, "bfloat16", 0.3, 0.0)

@@ -2,7 +2,8 @@
 """Experiment (round 4, K1): cross-XCD balancing of the attention launch (JENGA_ATTN_BALANCE) against the static mapping,
 same box, interleaved, at the HunyuanVideo 720p shape (flat lists).  Also dumps the per-workgroup [start, end] ticks of one
 balanced launch (JENGA_LP_TIMES_DUMP) so that the per-XCD finish times can be read.  One JSON line.
-  python tools/balance_ab.py [--iters 40] [--dump DIR]"""
+  python tools/balance_ab.py [--iters 40] [--dump DIR]      (--dump: the tick dump is in the experiments library only,
+  JENGA_LIB=$PWD/jenga_amd/libjenga_amd_exp.so, and records the rotated variants)"""
 import argparse
 import json
 import os

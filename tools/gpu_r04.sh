@@ -493,4 +493,14 @@ AF)
   run AF_s8_c16b $S
   brief $O/AF_*.json
   ;;
+AG)
+  # HEAD with the rejected launch modes moved to the experiments library: product suite, smoke, a short default line; the
+  # experiment kernels once through libjenga_amd_exp.so
+  timeout 1500 python -m pytest tests -q -m gpu > $O/AG_suite.log 2>&1; grep -E "passed|failed" $O/AG_suite.log
+  python __graft_entry__.py --smoke > $O/AG_smoke.log 2>&1; tail -1 $O/AG_smoke.log
+  JENGA_LIB=$PWD/jenga_amd/libjenga_amd_exp.so timeout 900 python -m pytest tests/test_gpu_pair.py tests/test_gpu_order.py tests/test_gpu_parity.py -q -m gpu -k "pair or sparse_kernel_vs_oracle or cohort or rotat or balanc" > $O/AG_exp.log 2>&1; tail -3 $O/AG_exp.log
+  JENGA_LIB=$PWD/jenga_amd/libjenga_amd_exp.so timeout 300 python tools/rotate_replay.py --iters 20 > $O/AG_replay.json 2> $O/AG_replay.err; cat $O/AG_replay.json
+  run AG_default --steps 20 --warmup 5
+  brief $O/AG_default.json
+  ;;
 esac

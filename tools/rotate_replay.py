@@ -9,7 +9,9 @@ launch position) and later launches REPLAY it (=replay): deterministic given the
   1. replay on the SAME lists the table was recorded on: is the gain of the clock mode kept?  (upper bound)
   2. replay on OTHER lists of the same shape (another seed; another drop rate): does a table transfer?  (what a product
      would need: the lists differ in every layer and step)
-Prints one JSON line.   python tools/rotate_replay.py [--iters 40]"""
+Needs the experiments library (record / replay is compiled into libjenga_amd_exp.so only):
+  python -m jenga_amd.build --experiments ; JENGA_LIB=$PWD/jenga_amd/libjenga_amd_exp.so python tools/rotate_replay.py [--iters 40]
+Prints one JSON line."""
 import argparse
 import json
 import os
