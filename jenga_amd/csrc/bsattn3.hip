@@ -642,8 +642,8 @@ void lp_times_hook(long long grid, hipStream_t stream) {
 // JENGA_ATTN_BALANCE: the ticket counters of a launch.  LP_BAL_SETS sets per device, handed out in turn under a mutex (ranks
 // simulated by threads launch concurrently on one device); a set is zeroed on the launch stream in front of the kernel, and
 // an event recorded behind the kernel makes the NEXT user of the set -- LP_BAL_SETS launches later, possibly on another
-// stream -- wait for it, so two launches in flight never share counters.  A capturing stream gets no set (-1: the static
-// mapping runs): an event recorded inside a capture cannot order it against launches outside.
+// stream -- wait for it, so two launches in flight never share counters.  (A capturing stream never gets here: the launcher
+// drops the flag, an event recorded inside a capture cannot order a set against launches outside.)
 struct LpBalanceSlots {
     std::mutex mu;
     int* base = nullptr;
@@ -657,8 +657,6 @@ LpBalanceSlots g_bal[64];
 int lp_balance_acquire(hipStream_t stream) {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return -1;
-    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-    if (hipStreamIsCapturing(stream, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) return -1;
     LpBalanceSlots& S = g_bal[dev];
     std::lock_guard<std::mutex> lock(S.mu);
     if (!S.base && hipGetSymbolAddress((void**)&S.base, HIP_SYMBOL(g_balance_ctr)) != hipSuccess) {
@@ -791,8 +789,11 @@ int jenga_bsattn_lp_launch(void* stream, const void* q, const void* k, const voi
     // events: none of that can be recorded into a HIP graph, so a capturing stream gets the plain static launch
     if (flags & (JENGA_ATTN_COHORT | JENGA_ATTN_ROTATE | JENGA_ATTN_BALANCE)) {
         hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-        if (hipStreamIsCapturing((hipStream_t)stream, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone)
-            flags &= ~(JENGA_ATTN_COHORT | JENGA_ATTN_ROTATE | JENGA_ATTN_BALANCE);
+        if (hipStreamIsCapturing((hipStream_t)stream, &cap) != hipSuccess) {
+            (void)hipGetLastError();      // (the query itself failed: not this launch's error)
+            cap = hipStreamCaptureStatusActive;
+        }
+        if (cap != hipStreamCaptureStatusNone) flags &= ~(JENGA_ATTN_COHORT | JENGA_ATTN_ROTATE | JENGA_ATTN_BALANCE);
     }
     bool cohort = false;
 #if !LP_EXP
