@@ -6,6 +6,21 @@
 namespace jenga {
 namespace {
 
+// Streaming accesses (round 4): the row kernels read every input byte and write every output byte once, hundreds of MB per
+// launch -- nontemporal loads / stores keep them from rotating through the L2 / Infinity Cache (tools/micro/hbm_copy.hip:
+// a 2 x 708 MB copy runs at 6.58 TB/s with them, 6.16 without; at a capped grid 5.75 vs 4.96): gather 5.5 -> 6.3 TB/s,
+// pack_v 5.2-5.5 -> 6.0, LayerNorm+modulate 5.5 -> 5.6 (profiles/r04_row_kernels_streaming_ab.json).  Small reused operands
+// (weights, modulation rows, cos / sin tables, indices) keep ordinary loads.
+typedef unsigned int jenga_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint4 ld_stream(const void* p) {
+    const jenga_u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const jenga_u32x4*>(p));
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ void st_stream(void* p, const uint4 v) {
+    const jenga_u32x4 w = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(w, reinterpret_cast<jenga_u32x4*>(p));
+}
+
 // ------------------------------------------------------------------------------------------------ gather
 // dst[b, i, :] = src[b, index[i], :]; one workgroup per output row (grid-stride), 16 B per lane.
 __global__ void gather_rows_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst,
@@ -17,7 +32,7 @@ __global__ void gather_rows_kernel(const uint4* __restrict__ src, uint4* __restr
         const long long s = index[i];
         const uint4* sp = src + b * src_bs + s * vec_per_row;
         uint4* dp = dst + b * dst_bs + i * vec_per_row;
-        for (int v = threadIdx.x; v < vec_per_row; v += blockDim.x) dp[v] = sp[v];
+        for (int v = threadIdx.x; v < vec_per_row; v += blockDim.x) st_stream(dp + v, ld_stream(sp + v));
     }
 }
 
@@ -168,8 +183,8 @@ __global__ void __launch_bounds__(128) qk_norm_rope_pool_kernel(const uint16_t* 
             }
             norm_rope_row<T>(fq, wqv, wq != nullptr, eps, rope, c, sn);
             norm_rope_row<T>(fk, wkv, wk != nullptr, eps, rope, c, sn);
-            *reinterpret_cast<uint4*>(oq + ooff) = pack8<T>(fq);
-            *reinterpret_cast<uint4*>(ok + ooff) = pack8<T>(fk);
+            *reinterpret_cast<uint4*>(oq + ooff) = pack8<T>(fq);      // (streaming accesses measured here: 4.81-4.87 against
+            *reinterpret_cast<uint4*>(ok + ooff) = pack8<T>(fk);      //  4.89-5.14 TB/s with ordinary ones -- not used)
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 aq[e] += fq[e];
@@ -294,8 +309,7 @@ __global__ void pack_v_kernel(const uint16_t* __restrict__ v, uint16_t* __restri
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int row = i * 16 + (threadIdx.x >> 4), c = threadIdx.x & 15;
-            *reinterpret_cast<uint4*>(&tile[row][c * 8]) =
-                *reinterpret_cast<const uint4*>(src + (long long)row * v_ss + c * 8);
+            *reinterpret_cast<uint4*>(&tile[row][c * 8]) = ld_stream(src + (long long)row * v_ss + c * 8);
         }
         __syncthreads();
         uint16_t* dst = vt + (((b * H + h) * dst_ntile) + dst_tile0 + tI) * (128 * 64);
@@ -310,7 +324,7 @@ __global__ void pack_v_kernel(const uint16_t* __restrict__ v, uint16_t* __restri
                 const int k0 = (p0 & 32) + pv_key_of_pos(p0 & 31), k1 = (p1 & 32) + pv_key_of_pos(p1 & 31);
                 w[e] = (uint32_t)tile[k0][d] | ((uint32_t)tile[k1][d] << 16);
             }
-            *reinterpret_cast<uint4*>(dst + d * 64 + pc * 8) = make_uint4(w[0], w[1], w[2], w[3]);
+            st_stream(dst + d * 64 + pc * 8, make_uint4(w[0], w[1], w[2], w[3]));
         }
         __syncthreads();
     }
@@ -1034,7 +1048,7 @@ __global__ void __launch_bounds__(256) ln_modulate_wave_kernel(const uint16_t* _
         const uint16_t* xr = x + row * x_rs + lane * 8;
         uint4 raw[NV];
 #pragma unroll
-        for (int i = 0; i < NV; ++i) raw[i] = *reinterpret_cast<const uint4*>(xr + i * 512);
+        for (int i = 0; i < NV; ++i) raw[i] = ld_stream(xr + i * 512);
         const bool alt = mask && mask[row];
         const uint16_t* sh = (alt ? shift2 : shift) + lane * 8;
         const uint16_t* sc = (alt ? scale2 : scale) + lane * 8;
@@ -1069,7 +1083,7 @@ __global__ void __launch_bounds__(256) ln_modulate_wave_kernel(const uint16_t* _
                 const float m = round_to<T>(n * round_to<T>(1.0f + sv[e]));       // x * (1 + scale)
                 o[e] = m + hv[e];                                                 // + shift (rounded by pack8)
             }
-            *reinterpret_cast<uint4*>(yr + i * 512) = pack8<T>(o);
+            st_stream(yr + i * 512, pack8<T>(o));
         }
     }
 }

@@ -503,4 +503,22 @@ AG)
   run AG_default --steps 20 --warmup 5
   brief $O/AG_default.json
   ;;
+AI)
+  # streaming (nontemporal) loads / stores in the row kernels: the library before (alt_libs/libjenga_amd_base.so) vs after,
+  # isolated kernel rates (roofline_secondary) and the loop, interleaved; the practical copy roof of the box beside them
+  ./tools/micro/hbm_copy > $O/AI_hbm_copy.txt 2>&1; grep -E "172800|D2D" $O/AI_hbm_copy.txt
+  L="--steps 6 --no-cpu-baseline --no-dense-ref --no-wan-extra --no-rotate-ref"
+  JENGA_LIB=$PWD/alt_libs/libjenga_amd_base.so run AI_base $L
+  run AI_nt $L
+  JENGA_LIB=$PWD/alt_libs/libjenga_amd_base.so run AI_base2 $L
+  run AI_nt2 $L
+  brief $O/AI_*.json
+  python - $O/AI_base.json $O/AI_nt.json $O/AI_base2.json $O/AI_nt2.json <<'PY'
+import json,sys
+for f in sys.argv[1:]:
+    d=json.loads([l for l in open(f).read().strip().splitlines() if l.startswith("{")][-1])
+    r=d["roofline_secondary"]
+    print(f.split("/")[-1], {k:(r[k]["ms"], r[k]["achieved"]) for k in ("gather_rows","ln_modulate","qk_norm_rope_pool","pack_v")})
+PY
+  ;;
 esac
