@@ -312,7 +312,9 @@ def secondary_roofline(dev, S_img=115200, S_txt=256, H=24, C=3072, mlp=12288, to
     w3 = rnd(C, C + mlp) * 0.02
     gemm("linear2 + gate*y + residual epilogue", S, C, C + mlp, lambda: _capi.linear(cat, w3, bias, gate=gate, res=xs))
     out["gemm"] = gem
-    out["note"] = ("isolated: 6-10 back-to-back launches per kernel between two HIP events, after the timed region (short "
+    out["note"] = ("HBM peak = the nominal 8 TB/s; a plain streaming copy of 2 x 708 MB reaches 6.6 TB/s on this chip (tools/micro/"
+                   "hbm_copy.hip, profiles/r04_micro_hbm_copy.txt: read-only 7.2, write-only 5.2).  "
+                   "Isolated: 6-10 back-to-back launches per kernel between two HIP events, after the timed region (short "
                    "runs read a few % high against the power-capped steady state of the loop); in-loop shares: "
                    "profiles/r04_bench_default_kernel_stats.csv")
     return out
