@@ -521,4 +521,11 @@ for f in sys.argv[1:]:
     print(f.split("/")[-1], {k:(r[k]["ms"], r[k]["achieved"]) for k in ("gather_rows","ln_modulate","qk_norm_rope_pool","pack_v")})
 PY
   ;;
+AJ)
+  # the full 50-step loop measured in both launch modes at HEAD, one box, back to back
+  L="--steps 50 --no-cpu-baseline --no-dense-ref --no-secondary --no-wan-extra --no-rotate-ref"
+  run AJ_full50 $L
+  JENGA_ATTN_FLAGS=157 run AJ_full50_rotate $L
+  brief $O/AJ_*.json
+  ;;
 esac
