@@ -31,7 +31,8 @@ ATTN_DEFAULT_FLAGS = int(os.environ.get("JENGA_ATTN_FLAGS", str(ATTN_XCD_REMAP |
 def set_attention_mode(mode):
     """"deterministic" (default: ascending list walk; bit-reproducible, the N-rank sequence-parallel forward equals the
     single-rank one bit for bit) or "throughput" (JENGA_ATTN_ROTATE: rotated list walk on a clock cursor, -2..3 % loop time,
-    results equal within fp32 rounding of the running sums but not bit-reproducible).  Same as JENGA_ATTN_FLAGS=29 / 157."""
+    results equal within fp32 rounding of the running sums but not bit-reproducible; measured on the HunyuanVideo shapes: -1.7 % over
+    all 50 steps -- on Wan2.1-14B it LOSES 2-3 %, leave it off there).  Same as JENGA_ATTN_FLAGS=29 / 157."""
     global ATTN_DEFAULT_FLAGS
     if mode == "deterministic":
         ATTN_DEFAULT_FLAGS &= ~ATTN_ROTATE
