@@ -142,3 +142,20 @@ def test_attention_mode_switch():
             _capi.set_attention_mode("fast")
     finally:
         _capi.ATTN_DEFAULT_FLAGS = before
+
+
+def test_attention_flag_constants_match_the_header():
+    """The Python flag constants of jenga_bsattn_fwd are the header's #defines (include/jenga_amd.h), and the modules'
+    default is XCD remap + balanced launch + LP kernel (+ the Python-side kept-count order)."""
+    import os
+    import re
+    from jenga_amd import _capi
+    hdr = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "jenga_amd.h")).read()
+    defs = {m.group(1): int(m.group(2)) for m in re.finditer(r"#define\s+JENGA_ATTN_(\w+)\s+(\d+)", hdr)}
+    assert defs == {"XCD_REMAP": 1, "PINGPONG": 2, "BALANCE": 4, "LP": 8, "COHORT": 32, "ROTATE": 128}
+    for name, val in defs.items():
+        assert getattr(_capi, "ATTN_" + name) == val, name
+    assert _capi.ATTN_SORTED == 16 and _capi.ATTN_PAIR == 64          # Python-side routing bits: not in the C header
+    if "JENGA_ATTN_FLAGS" not in os.environ:
+        assert _capi.ATTN_DEFAULT_FLAGS & ~_capi.ATTN_ROTATE == (_capi.ATTN_XCD_REMAP | _capi.ATTN_BALANCE | _capi.ATTN_LP
+                                                                  | _capi.ATTN_SORTED)
