@@ -487,7 +487,7 @@ __device__ __forceinline__ int lp_draw_ticket(int* ctr, int BH, int nq_img, int 
 #define LP_THREADS 256
 // VARIANT 0: the product kernel.  1: + the cohort start barrier.  2: dense cross-attention (jenga_cross_attn_fwd):
 // TEXT-mode rows only, kv-length mask on the last tile.  3: rotated list walk (JENGA_ATTN_ROTATE).  4: query blocks drawn
-// from per-XCD queues (JENGA_ATTN_BALANCE).  5: 4 + 3.  Separate instantiations on purpose (see above).  (Two more were measured and removed: rotation + pacing -- a workgroup ahead of the
+// from per-XCD queues (JENGA_ATTN_BALANCE).  5: 4 + 3.  6 (experiments library): 4 + 1.  Separate instantiations on purpose (see above).  (Two more were measured and removed: rotation + pacing -- a workgroup ahead of the
 // cursor sleeps -- lost 10 %; rotation + whole heads per XCD got the L2 hit rate to 47 % and 35.5 KB per kept pair but ran
 // 2 % behind plain rotation: eight heads in flight overflow the Infinity Cache.  profiles/r04_attn_rotate_ab.json.)
 template <typename T, int VARIANT>
@@ -505,7 +505,7 @@ __global__ void __launch_bounds__(LP_THREADS, 2) bsattn_lp_kernel(LpParams P) {
     if (VARIANT == 2) return;
     int li = id - P.n_text_wg_pad;
     int bal_seq = 0, bal_total = 0;
-    if (VARIANT == 4 || VARIANT == 5) {
+    if (VARIANT == 4 || VARIANT == 5 || VARIANT == 6) {
         // cross-XCD balancing: the hardware deals workgroup ids to the 8 XCDs round robin, so with one workgroup per query
         // block every XCD gets the same number of blocks whatever its speed -- and the XCDs of one chip differ by several
         // per cent.  Here a workgroup DRAWS its query block: a ticket from the queue of the XCD it runs on (the same
@@ -534,10 +534,12 @@ __global__ void __launch_bounds__(LP_THREADS, 2) bsattn_lp_kernel(LpParams P) {
         m = r;
     }
 #if LP_EXP
-    if (VARIANT == 1) {
+    if (VARIANT == 1 || VARIANT == 6) {      // (6: on drawn blocks -- the remapped launch position IS the queue position)
         if (threadIdx.x == 0) {
             const CohortCfg C = g_cohort_cfg;
             const int x = r & 7, pos = r >> 3;
+            // a workgroup that drew from another XCD's queue shares no L2 with that cohort: it reports in and does not wait
+            const bool guest = VARIANT == 6 && (((int)blockIdx.x - P.n_text_wg_pad) & 7) != x;
             int nv = P.nq_img - x * P.xcd_chunk;                 // valid launch positions of this XCD per (b, h)
             nv = nv < P.xcd_chunk ? nv : P.xcd_chunk;
             const int seq = bh * nv + pos, total = P.B * P.H * nv;
@@ -546,11 +548,27 @@ __global__ void __launch_bounds__(LP_THREADS, 2) bsattn_lp_kernel(LpParams P) {
             members = members < C.size ? members : C.size;
             members = members < C.quorum ? members : C.quorum;
             int* c = C.ctr + x * C.stride + gen;
-            __hip_atomic_fetch_add(c, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const long long t0 = (long long)wall_clock64();
-            while (__hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < members &&
-                   (long long)wall_clock64() - t0 < C.timeout)
-                __builtin_amdgcn_s_sleep(16);
+            {   // (one lane is active: its pointer, in SGPRs for the asm operands)
+                const unsigned long long cv = (unsigned long long)c;
+                const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)cv);
+                const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(cv >> 32));
+                c = reinterpret_cast<int*>(((unsigned long long)hi << 32) | lo);
+            }
+            // (opaque accesses like the ticket code's: with the compiler's own atomics this variant's main loop reloaded
+            // DMA offsets from scratch -- part of the loss recorded for it in profiles/r04_attn_cohort_ab.json)
+            int arrived = lp_ticket_add(c, -2) + 1;
+            auto now = [](int seq) {      // (s_memrealtime as a pure function of `seq`: the builtin counts as a memory access)
+                unsigned long long t;
+                asm("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0) ; clock %1" : "=s"(t) : "s"(seq));
+                return (long long)t;
+            };
+            const long long t0 = now(-1);
+            int spin = 0;
+            while (!guest && arrived < members && now(spin) - t0 < C.timeout) {
+                const unsigned zero = 0;
+                asm("s_sleep 16\n\tglobal_load_dword %0, %1, %2 sc1\n\ts_waitcnt vmcnt(0) ; poll %3" : "=v"(arrived) : "v"(zero), "s"(c), "s"(spin));
+                ++spin;
+            }
         }
         __syncthreads();
     }
@@ -865,7 +883,7 @@ int jenga_bsattn_lp_launch(void* stream, const void* q, const void* k, const voi
     // by launch position and stay with the static mapping.
     long long grid_bal = 0;
     int bal_slot = -1;
-    bool static_only = cohort || rot_ticks < 0;
+    bool static_only = (cohort && !(flags & JENGA_ATTN_BALANCE)) || rot_ticks < 0 || (cohort && rot_ticks != 0);
 #if LP_EXP
     static_only = static_only || getenv("JENGA_ROTATE_REPLAY") != nullptr;
 #endif
@@ -888,6 +906,12 @@ int jenga_bsattn_lp_launch(void* stream, const void* q, const void* k, const voi
     if (rot_ticks != 0 || grid_bal) lp_times_hook(grid_bal ? grid_bal : grid, (hipStream_t)stream);
 #endif
     hipError_t e;
+#if LP_EXP
+    if (grid_bal && cohort)
+        e = dtype == JENGA_BF16 ? lp_launch<BF16, 6>(P, grid_bal, (hipStream_t)stream)
+                                : lp_launch<FP16, 6>(P, grid_bal, (hipStream_t)stream);
+    else
+#endif
     if (grid_bal && rot_ticks > 0)
         e = dtype == JENGA_BF16 ? lp_launch<BF16, 5>(P, grid_bal, (hipStream_t)stream)
                                 : lp_launch<FP16, 5>(P, grid_bal, (hipStream_t)stream);

@@ -83,6 +83,9 @@ def test_cohort_start_barrier_is_bit_identical(dev, monkeypatch, H, nq_img, size
         coh = run(_capi.ATTN_XCD_REMAP | _capi.ATTN_LP | _capi.ATTN_SORTED | _capi.ATTN_COHORT)
         torch.cuda.synchronize()
         assert torch.equal(base, coh)
+        both = run(_capi.ATTN_XCD_REMAP | _capi.ATTN_LP | _capi.ATTN_SORTED | _capi.ATTN_COHORT | _capi.ATTN_BALANCE)
+        torch.cuda.synchronize()       # the barrier on DRAWN blocks (generation = ticket / size; guests do not wait)
+        assert torch.equal(base, both)
 
 
 @pytest.mark.parametrize("period_us", [1, 37, 5000])
