@@ -31,6 +31,16 @@
 // stream is in-order, so each of these took instructions out of the gaps between its MFMAs: MFMA-pipe busy 64 % -> 79 %
 // (profiles/r02_pmc_bsattn_lp*.json).  The first step, the < 6 remainder steps, the tail blocks that need text_amp or
 // the kv-length mask, and the text rows use the generic forms (LP_STEP, lp_slow_tile).
+//
+// Launch modes (round 4; instantiations of one kernel template, see bsattn_lp_kernel): the static mapping of query blocks
+// to workgroups (round 3's launch; what a capturing stream gets), the BALANCED launch (default: workgroups draw their query
+// block from per-XCD queues -- the XCDs of a chip run 3-8 % apart), the rotated list walk on a clock cursor (opt-in, not
+// bit-reproducible) on either mapping, and the dense cross-attention of the Wan blocks.  Two rules that the measurements
+// behind them produced, both checked by tests/test_isa_cpu.py:
+//   * the kernel sits at 256 VGPRs; anything compiled into the static instantiation moves spill reloads into the unrolled
+//     main loop -- new modes are new instantiations;
+//   * nothing the compiler can take for a store (an atomic, s_sleep, s_memrealtime) in front of the main loop: the uniform
+//     loads behind it stop being scalar loads, a DMA offset goes to scratch, and every reload drains the DMA queue.
 #include <cstdlib>
 #include <cstdio>
 #include <cstring>
