@@ -102,6 +102,7 @@ __device__ float g_rot_spread = 0.42f;  // JENGA_ATTN_ROTATE position mode: grow
 template <typename T, bool TEXT, bool XKV = false, int ROT = 0>
 __device__ __forceinline__ void attn_block_lp(const LpParams& P, unsigned char* smem, int b, int h, int m,
                                               int rot_period = 0, int rot_seq = 0) {
+    (void)rot_seq;      // (the experiments library's position / replay modes index by it)
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -434,6 +435,8 @@ __device__ __forceinline__ void lp_record_times(int li, long long t_start, long 
         tm[2 * li] = (unsigned)t_start;
         tm[2 * li + 1] = (unsigned)t_end;
     }
+#else
+    (void)li; (void)t_start; (void)t_end;
 #endif
 }
 
