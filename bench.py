@@ -51,6 +51,14 @@ PRESETS = {   # scripts/hyvideo_jenga_{base,turbo,flash,3stage}.sh and scripts/h
 }
 
 
+
+def attn_kernel_name():
+    """Name of the attention kernel the current default flags launch (as rocprofv3 prints it)."""
+    from jenga_amd import _capi
+    fl = _capi.ATTN_DEFAULT_FLAGS
+    return ("jenga::bsattn_lq_kernel<bf16>" if fl & _capi.ATTN_PAIR else
+            "jenga::bsattn_lp_kernel<bf16>" if fl & _capi.ATTN_LP else "jenga::bsattn_fwd_kernel<bf16>")
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -88,9 +96,8 @@ def parse():
     ap.add_argument("--no-wan-extra", action="store_true",
                     help="skip the short Wan2.1-14B leg (one forward at each drop rate, after the timed region) that puts a "
                          "configs[3] number into the default N=1 record")
-    ap.add_argument("--no-rotate-ref", action="store_true",
-                    help="skip the computed steps re-run after the timed region with JENGA_ATTN_ROTATE (the opt-in, not "
-                         "bit-reproducible launch mode of the attention kernel: rotated list walk on a clock cursor)")
+    ap.add_argument("--no-other-kernel-ref", action="store_true",
+                    help="skip the computed steps re-run after the timed region with the OTHER attention kernel (LP <-> pair)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-dense-ref", action="store_true",
                     help="skip the ONE dense (sa-drop 0) computed step that is run after the timed region to report "
@@ -511,7 +518,7 @@ def wan_main(a, dev):
                    "qk_norm_gain": 4.0, "weights": "random init N(0,0.02), seed 0 (norm_q / norm_k weights x 4: peaked "
                                                    "block softmax, top_k decides as in a trained model)",
                    "finite_output": finite, "parallelism": "single GPU"},
-        "roofline": {"kernel": "jenga::bsattn_lp_kernel<bf16>", "bound": "mfma", "achieved": round(ach, 1),
+        "roofline": {"kernel": attn_kernel_name(), "bound": "mfma", "achieved": round(ach, 1),
                      "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_PEAK_TFLOPS, 4), "traffic": None,
                      "launches": ps["launches"], "avg_launch_ms": round(ps["total_ms"] / max(ps["launches"], 1), 3),
                      "kept_block_pairs_per_launch": ps["pairs"] // max(ps["launches"], 1),
@@ -868,14 +875,14 @@ def main():
             dense_ms = float(tt.item())
         model.enable_skip = do_skip
 
-    # ---- the opt-in launch mode beside it (NOT in the timed region, not `value`): one computed step per stage with the
-    #      attention kernel's rotated list walk (JENGA_ATTN_ROTATE: every workgroup starts its ascending list at the phase of
-    #      a chip-wide clock cursor, so co-resident workgroups meet in the L2 without waiting; the accumulation order then
-    #      depends on start times -- results equal within fp32 rounding of the running sums, not bit-reproducible)
-    rot_ms, rot_prof = {}, None
-    if not a.no_rotate_ref and not dist_on and sim <= 1 and a.preset != "dense" and (_capi.ATTN_DEFAULT_FLAGS & _capi.ATTN_LP):
+    # ---- the other attention kernel beside it (NOT in the timed region, not `value`): one computed step per stage with the
+    #      kernel that is not the default (pair kernel <-> LP kernel), same box, same lists
+    rot_ms, rot_prof, other_flags = {}, None, None
+    if not a.no_other_kernel_ref and not dist_on and sim <= 1 and a.preset != "dense" and \
+            (_capi.ATTN_DEFAULT_FLAGS & (_capi.ATTN_LP | _capi.ATTN_PAIR)):
         flags0 = _capi.ATTN_DEFAULT_FLAGS
-        _capi.ATTN_DEFAULT_FLAGS = flags0 | _capi.ATTN_ROTATE
+        other_flags = _capi.ATTN_LP_FLAGS if (flags0 & _capi.ATTN_PAIR) else _capi.ATTN_PAIR_FLAGS
+        _capi.ATTN_DEFAULT_FLAGS = other_flags
         _capi.ATTN_PROFILE = rot_prof = _capi.AttnProfile()
         try:
             for k in range(len(stages)):
@@ -988,7 +995,7 @@ def main():
                                                                           if a.gemm_tuning.startswith("record:") else
                                                                           " (TunableOp replay, tuning off)")
                                       if gemm_file else "hipBLASLt default heuristic")},
-        "roofline": {"kernel": "jenga::bsattn_lp_kernel<bf16>" if (_capi.ATTN_DEFAULT_FLAGS & 8) else "jenga::bsattn_fwd_kernel<bf16>", "bound": "mfma", "achieved": round(ach, 1),
+        "roofline": {"kernel": attn_kernel_name(), "bound": "mfma", "achieved": round(ach, 1),
                      "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_PEAK_TFLOPS, 4),
                      "traffic": traffic, "traffic_TBps": traffic_tbps,
                      "traffic_provenance": "derived, not read in this run: a committed per-kept-pair constant x this run's pairs",
@@ -1021,10 +1028,10 @@ def main():
         r_ach = rs["pairs"] * FLOPS_PER_PAIR / (rs["total_ms"] * 1e-3) / 1e12 if rs["total_ms"] > 0 else 0.0
         est = sum(n * (rot_ms[key[0]] if key[1] == "c" and key[0] in rot_ms else class_ms(key) if sampled else mean(cls.get(key, [0.0])))
                   for key, n in counts.items()) / 1e3
-        res.setdefault("extra", {})["attn_rotate"] = {
-            "what": "JENGA_ATTN_ROTATE (JENGA_ATTN_FLAGS=157 = the default | 128), opt-in: rotated list walk on a clock cursor, period = the previous "
-                    "launch's workgroup lifetime; NOT bit-reproducible (accumulation order depends on start times) -- not the "
-                    "default, not `value`",
+        res.setdefault("extra", {})["attn_other_kernel"] = {
+            "what": f"JENGA_ATTN_FLAGS={other_flags}: the attention kernel that is NOT the default of this run "
+                    f"({'LP kernel, csrc/bsattn3.hip' if other_flags & _capi.ATTN_LP else 'pair kernel, csrc/bsattn5.hip'}); "
+                    "same box, same lists, not `value`",
             "ms_per_computed_step": {f"stage{k}": round(v, 2) for k, v in rot_ms.items()},
             "s_per_video_estimate": round(est, 3),
             "attention_TFLOPs": round(r_ach, 1), "attention_frac_of_peak": round(r_ach / MFMA_PEAK_TFLOPS, 4),

@@ -14,6 +14,13 @@
  *   - return value: JENGA_OK or an error code; jenga_last_error() gives the message for this thread.
  *   - head_dim must be 128, block size 128 (the only configuration the reference runs: HunyuanVideo,
  *     HunyuanVideo-I2V, Wan2.1 all use D=128 and BLOCK_M=BLOCK_N=128).
+ *   - state the library keeps (everything else is a pure function of its arguments):
+ *       a thread-local error string (jenga_last_error);
+ *       per device, for launches with JENGA_ATTN_BALANCE: 64 sets of 8 ticket counters in device memory, an event per
+ *       set, a mutex and a hand-out cursor (csrc/lp_balance.h) -- a launch zeroes its set on its own stream, sets are
+ *       reused behind their event, results do not depend on them;
+ *       per process: JENGA_BALANCE_EXTRA_PCT read once at the first balanced launch; one "dynamic LDS size set" flag per
+ *       kernel instantiation and device; the hipBLASLt handle, plan cache and timed algorithm choices of jenga_linear.
  */
 #ifndef JENGA_AMD_H
 #define JENGA_AMD_H
@@ -25,9 +32,11 @@
 extern "C" {
 #endif
 
-#define JENGA_ABI_VERSION 3   /* 2: jenga_block_select(flags), jenga_bsattn_fwd(order), jenga_sp_qkv_prologue, jenga_order_by_count, jenga_linear
+#define JENGA_ABI_VERSION 4   /* 2: jenga_block_select(flags), jenga_bsattn_fwd(order), jenga_sp_qkv_prologue, jenga_order_by_count, jenga_linear
                                * 3: jenga_sp_qkv_prologue takes (xq, xk) or xv alone; jenga_stream_delay; jenga_cross_attn_fwd;
-                               *    jenga_linear_export_choices / _import_choices; jenga_linear refuses a workspace smaller than its plan's */
+                               *    jenga_linear_export_choices / _import_choices; jenga_linear refuses a workspace smaller than its plan's
+                               * 4: jenga_pair_merge / jenga_bsattn_pair_fwd (the pair kernel) are part of the library; the experiment
+                               *    launch flags (ping-pong 2, cohort 32, rotate 128) are gone */
 
 enum { JENGA_OK = 0, JENGA_EINVAL = 1, JENGA_ELAUNCH = 2, JENGA_EUNSUPPORTED = 3 };
 enum { JENGA_BF16 = 0, JENGA_FP16 = 1 };
@@ -259,28 +268,19 @@ int jenga_bsattn_fwd(void* stream, const void* q, const void* k, const void* vt,
                      int64_t k_sb, int64_t k_ss, int64_t k_sh, int64_t o_sb, int64_t o_ss, int64_t o_sh,
                      float sm_scale, float text_amp, int64_t text_block_start, int dtype, int flags);
 /* flags: launch order and which of the parity-equivalent kernels runs (DESIGN.md section 3 has the measurements)
- *   neither PINGPONG nor LP: the round-1 kernel (csrc/bsattn.hip), 4-wave workgroup per 128-row query block */
+ *   no LP bit: the round-1 kernel (csrc/bsattn.hip), 4-wave workgroup per 128-row query block */
 #define JENGA_ATTN_XCD_REMAP 1 /* contiguous q-block ranges per XCD (L2 locality); 0 = plain head-major order */
-#define JENGA_ATTN_PINGPONG 2  /* EXPERIMENT (libraries built with JENGA_EXPERIMENTS only; else JENGA_EUNSUPPORTED):
-                                  8-wave workgroups, MFMA / softmax phases of the two waves per SIMD in anti-phase */
-#define JENGA_ATTN_BALANCE 4   /* (round 4, LP kernel with XCD_REMAP; part of the Python modules' default) every workgroup DRAWS
-                                  its query block: a ticket from the queue of the XCD it runs on (the same contiguous range
-                                  and order as the static mapping) and, once that is empty, from the fullest other queue; the
-                                  grid is oversubscribed by 1/8.  Evens out the speed differences between the 8 XCDs of a
-                                  chip (3-8 % in workgroup lifetime).  Bit-identical results.  Every launch in flight has its
-                                  own ticket counters (64 sets per device, reused behind an event); a capturing stream gets
-                                  the static mapping */
+#define JENGA_ATTN_BALANCE 4   /* (LP and pair kernels with XCD_REMAP; part of the Python modules' default) every workgroup
+                                  DRAWS its query block (pair): a ticket from the queue of the XCD it runs on (the same
+                                  contiguous range and order as the static mapping) and, once that is empty, from the
+                                  fullest other queue; the grid is oversubscribed by 1/8.  Evens out the speed differences
+                                  between the 8 XCDs of a chip (3-8 % in workgroup lifetime).  Bit-identical results.  Every
+                                  launch in flight has its own ticket counters (64 sets per device, reused behind an event);
+                                  a capturing stream gets the static mapping */
 #define JENGA_ATTN_LP 8        /* same decomposition, in-wave software pipeline (softmax inside the MFMA stream):
-                                  csrc/bsattn3.hip, the default of the Python modules (XCD_REMAP | LP) */
-#define JENGA_ATTN_COHORT 32   /* EXPERIMENT (libraries built with JENGA_EXPERIMENTS only; else JENGA_EUNSUPPORTED; round 4,
-                                  LP kernel with XCD_REMAP): the workgroups an XCD runs at a time start together (arrival
-                                  counters, bounded spin) and walk their lists in step: L2 hits for fabric bytes, slower */
-#define JENGA_ATTN_ROTATE 128  /* opt-in (round 4, LP kernel): every workgroup walks its list from a start rotated by the
-                                  phase of a chip-wide clock cursor (period: the previous launch's workgroup lifetime, or
-                                  JENGA_ROTATE_PERIOD_US): co-resident workgroups meet in the L2 without waiting.  Results
-                                  equal within fp32 rounding of the running sums, NOT bit-identical from run to run.  (The
-                                  experiments library adds a position mode and a record / replay mode of the start phases
-                                  and a per-workgroup tick dump: JENGA_ROTATE_SLOTS, JENGA_ROTATE_REPLAY, JENGA_LP_TIMES_DUMP) */
+                                  csrc/bsattn3.hip */
+/* (bits 2, 32 and 128 were the ping-pong, cohort and rotated-walk experiments of rounds 1-4: measured, recorded in
+ * DESIGN.md / profiles/, removed in ABI version 4; they are ignored) */
 /* order (may be NULL): int32 [B,H,nq_img], launch position -> image query block, a permutation per (b, h) -- a
  *   scheduling hint only (every query block is computed exactly once either way, results are bit-identical).
  *   jenga_order_by_count fills it from cnt: inside every segment of `segment` consecutive query blocks the blocks are
@@ -291,31 +291,30 @@ int jenga_bsattn_fwd(void* stream, const void* q, const void* k, const void* vt,
 int jenga_order_by_count(void* stream, const int32_t* cnt, int64_t BH, int64_t nq_img, int64_t segment,
                          int32_t* order);
 
-#ifdef JENGA_EXPERIMENTS
-/* ---- measured alternatives, NOT part of the product library (python -m jenga_amd.build --experiments builds
- * libjenga_amd_exp.so = the product sources + csrc/experiments/ with -DJENGA_EXPERIMENTS) ------------------------------
- * Pair variant: it halves the staged bytes of shared kv blocks but even with 85 % of the blocks shared it ran
- * 1017 TFLOP/s against 1044-1056 for jenga_bsattn_fwd on the same lists: two Hilbert-adjacent
- * query blocks per workgroup, kv blocks kept by BOTH staged once for 256 query rows, one wave per SIMD with the softmax
- * of one (32-row, 64-key) item interleaved into the MFMA stream of its neighbours (csrc/experiments/bsattn2.hip).
+/* ---------------------------------------------------------------------------------------------------
+ * Block-sparse attention forward on query-block PAIRS (csrc/bsattn5.hip, round 5; same reference lines and semantics as
+ * jenga_bsattn_fwd).  Two Hilbert-adjacent query blocks per workgroup, one wave per SIMD, 64 query rows per wave: a kv
+ * block kept by BOTH is staged once for 256 query rows and every K / V^T fragment read from LDS feeds two MFMAs.
  *   jenga_pair_merge: idx/cnt of jenga_block_select ->
  *       pidx int32 [B,H,ceil(nq_img/2),n_blocks]: per query-block pair (2j, 2j+1) the kv blocks both rows keep, then
  *            those only row 2j keeps, then those only row 2j+1 keeps -- each part ascending;
  *       pcnt int32 [B,H,ceil(nq_img/2),4]: the three part lengths, 0.   (odd nq_img: the last pair has one row)
- *   jenga_bsattn_pair_fwd: same arguments and semantics as jenga_bsattn_fwd with (pidx, pcnt) in place of (idx, cnt).
- *       The kv blocks of a row are visited in the order (only-this-row, shared) instead of ascending; online softmax
- *       is order independent up to fp32 rounding and every rescale stays an exact power of two.
- *   flags of jenga_bsattn_pair_fwd: JENGA_ATTN_XCD_REMAP; with JENGA_ATTN_LP the 8-wave "LP pair" experiment runs
- *   instead (csrc/experiments/bsattn4.hip: two query blocks per 512-thread workgroup, shared kv blocks staged once for
- *   both; restriction: no masked image block in an unshared list, i.e. seqlens >= the image length). */
+ *   jenga_bsattn_pair_fwd: same arguments and semantics as jenga_bsattn_fwd with (pidx, pcnt) in place of (idx, cnt);
+ *       text query blocks run as pairs of their own in the same launch.  The kv blocks of a row are visited in the order
+ *       (only-this-row, shared), each part ascending, instead of ascending overall: online softmax is order independent up
+ *       to fp32 rounding of the running sums and every rescale stays an exact power of two -- results are deterministic and
+ *       equal to jenga_bsattn_fwd's within that rounding, not bit for bit.
+ *   order (may be NULL): int32 [B,H,ceil(nq_img/2)], launch position -> pair, a permutation per (b, h): the scheduling
+ *       hint of jenga_bsattn_fwd for pairs (jenga_order_by_count on the pairs' work 2 n_shared + n_a + n_b, segment =
+ *       ceil(npairs / 8) with JENGA_ATTN_XCD_REMAP); results do not depend on it.
+ *   flags: JENGA_ATTN_XCD_REMAP (contiguous pair ranges per XCD), JENGA_ATTN_BALANCE (pairs drawn from per-XCD queues). */
 int jenga_pair_merge(void* stream, const int32_t* idx, const int32_t* cnt, int64_t B, int64_t H, int64_t nq_img,
                      int64_t n_blocks, int32_t* pidx, int32_t* pcnt);
 int jenga_bsattn_pair_fwd(void* stream, const void* q, const void* k, const void* vt, void* o,
-                          const int32_t* seqlens, const int32_t* pidx, const int32_t* pcnt, int64_t B, int64_t H,
-                          int64_t n_blocks, int64_t nq_img, int64_t q_sb, int64_t q_ss, int64_t q_sh, int64_t k_sb,
+                          const int32_t* seqlens, const int32_t* pidx, const int32_t* pcnt, const int32_t* order,
+                          int64_t B, int64_t H, int64_t n_blocks, int64_t nq_img, int64_t q_sb, int64_t q_ss, int64_t q_sh, int64_t k_sb,
                           int64_t k_ss, int64_t k_sh, int64_t o_sb, int64_t o_ss, int64_t o_sh, float sm_scale,
                           float text_amp, int64_t text_block_start, int dtype, int flags);
-#endif /* JENGA_EXPERIMENTS */
 
 /* ---------------------------------------------------------------------------------------------------
  * Dense cross-attention (ABI 3).  Replaces the flash_attention call of WanT2VCrossAttention.forward

@@ -12,35 +12,18 @@ LIB_PATH = os.environ.get("JENGA_LIB", os.path.join(_HERE, "libjenga_amd.so"))
 JENGA_BF16, JENGA_FP16 = 0, 1
 # jenga_bsattn_fwd flags (include/jenga_amd.h).  No kernel bit = the round-1 kernel, exactly as in the C header.
 ATTN_XCD_REMAP = 1
-ATTN_PINGPONG = 2    # experiment: needs libjenga_amd_exp.so (python -m jenga_amd.build --experiments; JENGA_LIB=...)
-ATTN_BALANCE = 4     # round 4: query blocks DRAWN from per-XCD queues on an oversubscribed grid (LP kernel + XCD remap): evens out
-#                      the speed differences between the XCDs of a chip; bit-identical; in the default since round 4
+ATTN_BALANCE = 4     # query blocks (pairs) DRAWN from per-XCD queues on an oversubscribed grid: evens out the speed differences
+#                      between the XCDs of a chip; bit-identical; in the default since round 4
 ATTN_LEGACY = 0      # (readability alias) no kernel bit: the round-1 kernel, one query block per 4-wave workgroup
-ATTN_LP = 8          # round-1 decomposition + in-wave software pipeline (csrc/bsattn3.hip): the default
+ATTN_LP = 8          # round-1 decomposition + in-wave software pipeline (csrc/bsattn3.hip)
 ATTN_SORTED = 16     # (Python-side) kept-count-aware launch order: jenga_order_by_count feeds jenga_bsattn_fwd's `order`
-ATTN_COHORT = 32     # experiment (round 4; experiments library only): cohort start barrier per XCD generation
-ATTN_ROTATE = 128    # experiment (round 4): rotated list walk on a clock cursor (LP kernel); not bit-reproducible
-ATTN_PAIR = 64       # (Python-side, experiment) route to jenga_bsattn_pair_fwd: the pair kernel; with ATTN_LP the 8-wave
-#                      LP pair (csrc/experiments/); needs libjenga_amd_exp.so
-# default: LP kernel, XCD remap, kept-count-aware order inside every XCD's range (+3.3 % sustained on lists whose counts
-# vary, neutral on constant counts: profiles/r03_attn_order_ab.json), cross-XCD balancing (+2.6 % on flat lists, +4.4 % on
-# clustered ones, -1.7 % loop time: profiles/r04_attn_balance_ab.json).  25 = the round-3 default (static mapping).
-ATTN_DEFAULT_FLAGS = int(os.environ.get("JENGA_ATTN_FLAGS", str(ATTN_XCD_REMAP | ATTN_BALANCE | ATTN_LP | ATTN_SORTED)))
-
-
-def set_attention_mode(mode):
-    """"deterministic" (default: ascending list walk; bit-reproducible, the N-rank sequence-parallel forward equals the
-    single-rank one bit for bit) or "throughput" (JENGA_ATTN_ROTATE: rotated list walk on a clock cursor, -2..3 % loop time,
-    results equal within fp32 rounding of the running sums but not bit-reproducible; measured on the HunyuanVideo shapes: -1.7 % over
-    all 50 steps -- on Wan2.1-14B it LOSES 2-3 %, leave it off there).  Same as JENGA_ATTN_FLAGS=29 / 157."""
-    global ATTN_DEFAULT_FLAGS
-    if mode == "deterministic":
-        ATTN_DEFAULT_FLAGS &= ~ATTN_ROTATE
-    elif mode == "throughput":
-        ATTN_DEFAULT_FLAGS |= ATTN_ROTATE
-    else:
-        raise ValueError("attention mode must be 'deterministic' or 'throughput'")
-    return ATTN_DEFAULT_FLAGS
+ATTN_PAIR = 64       # (Python-side) route to jenga_pair_merge + jenga_bsattn_pair_fwd: the pair kernel of round 5
+#                      (csrc/bsattn5.hip: two Hilbert-adjacent query blocks per workgroup, 64 query rows per wave)
+# LP default: LP kernel, XCD remap, kept-count-aware order inside every XCD's range (+3.3 % sustained on lists whose counts
+# vary: profiles/r03_attn_order_ab.json), cross-XCD balancing (-1.7 % loop time: profiles/r04_attn_balance_ab.json).
+ATTN_LP_FLAGS = ATTN_XCD_REMAP | ATTN_BALANCE | ATTN_LP | ATTN_SORTED
+ATTN_PAIR_FLAGS = ATTN_XCD_REMAP | ATTN_BALANCE | ATTN_SORTED | ATTN_PAIR
+ATTN_DEFAULT_FLAGS = int(os.environ.get("JENGA_ATTN_FLAGS", str(ATTN_LP_FLAGS)))
 
 
 SELECT_DEVICE_SCAN = 1   # jenga_block_select flags: torch's DEVICE cumsum semantics for the kept-count rule
@@ -79,12 +62,8 @@ SIGNATURES = {
     "jenga_cross_attn_fwd": (_i32, [_vp] * 5 + [_i64] * 14 + [_f32, _i32]),
     "jenga_linear_export_choices": (_i64, [_vp, _i64]),
     "jenga_linear_import_choices": (_i32, [_vp, _i64]),
-}
-
-# the experiments library (libjenga_amd_exp.so, include/jenga_amd.h under JENGA_EXPERIMENTS) adds these
-EXPERIMENT_SIGNATURES = {
     "jenga_pair_merge": (_i32, [_vp, _vp, _vp] + [_i64] * 4 + [_vp, _vp]),
-    "jenga_bsattn_pair_fwd": (_i32, [_vp] * 8 + [_i64] * 13 + [_f32, _f32, _i64, _i32, _i32]),
+    "jenga_bsattn_pair_fwd": (_i32, [_vp] * 9 + [_i64] * 13 + [_f32, _f32, _i64, _i32, _i32]),
 }
 
 _lib = None
@@ -136,19 +115,10 @@ def lib():
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)
             fn.restype, fn.argtypes = res, args
-        for name, (res, args) in EXPERIMENT_SIGNATURES.items():
-            if hasattr(L, name):
-                fn = getattr(L, name)
-                fn.restype, fn.argtypes = res, args
-        if L.jenga_abi_version() != 3:
+        if L.jenga_abi_version() != 4:
             raise JengaError("libjenga_amd.so ABI version mismatch; rebuild")
         _lib = L
     return _lib
-
-
-def has_experiments():
-    """True when the loaded library was built with JENGA_EXPERIMENTS (pair / LP-pair / ping-pong kernels)."""
-    return hasattr(lib(), "jenga_bsattn_pair_fwd")
 
 
 def _check(rc, what):
@@ -714,19 +684,20 @@ def bsattn_fwd(q, k, vt, seqlens, idx, cnt, nq_img, sm_scale, text_amp, text_blo
     if not xcd_remap:
         fl &= ~ATTN_XCD_REMAP
     pair = bool(fl & ATTN_PAIR)
-    if (pair or (fl & (ATTN_PINGPONG | ATTN_COHORT))) and not has_experiments():
-        raise JengaError("the pair / ping-pong / cohort attention launches are experiments: build libjenga_amd_exp.so with "
-                         "`python -m jenga_amd.build --experiments` and set JENGA_LIB to it")
-    if pair and (fl & ATTN_LP) and n_blocks == nq_img:
-        # the 8-wave LP pair takes no masked image block in an unshared list (csrc/experiments/bsattn4.hip): without
-        # text blocks the padded last image block can be one
-        raise JengaError("ATTN_LP | ATTN_PAIR needs text blocks behind the image blocks (masked image blocks in an "
-                         "unshared list are not handled by that experiment)")
     prof = ATTN_PROFILE
     with _on(q.device):
         pidx = pcnt = order_t = None
+        porder = None
         if pair and nq_img > 0:
             pidx, pcnt = pair_merge(idx, cnt, n_blocks)
+            npair = pidx.shape[2]
+            if (fl & ATTN_SORTED) and npair > 1:
+                # work-aware launch order of the pairs inside every XCD's range: a shared block costs two 32-row items per
+                # wave and tile, an unshared one one
+                seg = (npair + 7) // 8 if ((fl & ATTN_XCD_REMAP) and npair >= 64) else npair
+                if seg <= 2048:
+                    work = (2 * pcnt[..., 0] + pcnt[..., 1] + pcnt[..., 2]).contiguous()
+                    porder = order_by_count(work, seg)
         if order is not None:
             order_t = order
         elif (fl & ATTN_SORTED) and nq_img > 0 and (fl & ATTN_LP) and not pair:
@@ -741,13 +712,13 @@ def bsattn_fwd(q, k, vt, seqlens, idx, cnt, nq_img, sm_scale, text_amp, text_blo
             e0.record()
         common = (B, H, n_blocks, nq_img, *_bshd_strides(q), *_bshd_strides(k), *_bshd_strides(out), float(sm_scale),
                   float(text_amp), int(text_block_start), dtype_code(q.dtype))
-        cflags = fl & (ATTN_XCD_REMAP | ATTN_PINGPONG | ATTN_BALANCE | ATTN_LP | ATTN_COHORT | ATTN_ROTATE)
+        cflags = fl & (ATTN_XCD_REMAP | ATTN_BALANCE | ATTN_LP)
         if not pair:
             _check(lib().jenga_bsattn_fwd(_stream(q.device), _p(q), _p(k), _p(vt), _p(out), _p(seqlens), _p(idx),
                                           _p(cnt), _p(order_t), *common, cflags), "jenga_bsattn_fwd")
         else:
             _check(lib().jenga_bsattn_pair_fwd(_stream(q.device), _p(q), _p(k), _p(vt), _p(out), _p(seqlens),
-                                               _p(pidx), _p(pcnt), *common, cflags & ~ATTN_PINGPONG),
+                                               _p(pidx), _p(pcnt), _p(porder), *common, cflags & ~ATTN_LP),
                    "jenga_bsattn_pair_fwd")
         if prof is not None:
             e1.record()
@@ -799,12 +770,10 @@ def order_by_count(cnt, segment):
 
 
 def pair_merge(idx, cnt, n_blocks):
-    """(experiments library) idx int32 [B,H,nq,n_blocks], cnt int32 [B,H,nq] (jenga_block_select) -> (pidx
+    """idx int32 [B,H,nq,n_blocks], cnt int32 [B,H,nq] (jenga_block_select) -> (pidx
     [B,H,ceil(nq/2),n_blocks], pcnt [B,H,ceil(nq/2),4]): per query-block pair the kv blocks both keep | only the even
     row | only the odd row."""
     _need_gpu(idx, "pair_merge")
-    if not has_experiments():
-        raise JengaError("pair_merge is part of the experiments library (python -m jenga_amd.build --experiments)")
     B, H, nq, nb = idx.shape
     if nb != n_blocks or tuple(cnt.shape) != (B, H, nq) or idx.dtype != torch.int32 or cnt.dtype != torch.int32:
         raise ValueError("pair_merge: idx / cnt must be int32 [B,H,nq,n_blocks] / [B,H,nq]")

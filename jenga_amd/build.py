@@ -27,16 +27,9 @@ SOURCES = [
     # -Wno-inline-asm: the LDS-DMA helpers write M0 and say so in their clobber lists (a compiler-generated M0 user
     # must not assume it survives); clang warns that M0 is a reserved register -- that is the point of declaring it
     ("bsattn3.hip", ["-fno-honor-nans", "-fno-slp-vectorize", "-Wno-inline-asm"]),
+    # the pair kernel (round 5): same flags; its QK^T MFMAs are inline asm (lp_core.h, LP_QK_MFMA_ASM)
+    ("bsattn5.hip", ["-fno-honor-nans", "-fno-slp-vectorize", "-Wno-inline-asm"]),
 ]
-# measured-and-rejected attention kernels (the pair kernel, the 8-wave LP pair, the ping-pong variant inside
-# bsattn.hip): built only into libjenga_amd_exp.so by `python -m jenga_amd.build --experiments` (= every product source
-# compiled with -DJENGA_EXPERIMENTS + these); `JENGA_LIB=.../libjenga_amd_exp.so` selects it (tests/test_gpu_pair.py)
-EXPERIMENT_SOURCES = [
-    ("experiments/bsattn2.hip", ["-fno-honor-nans", "-fno-slp-vectorize", "-Wno-inline-asm"]),
-    ("experiments/bsattn4.hip", ["-fno-honor-nans", "-fno-slp-vectorize", "-Wno-inline-asm"]),
-]
-LIB_EXP = os.path.join(HERE, "libjenga_amd_exp.so")
-
 
 def _hipcc():
     for c in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
@@ -45,29 +38,47 @@ def _hipcc():
     raise RuntimeError("hipcc not found")
 
 
-def needs_build(lib=LIB):
-    if not os.path.exists(lib):
-        return True
-    t = os.path.getmtime(lib)
-    deps = [os.path.join(d, f) for d, _, fs in os.walk(CSRC) for f in fs] + [
+def _deps():
+    return sorted(os.path.join(d, f) for d, _, fs in os.walk(CSRC) for f in fs) + [
         os.path.join(HERE, "..", "include", "jenga_amd.h"), os.path.abspath(__file__)]   # (the flags live here)
-    return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=False, experiments=False):
-    lib = LIB_EXP if experiments else LIB
+def source_digest():
+    """sha256 over every file the library is built from (csrc/, the header, this file: the flags live here)."""
+    import hashlib
+    h = hashlib.sha256()
+    for d in _deps():
+        h.update(os.path.relpath(d, HERE).encode())
+        with open(d, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
+STAMP = LIB + ".src.sha256"       # written next to the library (git-ignored like it, ships to the GPU box with it)
+
+
+def needs_build(lib=LIB):
+    """True unless `lib` exists and was built from exactly the sources in the tree (content hash, not mtimes: a snapshot
+    copied to another machine keeps its prebuilt library only if it really matches)."""
+    if not os.path.exists(lib) or not os.path.exists(STAMP):
+        return True
+    with open(STAMP) as f:
+        return f.read().strip() != source_digest()
+
+
+def build(force=False, verbose=False):
+    lib = LIB
     if not force and not needs_build(lib):
         return lib
     hipcc = _hipcc()
-    objdir = os.path.join(HERE, "build", "exp" if experiments else "")
+    objdir = os.path.join(HERE, "build")
     os.makedirs(objdir, exist_ok=True)
     objs = []
     procs = []
-    for src, extra in SOURCES + (EXPERIMENT_SOURCES if experiments else []):
+    for src, extra in SOURCES:
         obj = os.path.join(objdir, os.path.basename(src).rsplit(".", 1)[0] + ".o")
         cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-x", "hip", "-c",
-               os.path.join(CSRC, src), "-o", obj] + extra + (["-DJENGA_EXPERIMENTS"] if experiments else []) \
-            + os.environ.get("JENGA_HIPCC_FLAGS", "").split()
+               os.path.join(CSRC, src), "-o", obj] + extra + os.environ.get("JENGA_HIPCC_FLAGS", "").split()
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
@@ -80,8 +91,10 @@ def build(force=False, verbose=False, experiments=False):
             print(out.decode(), file=sys.stderr)
     cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", lib] + objs + ["-lhipblaslt"]
     subprocess.check_call(cmd)
+    with open(STAMP, "w") as f:
+        f.write(source_digest() + "\n")
     return lib
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True, experiments="--experiments" in sys.argv))
+    print(build(force="--force" in sys.argv, verbose=True))

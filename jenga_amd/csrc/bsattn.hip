@@ -422,10 +422,6 @@ __device__ __forceinline__ void attn_block(const AttnParams& P, unsigned char* s
     }
 }
 
-#ifdef JENGA_EXPERIMENTS
-#include "experiments/bsattn_pp.inc"   // the 8-wave ping-pong variant (JENGA_ATTN_PINGPONG): measured, not a product kernel
-#endif
-
 template <typename T>
 __global__ void __launch_bounds__(256, 2) bsattn_fwd_kernel(AttnParams P) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -524,39 +520,13 @@ extern "C" int jenga_bsattn_fwd(void* stream, const void* q, const void* k, cons
         return JENGA_EINVAL;
     }
     hipError_t e;
-#ifdef JENGA_EXPERIMENTS
-    if (flags & JENGA_ATTN_PINGPONG) {
-        const size_t smem_pp = PP_LDS_BYTES;
-        // (set on every call: cheap, and correct on whichever device / context is current)
-        (void)hipFuncSetAttribute((const void*)bsattn_pp_kernel<BF16>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)smem_pp);
-        (void)hipFuncSetAttribute((const void*)bsattn_pp_kernel<FP16>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)smem_pp);
-        if (dtype == JENGA_BF16)
-            hipLaunchKernelGGL(bsattn_pp_kernel<BF16>, dim3((unsigned)grid), dim3(512), smem_pp, (hipStream_t)stream, P);
-        else
-            hipLaunchKernelGGL(bsattn_pp_kernel<FP16>, dim3((unsigned)grid), dim3(512), smem_pp, (hipStream_t)stream, P);
-        e = hipGetLastError();
-        if (e != hipSuccess) {
-            set_error("jenga_bsattn_fwd (pingpong): %s", hipGetErrorString(e));
-            return JENGA_ELAUNCH;
-        }
-        return JENGA_OK;
-    }
-#else
-    if (flags & JENGA_ATTN_PINGPONG) {
-        set_error("jenga_bsattn_fwd: the ping-pong kernel is an experiment (build with JENGA_EXPERIMENTS)");
-        return JENGA_EUNSUPPORTED;
-    }
-#endif
     const size_t smem = W4_LDS_BYTES;
+    static bool smem_set[2][64] = {};
     if (dtype == JENGA_BF16) {
-        (void)hipFuncSetAttribute((const void*)bsattn_fwd_kernel<BF16>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)smem);
+        lp_set_smem_once((const void*)bsattn_fwd_kernel<BF16>, (int)smem, smem_set[0]);
         hipLaunchKernelGGL(bsattn_fwd_kernel<BF16>, dim3((unsigned)grid), dim3(256), smem, (hipStream_t)stream, P);
     } else {
-        (void)hipFuncSetAttribute((const void*)bsattn_fwd_kernel<FP16>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)smem);
+        lp_set_smem_once((const void*)bsattn_fwd_kernel<FP16>, (int)smem, smem_set[1]);
         hipLaunchKernelGGL(bsattn_fwd_kernel<FP16>, dim3((unsigned)grid), dim3(256), smem, (hipStream_t)stream, P);
     }
     e = hipGetLastError();

@@ -32,22 +32,19 @@
 // (profiles/r02_pmc_bsattn_lp*.json).  The first step, the < 6 remainder steps, the tail blocks that need text_amp or
 // the kv-length mask, and the text rows use the generic forms (LP_STEP, lp_slow_tile).
 //
-// Launch modes (round 4; instantiations of one kernel template, see bsattn_lp_kernel): the static mapping of query blocks
-// to workgroups (round 3's launch; what a capturing stream gets), the BALANCED launch (default: workgroups draw their query
-// block from per-XCD queues -- the XCDs of a chip run 3-8 % apart), the rotated list walk on a clock cursor (opt-in, not
-// bit-reproducible) on either mapping, and the dense cross-attention of the Wan blocks.  Two rules that the measurements
-// behind them produced, both checked by tests/test_isa_cpu.py:
+// Launch modes (instantiations of one kernel template, see bsattn_lp_kernel): the static mapping of query blocks to
+// workgroups (what a capturing stream gets), the BALANCED launch (default: workgroups draw their query block from per-XCD
+// queues -- the XCDs of a chip run 3-8 % apart; bit-identical to the static mapping) and the dense cross-attention of the Wan
+// blocks.  Two rules that the measurements behind them produced, both checked by tests/test_isa_cpu.py:
 //   * the kernel sits at 256 VGPRs; anything compiled into the static instantiation moves spill reloads into the unrolled
 //     main loop -- new modes are new instantiations;
 //   * nothing the compiler can take for a store (an atomic, s_sleep, s_memrealtime) in front of the main loop: the uniform
 //     loads behind it stop being scalar loads, a DMA offset goes to scratch, and every reload drains the DMA queue.
+// The launch-order experiments of rounds 3-4 (cohort start barrier, rotated list walk on a clock cursor and its replay /
+// position modes) are measured, recorded in profiles/r04_attn_*.json and DESIGN.md, and gone from the source (git 882bacf).
 #include <cstdlib>
-#include <cstdio>
-#include <cstring>
-#include <mutex>
-#include <string>
-#include <vector>
 
+#include "lp_balance.h"
 #include "lp_core.h"
 
 namespace jenga {
@@ -76,33 +73,10 @@ struct LpParams {
     int bal_set;     // JENGA_ATTN_BALANCE: which of the LP_BAL_SETS ticket-counter sets this launch draws from
 };
 
-// LP_EXP: the measured-and-rejected launch modes (cohort start barrier; position / replay modes of the rotated walk;
-// per-workgroup tick dump) are compiled into libjenga_amd_exp.so only (python -m jenga_amd.build --experiments)
-#ifdef JENGA_EXPERIMENTS
-#define LP_EXP 1
-#else
-#define LP_EXP 0
-#endif
-#if LP_EXP
-#define LP_ROT_REPLAY (-1000000000)   // rot_period value selecting the replay branch
-__device__ unsigned short* g_rot_table;   // JENGA_ROTATE_REPLAY: one start phase (16-bit fraction of a turn) per image workgroup
-__device__ unsigned* g_rot_times;          // record mode: [start, end] wall-clock ticks (low 32 bits) per launch position
-__device__ int g_rot_table_mode;          // 0 off, 1 record (clock mode writes the phase it used), 2 replay (read instead of the clock)
-__device__ float g_rot_spread = 0.42f;  // JENGA_ATTN_ROTATE position mode: growth of the start-time spread per sqrt(generation)
-#endif
-
 // XKV: the cross-attention instantiation (TEXT rows against a kv sequence whose last tile may be ragged); a template
 // parameter so that the product kernel's code (and its register allocation) is exactly what it is without that path
-// ROT (round 4, JENGA_ATTN_ROTATE; 2 = clock mode, 1 = clock / replay / position modes in the experiments library -- a separate
-// instantiation: the balanced launch's main loop keeps its DMA offsets in registers only without the other modes' code): the fast part of the ascending list is walked from a ROTATED start --
-// logical entry j < n_rot is physical entry (j + rot) mod n_rot, rot = phase of a chip-wide wall-clock cursor x n_rot -- so
-// that workgroups started at different times are at the same kv blocks at the same time WITHOUT waiting for each other.
-// The summation order of the online softmax then depends on the start time: results are equal within fp32 rounding of
-// the running sums, not bit-identical from run to run.  rot_period: the cursor's period in wall-clock ticks.
-template <typename T, bool TEXT, bool XKV = false, int ROT = 0>
-__device__ __forceinline__ void attn_block_lp(const LpParams& P, unsigned char* smem, int b, int h, int m,
-                                              int rot_period = 0, int rot_seq = 0) {
-    (void)rot_seq;      // (the experiments library's position / replay modes index by it)
+template <typename T, bool TEXT, bool XKV = false>
+__device__ __forceinline__ void attn_block_lp(const LpParams& P, unsigned char* smem, int b, int h, int m) {
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -171,20 +145,12 @@ __device__ __forceinline__ void attn_block_lp(const LpParams& P, unsigned char* 
 
     // kept list, 64 entries at a time in one VGPR (bsattn.hip)
     int lchunk = 0, lbase = -64;
-    int rot = 0, n_rot = 0;
-    auto phys = [&](int j) -> int {
-        if (!ROT || j >= n_rot) return j;
-        const int p_ = j + rot;
-        return p_ >= n_rot ? p_ - n_rot : p_;
-    };
     auto blk_at = [&](int i) -> int {
         if (i >= nkept) i = nkept - 1;   // the last steps stage one (unused) tile more: same piece count every step
         if (TEXT) return i;
         if (i < lbase || i >= lbase + 64) {
             lbase = i & ~63;
-            // (ROT: the window lives in LOGICAL index space, every lane fetches its own physical entry -- the rotation's
-            // wrap point needs no special case anywhere else)
-            lchunk = (lbase + lane < nkept) ? list[phys(lbase + lane)] : 0;
+            lchunk = (lbase + lane < nkept) ? list[lbase + lane] : 0;
             // wait HERE for the (rare) reload: at the join in front of v_readlane hipcc's vmcnt(0) runs every step and
             // drains the whole LDS-DMA prefetch (the hardware counter includes the asm loads)
             __builtin_amdgcn_s_waitcnt(0x0F70);
@@ -214,7 +180,7 @@ __device__ __forceinline__ void attn_block_lp(const LpParams& P, unsigned char* 
         const int first = t >> 1, last = (t + 7) >> 1;
         if (first < lbase || last >= lbase + 64) {
             lbase = first;
-            lchunk = (lbase + lane < nkept) ? list[phys(lbase + lane)] : 0;
+            lchunk = (lbase + lane < nkept) ? list[lbase + lane] : 0;
             __builtin_amdgcn_s_waitcnt(0x0F70);
         }
     };
@@ -263,47 +229,6 @@ __device__ __forceinline__ void attn_block_lp(const LpParams& P, unsigned char* 
         while (t_all > 0 && blk_at((t_all - 1) >> 1) * 128 + ((t_all - 1) & 1) * 64 >= seqlen) --t_all;
     }
     int t_fast = 2 * n_fast < t_all ? 2 * n_fast : t_all;
-    if (ROT && n_fast > 1 && rot_period > 0) {
-        // clock mode: one clock reading for the whole workgroup (its four waves share the tile order)
-        if (tid == 0) {
-            const unsigned long long c = (unsigned long long)wall_clock64() % (unsigned long long)rot_period;
-            *reinterpret_cast<int*>(smem) = (int)((c * (unsigned long long)n_fast) / (unsigned long long)rot_period);
-#if LP_EXP
-            if (ROT == 1 && g_rot_table_mode == 1)      // record: the phase this workgroup started at (rot_seq = its launch position)
-                g_rot_table[rot_seq] = (unsigned short)((c << 16) / (unsigned long long)rot_period);
-#endif
-        }
-        __syncthreads();
-        rot = __builtin_amdgcn_readfirstlane(*reinterpret_cast<const int*>(smem));
-        n_rot = n_fast;
-        lbase = -64;          // (the window holds unrotated entries from the tail scan)
-        __syncthreads();
-#if LP_EXP
-    } else if (ROT == 1 && n_fast > 1 && rot_period == LP_ROT_REPLAY) {
-        // replay (deterministic): the start phase a clock-mode launch of this shape recorded for this launch position
-        rot = (int)(((unsigned)g_rot_table[rot_seq] * (unsigned)n_fast) >> 16);
-        n_rot = n_fast;
-        lbase = -64;
-    } else if (ROT == 1 && n_fast > 1 && rot_period < 0) {
-        // position mode (deterministic): in the steady state an XCD starts S = -rot_period workgroups per mean workgroup
-        // lifetime (work conservation: its S slots are always full), so the rot_seq-th workgroup of the XCD's queue starts
-        // at cursor phase frac(rot_seq / S) -- no clock, no period to know
-        const int S = -rot_period;
-        // ... once the starts are staggered.  A launch begins with all S slots starting TOGETHER (true phase 0 for all of
-        // them); the stagger then grows generation by generation as lifetimes vary (a random walk per slot: the width of
-        // the start-time spread after g generations is ~ spread * sqrt(g) of a lifetime, capped at one lifetime).  The
-        // k-th workgroup to start in generation g therefore sits at phase (k / S - 1/2) * min(1, spread * sqrt(g)).
-        const int g = rot_seq / S, k = rot_seq % S;
-        float w = g_rot_spread * __builtin_sqrtf((float)g);
-        w = w > 1.f ? 1.f : w;
-        float ph = ((float)k / (float)S - 0.5f) * w;
-        ph -= __builtin_floorf(ph);
-        rot = (int)(ph * (float)n_fast);
-        rot = rot >= n_fast ? n_fast - 1 : rot;
-        n_rot = n_fast;
-        lbase = -64;
-#endif
-    }
     if (XKV && P.text_kv_len > 0) {     // cross-attention: whole tiles in the pipeline, the ragged one in the slow form
         t_all = (P.text_kv_len + 63) >> 6;
         t_fast = P.text_kv_len >> 6;
@@ -408,101 +333,10 @@ __device__ __forceinline__ void attn_block_lp(const LpParams& P, unsigned char* 
     }
 }
 
-#if LP_EXP
-// JENGA_ATTN_COHORT (round-4 experiment): the workgroups an XCD runs at a time start TOGETHER -- one arrival counter per
-// XCD and per generation of `size` consecutive launch positions, bounded spin -- so that they walk their ascending lists
-// in step and meet in the XCD's L2.  The configuration lives in a device global written on the launch stream, NOT in
-// LpParams: the kernel sits at 256 VGPRs and a longer kernarg block moves spill reloads into the unrolled main loop.
-struct CohortCfg {
-    int* ctr;
-    int size, stride, timeout;   // timeout in wall-clock ticks (100 MHz)
-    int quorum;                  // arrivals a member waits for (<= size): the stragglers of a generation start late
-};
-__device__ CohortCfg g_cohort_cfg;
-#endif
-__device__ int g_rot_period_ticks;      // JENGA_ATTN_ROTATE: the cursor's period (wall-clock ticks, 100 MHz)
-#define LP_BAL_SETS 64
-__device__ int g_balance_ctr[LP_BAL_SETS][8];   // JENGA_ATTN_BALANCE: tickets drawn from each XCD's queue, one set per launch in
-                                               // flight (the launcher hands the sets out in turn and zeroes one on the stream)
-__device__ int g_rot_T_est = 87500;     // lifetime of the image workgroup that finished last (ticks): the NEXT launch's period
-                                        // in auto mode (copied device-to-device on the launch stream; 875 us to begin with)
-
-// instrumentation (experiments library, JENGA_LP_TIMES_DUMP): [start, end] of every image workgroup of the rotated variants
-__device__ __forceinline__ void lp_record_times(int li, long long t_start, long long t_end) {
-#if LP_EXP
-    unsigned* tm = g_rot_times;
-    if (tm) {
-        tm[2 * li] = (unsigned)t_start;
-        tm[2 * li + 1] = (unsigned)t_end;
-    }
-#else
-    (void)li; (void)t_start; (void)t_end;
-#endif
-}
-
-// JENGA_ATTN_BALANCE: thread 0 draws (queue y, ticket t) -- own queue first, then the fullest other one, at most 8 attempts --
-// and the workgroup gets it through LDS as (y << 28 | t), or -1 when every queue is empty.
-// The counter accesses are inline assembly WITHOUT a memory clobber, on purpose: an atomic the compiler can see counts as a
-// possible write to everything the kernel loads afterwards, its uniform loads (launch order, kept count, sequence length,
-// the list window) stop being scalar loads and come back through VGPRs, and with 256 VGPRs in use that costs the main loop
-// one or two of its DMA offsets -- reloaded from scratch three times per 12 steps, each reload draining the DMA queue
-// (measured: -2.8 % before any balancing gain).  Nothing else in the kernel reads or writes the counters.
-typedef int lp_int4 __attribute__((ext_vector_type(4)));
-// (not `volatile`, no memory clobber: to the compiler these are pure functions of their operands -- `seq` differs between
-// any two calls of a workgroup so that they are never merged)
-__device__ __forceinline__ int lp_ticket_add(int* p, int seq) {   // p: wave-uniform
-    int old;
-    const unsigned zero = 0;
-    const int one = 1;
-    asm("global_atomic_add %0, %1, %2, %3 sc0\n\ts_waitcnt vmcnt(0) ; draw %4" : "=v"(old) : "v"(zero), "v"(one), "s"(p), "s"(seq));
-    return old;
-}
-__device__ __forceinline__ int lp_draw_ticket(int* ctr, int BH, int nq_img, int xcd_chunk, int x, int* lds) {
-    if (threadIdx.x == 0) {
-        auto qlen = [&](int z) {
-            int nv = nq_img - z * xcd_chunk;
-            nv = nv < xcd_chunk ? nv : xcd_chunk;
-            return nv > 0 ? BH * nv : 0;
-        };
-        int y = x, t = qlen(x);
-        if (t > 0) t = lp_ticket_add(ctr + x, -1);
-        if (t >= qlen(x)) {
-            y = -1;
-#pragma nounroll
-            for (int attempt = 0; attempt < 8 && y < 0; ++attempt) {
-                lp_int4 c0, c1;
-                const unsigned zero = 0;
-                asm("global_load_dwordx4 %0, %2, %3 sc1\n\tglobal_load_dwordx4 %1, %2, %3 offset:16 sc1\n\t"
-                    "s_waitcnt vmcnt(0) ; scan %4"
-                    : "=&v"(c0), "=&v"(c1)
-                    : "v"(zero), "s"(ctr), "s"(attempt));
-                const int drawn[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
-                int best = -1, left = 0;
-#pragma unroll
-                for (int z = 0; z < 8; ++z) {
-                    const int l = qlen(z) - drawn[z];
-                    if (l > left) { left = l; best = z; }
-                }
-                if (best < 0) break;
-                best = __builtin_amdgcn_readfirstlane(best);     // (one lane is active: its value, in an SGPR for the asm)
-                const int tt = lp_ticket_add(ctr + best, attempt);
-                if (tt < qlen(best)) { y = best; t = tt; }
-            }
-        }
-        lds[0] = y < 0 ? -1 : (y << 28 | t);
-    }
-    __syncthreads();
-    const int ticket = __builtin_amdgcn_readfirstlane(lds[0]);
-    __syncthreads();
-    return ticket;
-}
-
 #define LP_THREADS 256
-// VARIANT 0: the product kernel.  1: + the cohort start barrier.  2: dense cross-attention (jenga_cross_attn_fwd):
-// TEXT-mode rows only, kv-length mask on the last tile.  3: rotated list walk (JENGA_ATTN_ROTATE).  4: query blocks drawn
-// from per-XCD queues (JENGA_ATTN_BALANCE).  5: 4 + 3.  6 (experiments library): 4 + 1.  Separate instantiations on purpose (see above).  (Two more were measured and removed: rotation + pacing -- a workgroup ahead of the
-// cursor sleeps -- lost 10 %; rotation + whole heads per XCD got the L2 hit rate to 47 % and 35.5 KB per kept pair but ran
-// 2 % behind plain rotation: eight heads in flight overflow the Infinity Cache.  profiles/r04_attn_rotate_ab.json.)
+// VARIANT 0: the product kernel, static mapping.  2: dense cross-attention (jenga_cross_attn_fwd): TEXT-mode rows only,
+// kv-length mask on the last tile.  4: query blocks drawn from per-XCD queues (JENGA_ATTN_BALANCE, lp_balance.h).  Separate
+// instantiations on purpose (see the header).  (Variants 1, 3, 5, 6 were the launch-order experiments of round 4.)
 template <typename T, int VARIANT>
 __global__ void __launch_bounds__(LP_THREADS, 2) bsattn_lp_kernel(LpParams P) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -517,16 +351,9 @@ __global__ void __launch_bounds__(LP_THREADS, 2) bsattn_lp_kernel(LpParams P) {
     }
     if (VARIANT == 2) return;
     int li = id - P.n_text_wg_pad;
-    int bal_seq = 0, bal_total = 0;
-    if (VARIANT == 4 || VARIANT == 5 || VARIANT == 6) {
-        // cross-XCD balancing: the hardware deals workgroup ids to the 8 XCDs round robin, so with one workgroup per query
-        // block every XCD gets the same number of blocks whatever its speed -- and the XCDs of one chip differ by several
-        // per cent.  Here a workgroup DRAWS its query block: a ticket from the queue of the XCD it runs on (the same
-        // contiguous range, the same order as the static mapping), and once that queue is empty from the queue with the
-        // most blocks left.  The grid is oversubscribed (the launcher adds 1/8) so that a fast XCD has workgroups left
-        // to draw with; a workgroup that finds every queue empty exits.  Which workgroup computes a block does not enter
-        // the result: bit-identical to the static mapping.  The ticket becomes the launch position the static mapping
-        // would have given that block, and the code below runs unchanged.
+    if (VARIANT == 4) {
+        // the ticket becomes the launch position the static mapping would have given that block, and the code below runs
+        // unchanged
         const int ticket = lp_draw_ticket(g_balance_ctr[P.bal_set], P.B * P.H, P.nq_img, P.xcd_chunk, li & 7,
                                           reinterpret_cast<int*>(smem));
         if (ticket < 0) return;
@@ -534,8 +361,6 @@ __global__ void __launch_bounds__(LP_THREADS, 2) bsattn_lp_kernel(LpParams P) {
         int nv = P.nq_img - y * P.xcd_chunk;
         nv = nv < P.xcd_chunk ? nv : P.xcd_chunk;
         li = __builtin_amdgcn_readfirstlane((t / nv) * P.img_per_head + (((t % nv) << 3) | y));
-        bal_seq = t;
-        bal_total = __builtin_amdgcn_readfirstlane(P.B * P.H * nv);
     }
     const int bh = li / P.img_per_head;
     const int r = li % P.img_per_head;
@@ -546,225 +371,17 @@ __global__ void __launch_bounds__(LP_THREADS, 2) bsattn_lp_kernel(LpParams P) {
     } else {
         m = r;
     }
-#if LP_EXP
-    if (VARIANT == 1 || VARIANT == 6) {      // (6: on drawn blocks -- the remapped launch position IS the queue position)
-        if (threadIdx.x == 0) {
-            const CohortCfg C = g_cohort_cfg;
-            const int x = r & 7, pos = r >> 3;
-            // a workgroup that drew from another XCD's queue shares no L2 with that cohort: it reports in and does not wait
-            const bool guest = VARIANT == 6 && (((int)blockIdx.x - P.n_text_wg_pad) & 7) != x;
-            int nv = P.nq_img - x * P.xcd_chunk;                 // valid launch positions of this XCD per (b, h)
-            nv = nv < P.xcd_chunk ? nv : P.xcd_chunk;
-            const int seq = bh * nv + pos, total = P.B * P.H * nv;
-            const int gen = seq / C.size;
-            int members = total - gen * C.size;
-            members = members < C.size ? members : C.size;
-            members = members < C.quorum ? members : C.quorum;
-            int* c = C.ctr + x * C.stride + gen;
-            {   // (one lane is active: its pointer, in SGPRs for the asm operands)
-                const unsigned long long cv = (unsigned long long)c;
-                const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)cv);
-                const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(cv >> 32));
-                c = reinterpret_cast<int*>(((unsigned long long)hi << 32) | lo);
-            }
-            // (opaque accesses like the ticket code's: with the compiler's own atomics this variant's main loop reloaded
-            // DMA offsets from scratch -- part of the loss recorded for it in profiles/r04_attn_cohort_ab.json)
-            int arrived = lp_ticket_add(c, -2) + 1;
-            auto now = [](int seq) {      // (s_memrealtime as a pure function of `seq`: the builtin counts as a memory access)
-                unsigned long long t;
-                asm("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0) ; clock %1" : "=s"(t) : "s"(seq));
-                return (long long)t;
-            };
-            const long long t0 = now(-1);
-            int spin = 0;
-            while (!guest && arrived < members && now(spin) - t0 < C.timeout) {
-                const unsigned zero = 0;
-                asm("s_sleep 16\n\tglobal_load_dword %0, %1, %2 sc1\n\ts_waitcnt vmcnt(0) ; poll %3" : "=v"(arrived) : "v"(zero), "s"(c), "s"(spin));
-                ++spin;
-            }
-        }
-        __syncthreads();
-    }
-#endif
     if (P.order) m = P.order[(long long)bh * P.nq_img + m];   // kept-count-aware order inside the XCD's range
-    if (VARIANT == 3 || VARIANT == 5) {
-        int seq = li, seq_total = P.B * P.H * P.img_per_head;
-        if (VARIANT == 5) {
-            seq = bal_seq;
-            seq_total = bal_total;
-        } else if (P.xcd_chunk) {      // this workgroup's number in its XCD's queue (launch positions, before the count order)
-            int nv = P.nq_img - (r & 7) * P.xcd_chunk;
-            nv = nv < P.xcd_chunk ? nv : P.xcd_chunk;
-            seq = bh * nv + (r >> 3);
-            seq_total = P.B * P.H * nv;
-        }
-        const bool mid_queue = seq * 4 >= seq_total && seq * 4 < 3 * seq_total;
-        int period = g_rot_period_ticks;
-        if (period > 0) period = period < 5000 ? 5000 : (period > 1000000 ? 1000000 : period);   // 50 us .. 10 ms
-#if LP_EXP
-        if (VARIANT == 3) {
-            const int table_mode = g_rot_table_mode;
-            if (table_mode == 2) period = LP_ROT_REPLAY;
-            if (table_mode) seq = li;        // the table is indexed by launch position
-        }
-#endif
-        const long long t_start = (long long)wall_clock64();
-        attn_block_lp<T, false, false, (LP_EXP && VARIANT == 3) ? 1 : 2>(P, smem, bh / P.H, bh % P.H, m, period, seq);
-        // the next launch's period (auto mode): the lifetime of a workgroup from the MIDDLE of its XCD's queue -- the last
-        // ones run on a draining chip and are faster than the steady state the cursor has to match
-        if (threadIdx.x == 0) {
-            const long long t_end = (long long)wall_clock64();
-            if (mid_queue) g_rot_T_est = (int)(t_end - t_start);
-            lp_record_times((int)blockIdx.x - P.n_text_wg_pad, t_start, t_end);
-        }
-    } else
-        attn_block_lp<T, false>(P, smem, bh / P.H, bh % P.H, m);
+    attn_block_lp<T, false>(P, smem, bh / P.H, bh % P.H, m);
 }
 
 template <typename T, int VARIANT>
 static hipError_t lp_launch(const LpParams& P, long long grid, hipStream_t stream) {
-    const size_t smem = LP_LDS_BYTES;
-    (void)hipFuncSetAttribute((const void*)bsattn_lp_kernel<T, VARIANT>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)smem);
-    hipLaunchKernelGGL((bsattn_lp_kernel<T, VARIANT>), dim3((unsigned)grid), dim3(LP_THREADS), smem, stream, P);
+    static bool smem_set[64] = {};
+    lp_set_smem_once((const void*)bsattn_lp_kernel<T, VARIANT>, LP_LDS_BYTES, smem_set);
+    hipLaunchKernelGGL((bsattn_lp_kernel<T, VARIANT>), dim3((unsigned)grid), dim3(LP_THREADS), LP_LDS_BYTES, stream, P);
     return hipGetLastError();
 }
-
-// ---- host side of the experiment variants (state per device; launches carrying these flags must not overlap on one device)
-
-#if LP_EXP
-// JENGA_LP_TIMES_DUMP=<file>: the rotate / balance variants write [start, end] wall-clock ticks (100 MHz, low 32 bits) of
-// every image workgroup, indexed by launch position; the file holds the launch BEFORE the current one (written in front of
-// the next launch with the variable set, after a stream synchronisation) as raw uint32 pairs.
-void lp_times_hook(long long grid, hipStream_t stream) {
-    static unsigned* times[64] = {nullptr};
-    static long long times_n[64] = {0}, used_n[64] = {0};
-    static bool armed[64] = {false};     // the device global holds a buffer (it starts out null)
-    const char* file = getenv("JENGA_LP_TIMES_DUMP");
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return;
-    if (!file && !armed[dev]) return;
-    if (file && used_n[dev] > 0 && hipStreamSynchronize(stream) == hipSuccess) {
-        std::vector<unsigned> h((size_t)used_n[dev] * 2, 0);
-        if (hipMemcpy(h.data(), times[dev], h.size() * sizeof(unsigned), hipMemcpyDeviceToHost) == hipSuccess)
-            if (FILE* f = fopen(file, "wb")) {
-                fwrite(h.data(), sizeof(unsigned), h.size(), f);
-                fclose(f);
-            }
-    }
-    used_n[dev] = 0;
-    unsigned* ptr = nullptr;
-    if (file) {
-        if (times_n[dev] < grid) {
-            if (times[dev]) (void)hipFree(times[dev]);
-            times[dev] = nullptr;
-            times_n[dev] = hipMalloc((void**)&times[dev], (size_t)grid * 2 * sizeof(unsigned)) == hipSuccess ? grid : 0;
-        }
-        if (times_n[dev] >= grid && hipMemsetAsync(times[dev], 0, (size_t)grid * 2 * sizeof(unsigned), stream) == hipSuccess) {
-            ptr = times[dev];
-            used_n[dev] = grid;
-        }
-    }
-    (void)hipMemcpyToSymbolAsync(HIP_SYMBOL(g_rot_times), &ptr, sizeof(ptr), 0, hipMemcpyHostToDevice, stream);
-    armed[dev] = ptr != nullptr;
-}
-#endif
-
-// JENGA_ATTN_BALANCE: the ticket counters of a launch.  LP_BAL_SETS sets per device, handed out in turn under a mutex (ranks
-// simulated by threads launch concurrently on one device); a set is zeroed on the launch stream in front of the kernel, and
-// an event recorded behind the kernel makes the NEXT user of the set -- LP_BAL_SETS launches later, possibly on another
-// stream -- wait for it, so two launches in flight never share counters.  (A capturing stream never gets here: the launcher
-// drops the flag, an event recorded inside a capture cannot order a set against launches outside.)
-struct LpBalanceSlots {
-    std::mutex mu;
-    int* base = nullptr;
-    hipEvent_t done[LP_BAL_SETS] = {};
-    bool used[LP_BAL_SETS] = {};
-    bool busy[LP_BAL_SETS] = {};
-    unsigned next = 0;
-};
-LpBalanceSlots g_bal[64];
-
-int lp_balance_acquire(hipStream_t stream) {
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return -1;
-    LpBalanceSlots& S = g_bal[dev];
-    std::lock_guard<std::mutex> lock(S.mu);
-    if (!S.base && hipGetSymbolAddress((void**)&S.base, HIP_SYMBOL(g_balance_ctr)) != hipSuccess) {
-        S.base = nullptr;
-        return -1;
-    }
-    int k = -1;
-    for (int tries = 0; tries < LP_BAL_SETS && k < 0; ++tries) {     // (a set between acquire and release belongs to another thread)
-        const int c = (int)(S.next++ % LP_BAL_SETS);
-        if (!S.busy[c]) k = c;
-    }
-    if (k < 0) return -1;
-    if (!S.done[k] && hipEventCreateWithFlags(&S.done[k], hipEventDisableTiming) != hipSuccess) {
-        S.done[k] = nullptr;
-        return -1;
-    }
-    if (S.used[k] && hipStreamWaitEvent(stream, S.done[k], 0) != hipSuccess) return -1;
-    if (hipMemsetAsync(S.base + 8 * k, 0, 8 * sizeof(int), stream) != hipSuccess) return -1;
-    S.busy[k] = true;
-    return k;
-}
-
-void lp_balance_release(int k, hipStream_t stream) {
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return;
-    LpBalanceSlots& S = g_bal[dev];
-    std::lock_guard<std::mutex> lock(S.mu);
-    S.used[k] = hipEventRecord(S.done[k], stream) == hipSuccess;
-    if (!S.used[k]) (void)hipStreamSynchronize(stream);   // (no event: the set must be idle before anybody reuses it)
-    S.busy[k] = false;
-}
-
-#if LP_EXP
-// JENGA_ROTATE_REPLAY=record|replay: a clock-mode launch writes every workgroup's start phase to a per-device table
-// (16-bit fraction of a turn per launch position); later launches of the same grid read it instead of the clock --
-// deterministic given the table.  JENGA_ROTATE_TABLE_DUMP=<file> writes the table in front of every replay launch,
-// JENGA_ROTATE_TABLE_LOAD=<file> reads it from a file (once per grid size).
-void lp_replay_table(long long grid, hipStream_t stream) {
-    static unsigned short* table[64] = {nullptr};
-    static long long table_n[64] = {0}, loaded_n[64] = {0};
-    int dev = 0, mode = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return;
-    if (const char* ev = getenv("JENGA_ROTATE_REPLAY")) mode = !strcmp(ev, "record") ? 1 : (!strcmp(ev, "replay") ? 2 : 0);
-    if (mode && table_n[dev] < grid) {
-        if (table[dev]) (void)hipFree(table[dev]);
-        table[dev] = nullptr;
-        table_n[dev] = 0;
-        if (hipMalloc((void**)&table[dev], (size_t)grid * sizeof(unsigned short)) == hipSuccess &&
-            hipMemsetAsync(table[dev], 0, (size_t)grid * sizeof(unsigned short), stream) == hipSuccess)
-            table_n[dev] = grid;
-        (void)hipMemcpyToSymbolAsync(HIP_SYMBOL(g_rot_table), &table[dev], sizeof(table[dev]), 0, hipMemcpyHostToDevice,
-                                     stream);
-    }
-    if (mode && !table_n[dev]) mode = 0;
-    if (mode == 2 && getenv("JENGA_ROTATE_TABLE_LOAD") && loaded_n[dev] != grid) {
-        if (FILE* f = fopen(getenv("JENGA_ROTATE_TABLE_LOAD"), "rb")) {
-            std::vector<unsigned short> h((size_t)grid, 0);
-            const size_t got = fread(h.data(), sizeof(unsigned short), (size_t)grid, f);
-            fclose(f);
-            if (got == (size_t)grid && hipStreamSynchronize(stream) == hipSuccess &&
-                hipMemcpy(table[dev], h.data(), (size_t)grid * 2, hipMemcpyHostToDevice) == hipSuccess)
-                loaded_n[dev] = grid;
-        }
-        if (loaded_n[dev] != grid) mode = 0;
-    }
-    if (mode == 2 && getenv("JENGA_ROTATE_TABLE_DUMP")) {
-        std::vector<unsigned short> h((size_t)grid, 0);
-        if (hipStreamSynchronize(stream) == hipSuccess &&
-            hipMemcpy(h.data(), table[dev], (size_t)grid * 2, hipMemcpyDeviceToHost) == hipSuccess)
-            if (FILE* f = fopen(getenv("JENGA_ROTATE_TABLE_DUMP"), "wb")) {
-                fwrite(h.data(), sizeof(unsigned short), (size_t)grid, f);
-                fclose(f);
-            }
-    }
-    (void)hipMemcpyToSymbolAsync(HIP_SYMBOL(g_rot_table_mode), &mode, sizeof(int), 0, hipMemcpyHostToDevice, stream);
-}
-#endif
 
 }  // namespace
 }  // namespace jenga
@@ -816,97 +433,24 @@ int jenga_bsattn_lp_launch(void* stream, const void* q, const void* k, const voi
         set_error("jenga_bsattn_fwd: grid size %lld out of range", grid);
         return JENGA_EINVAL;
     }
-    // the launch modes below keep per-device state that is written on the launch stream from host variables or ordered by
-    // events: none of that can be recorded into a HIP graph, so a capturing stream gets the plain static launch
-    if (flags & (JENGA_ATTN_COHORT | JENGA_ATTN_ROTATE | JENGA_ATTN_BALANCE)) {
+    // the balanced launch keeps per-device state that is ordered by events: that cannot be recorded into a HIP graph, so a
+    // capturing stream gets the plain static launch
+    if (flags & JENGA_ATTN_BALANCE) {
         hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
         if (hipStreamIsCapturing((hipStream_t)stream, &cap) != hipSuccess) {
             (void)hipGetLastError();      // (the query itself failed: not this launch's error)
             cap = hipStreamCaptureStatusActive;
         }
-        if (cap != hipStreamCaptureStatusNone) flags &= ~(JENGA_ATTN_COHORT | JENGA_ATTN_ROTATE | JENGA_ATTN_BALANCE);
+        if (cap != hipStreamCaptureStatusNone) flags &= ~JENGA_ATTN_BALANCE;
     }
-    bool cohort = false;
-#if !LP_EXP
-    if (flags & JENGA_ATTN_COHORT) {
-        set_error("jenga_bsattn_fwd: the cohort start barrier is an experiment (build with JENGA_EXPERIMENTS)");
-        return JENGA_EUNSUPPORTED;
-    }
-#else
-    if ((flags & JENGA_ATTN_COHORT) && P.xcd_chunk) {
-        // EXPERIMENT: one lazily allocated counter block per device, zeroed on the launch stream in front of every launch,
-        // the configuration written to the device global the same way -- launches with this flag must not overlap on one
-        // device
-        static int* ctr[64] = {nullptr};
-        constexpr int STRIDE = 4096;
-        int dev = 0;
-        (void)hipGetDevice(&dev);
-        int size = 64, timeout_us = 300;
-        if (const char* ev = getenv("JENGA_COHORT_SIZE")) size = atoi(ev);
-        if (const char* ev = getenv("JENGA_COHORT_TIMEOUT_US")) timeout_us = atoi(ev);
-        int quorum = size;
-        if (const char* ev = getenv("JENGA_COHORT_QUORUM")) quorum = atoi(ev);
-        if (quorum < 1 || quorum > size) quorum = size;
-        const long long gens = size > 0 ? (B * H * (long long)P.xcd_chunk + size - 1) / size : STRIDE;
-        if (dev >= 0 && dev < 64 && size > 0 && gens < STRIDE) {
-            if (!ctr[dev] && hipMalloc((void**)&ctr[dev], 8 * STRIDE * sizeof(int)) != hipSuccess) ctr[dev] = nullptr;
-            CohortCfg cfg{ctr[dev], size, STRIDE, timeout_us * 100, quorum};
-            if (ctr[dev] && hipMemsetAsync(ctr[dev], 0, 8 * STRIDE * sizeof(int), (hipStream_t)stream) == hipSuccess &&
-                hipMemcpyToSymbolAsync(HIP_SYMBOL(g_cohort_cfg), &cfg, sizeof(cfg), 0, hipMemcpyHostToDevice,
-                                       (hipStream_t)stream) == hipSuccess)
-                cohort = true;
-        }
-    }
-#endif
-    int rot_ticks = 0;
-    if ((flags & JENGA_ATTN_ROTATE) && !cohort) {
-        // period of the cursor: JENGA_ROTATE_PERIOD_US=<microseconds>, or (default, "auto") the lifetime of a mid-queue image
-        // workgroup of the previous launch with this flag -- copied device to device on the launch stream, so one launch
-        // sees one period and no host synchronisation is involved
-        int us = 0;
-        if (const char* ev = getenv("JENGA_ROTATE_PERIOD_US")) us = atoi(ev);
-        rot_ticks = us > 0 ? us * 100 : 1;
-        bool auto_period = us <= 0;
-#if LP_EXP
-        // JENGA_ROTATE_SLOTS=S: position mode with S workgroups resident per XCD (64 = 32 CUs x 2); deterministic
-        if (const char* ev = getenv("JENGA_ROTATE_SLOTS")) {
-            const int slots = atoi(ev);
-            if (slots > 0) rot_ticks = -slots;
-            float spread = 0.42f;
-            if (const char* es = getenv("JENGA_ROTATE_SPREAD")) spread = (float)atof(es);
-            (void)hipMemcpyToSymbolAsync(HIP_SYMBOL(g_rot_spread), &spread, sizeof(float), 0, hipMemcpyHostToDevice,
-                                         (hipStream_t)stream);
-        }
-        if (rot_ticks < 0) auto_period = false;
-        if (rot_ticks > 0) lp_replay_table(grid, (hipStream_t)stream);
-#endif
-        if (auto_period) {
-            void *dst = nullptr, *src = nullptr;
-            if (hipGetSymbolAddress(&dst, HIP_SYMBOL(g_rot_period_ticks)) != hipSuccess ||
-                hipGetSymbolAddress(&src, HIP_SYMBOL(g_rot_T_est)) != hipSuccess ||
-                hipMemcpyAsync(dst, src, sizeof(int), hipMemcpyDeviceToDevice, (hipStream_t)stream) != hipSuccess)
-                rot_ticks = 0;
-        } else if (rot_ticks != 0 && hipMemcpyToSymbolAsync(HIP_SYMBOL(g_rot_period_ticks), &rot_ticks, sizeof(int), 0,
-                                                           hipMemcpyHostToDevice, (hipStream_t)stream) != hipSuccess) {
-            rot_ticks = 0;
-        }
-    }
-    // JENGA_ATTN_BALANCE: query blocks drawn from per-XCD queues, grid oversubscribed by 1/8 (JENGA_BALANCE_EXTRA_PCT) so
-    // that a fast XCD has workgroups left to draw from a slow one's queue.  Position mode / replay of the rotated walk index
-    // by launch position and stay with the static mapping.
+    // JENGA_ATTN_BALANCE: query blocks drawn from per-XCD queues, grid oversubscribed by 1/8 (JENGA_BALANCE_EXTRA_PCT, at
+    // least 8 workgroups) so that a fast XCD has workgroups left to draw from a slow one's queue
     long long grid_bal = 0;
     int bal_slot = -1;
-    bool static_only = (cohort && !(flags & JENGA_ATTN_BALANCE)) || rot_ticks < 0 || (cohort && rot_ticks != 0);
-#if LP_EXP
-    static_only = static_only || getenv("JENGA_ROTATE_REPLAY") != nullptr;
-#endif
-    if ((flags & JENGA_ATTN_BALANCE) && P.xcd_chunk && !static_only && (P.n_text_wg_pad & 7) == 0 &&
-        (P.img_per_head & 7) == 0) {
-        int pct = 12;
-        if (const char* ev = getenv("JENGA_BALANCE_EXTRA_PCT")) pct = atoi(ev);
-        pct = pct < 0 ? 0 : (pct > 100 ? 100 : pct);
+    if ((flags & JENGA_ATTN_BALANCE) && P.xcd_chunk && (P.n_text_wg_pad & 7) == 0 && (P.img_per_head & 7) == 0) {
         const long long img = B * H * (long long)P.img_per_head;
-        const long long extra = ((img * pct / 100) + 7) & ~7LL;
+        long long extra = ((img * lp_balance_extra_pct() / 100) + 7) & ~7LL;
+        extra = extra < 8 ? 8 : extra;
         if (grid + extra <= 0x7fffffffLL && B * H * (long long)P.xcd_chunk < (1LL << 28)) {
             bal_slot = lp_balance_acquire((hipStream_t)stream);
             if (bal_slot >= 0) {
@@ -915,30 +459,10 @@ int jenga_bsattn_lp_launch(void* stream, const void* q, const void* k, const voi
             }
         }
     }
-#if LP_EXP
-    if (rot_ticks != 0 || grid_bal) lp_times_hook(grid_bal ? grid_bal : grid, (hipStream_t)stream);
-#endif
     hipError_t e;
-#if LP_EXP
-    if (grid_bal && cohort)
-        e = dtype == JENGA_BF16 ? lp_launch<BF16, 6>(P, grid_bal, (hipStream_t)stream)
-                                : lp_launch<FP16, 6>(P, grid_bal, (hipStream_t)stream);
-    else
-#endif
-    if (grid_bal && rot_ticks > 0)
-        e = dtype == JENGA_BF16 ? lp_launch<BF16, 5>(P, grid_bal, (hipStream_t)stream)
-                                : lp_launch<FP16, 5>(P, grid_bal, (hipStream_t)stream);
-    else if (grid_bal)
+    if (grid_bal)
         e = dtype == JENGA_BF16 ? lp_launch<BF16, 4>(P, grid_bal, (hipStream_t)stream)
                                 : lp_launch<FP16, 4>(P, grid_bal, (hipStream_t)stream);
-    else if (rot_ticks != 0)
-        e = dtype == JENGA_BF16 ? lp_launch<BF16, 3>(P, grid, (hipStream_t)stream)
-                                : lp_launch<FP16, 3>(P, grid, (hipStream_t)stream);
-#if LP_EXP
-    else if (cohort)
-        e = dtype == JENGA_BF16 ? lp_launch<BF16, 1>(P, grid, (hipStream_t)stream)
-                                : lp_launch<FP16, 1>(P, grid, (hipStream_t)stream);
-#endif
     else
         e = dtype == JENGA_BF16 ? lp_launch<BF16, 0>(P, grid, (hipStream_t)stream)
                                 : lp_launch<FP16, 0>(P, grid, (hipStream_t)stream);

@@ -3,6 +3,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <mutex>
+
 #include "../../include/jenga_amd.h"
 
 namespace jenga {
@@ -81,6 +83,18 @@ __host__ __device__ __forceinline__ int pv_key_of_pos(int p) {
 
 void set_error(const char* fmt, ...);
 
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per kernel instantiation and device: `done` is a static of the
+// instantiation's launch function
+inline void lp_set_smem_once(const void* kernel, int bytes, bool (&done)[64]) {
+    static std::mutex mu;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = -1;
+    std::lock_guard<std::mutex> lock(mu);
+    if (dev >= 0 && done[dev]) return;
+    if (hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess && dev >= 0)
+        done[dev] = true;
+}
+
 }  // namespace jenga
 
 // bsattn3.hip: the launcher behind jenga_bsattn_fwd(..., flags & JENGA_ATTN_LP); arguments already validated
@@ -89,11 +103,3 @@ int jenga_bsattn_lp_launch(void* stream, const void* q, const void* k, const voi
                            int64_t n_blocks, int64_t nq_img, int64_t q_sb, int64_t q_ss, int64_t q_sh, int64_t k_sb,
                            int64_t k_ss, int64_t k_sh, int64_t o_sb, int64_t o_ss, int64_t o_sh, float sm_scale,
                            float text_amp, int64_t text_block_start, int dtype, int flags);
-#ifdef JENGA_EXPERIMENTS
-// experiments/bsattn4.hip: the launcher behind jenga_bsattn_pair_fwd(..., flags & JENGA_ATTN_LP)
-int jenga_bsattn_lp2_launch(void* stream, const void* q, const void* k, const void* vt, void* o, const int32_t* seqlens,
-                           const int32_t* pidx, const int32_t* pcnt, int64_t B, int64_t H, int64_t n_blocks,
-                           int64_t nq_img, int64_t q_sb, int64_t q_ss, int64_t q_sh, int64_t k_sb, int64_t k_ss,
-                           int64_t k_sh, int64_t o_sb, int64_t o_ss, int64_t o_sh, float sm_scale, float text_amp,
-                           int64_t text_block_start, int dtype, int flags);
-#endif

@@ -1,5 +1,5 @@
-// Shared device code of the LP attention kernels (bsattn3.hip: one query block per 4-wave workgroup; bsattn4.hip: two
-// query blocks per 8-wave workgroup sharing staged tiles): LDS tile geometry, LDS-DMA helpers, the per-wave softmax
+// Shared device code of the LP attention kernels (bsattn3.hip: one query block per 4-wave workgroup, two workgroups per CU;
+// bsattn5.hip: a PAIR of query blocks per 4-wave workgroup, one workgroup per CU): LDS tile geometry, LDS-DMA helpers, the per-wave softmax
 // state, the exact (max-first) path, the 16-slot pipelined basic block lp_bb and the unpipelined tail tile.
 // See the header of bsattn3.hip for the design.
 #pragma once
@@ -18,7 +18,8 @@ template <typename T> __device__ __forceinline__ constexpr float lp_tiny();
 template <> __device__ __forceinline__ constexpr float lp_tiny<BF16>() { return 8.673617379884035e-19f; }   // 2^-60
 template <> __device__ __forceinline__ constexpr float lp_tiny<FP16>() { return 0.0625f; }                   // 2^-4
 
-// four 1-KiB LDS-DMA pieces of one tile (see bsattn2.hip: immediate offsets, piece i's lane offsets biased by -1024 i)
+// four 1-KiB LDS-DMA pieces of one tile (the instruction's immediate offset adds to BOTH addresses: piece i's lane offsets
+// are biased by -1024 i, so one M0 value serves the four pieces)
 __device__ __forceinline__ void lp_stage4(const void* base, unsigned lds, unsigned o0, unsigned o1, unsigned o2,
                                           unsigned o3) {
     asm volatile("s_mov_b32 m0, %0\n\t"
@@ -52,8 +53,89 @@ __device__ __forceinline__ void lp_stage1(const LpDma& d) {
 #define LP_WAIT_ALL() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
 #define LP_WAIT_KEEP4() asm volatile("s_waitcnt vmcnt(4)" ::: "memory")
 
+// QK^T MFMAs.  Default: the compiler's builtin.  With LP_QK_MFMA_ASM (the pair kernel, bsattn5.hip: one wave per SIMD, 512
+// registers) the instruction is written out with explicit register classes -- D / C (the scores) in architectural VGPRs, the
+// Q operand in the accumulator half of the register file: at that budget hipcc selects the "AGPR form" for every builtin
+// MFMA (scores land in AGPRs, one v_accvgpr_read per score in front of the softmax), rematerialises the -m~ C operand with 16
+// v_accvgpr_write per item and parks Q in AGPRs only to copy it back in front of every MFMA (4 v_accvgpr_read each).
+// hipcc's hazard recogniser does not look into asm statements; what covers each hazard is listed at lq_bb (bsattn5.hip).
+#ifndef LP_QK_MFMA_ASM
+#define LP_QK_MFMA_ASM 0
+#endif
+typedef unsigned lp_u32x4 __attribute__((ext_vector_type(4)));
+// a Q fragment (8 x 16 bit per lane).  asm form: a register TUPLE type that is handed to the asm statements as it is -- built
+// from a uint4 per use, its four dwords live wherever the allocator put them and are gathered into a fresh AGPR quad in front
+// of every MFMA
+#if LP_QK_MFMA_ASM
+typedef lp_u32x4 LpQ;
+#else
+typedef uint4 LpQ;
+#endif
+// d = a . b + c  (c another register tuple: the first MFMA of an item)
+template <typename T>
+__device__ __forceinline__ void lp_qk_first(f32x16& d, const uint4& a, const LpQ& b, const f32x16& c) {
+#if LP_QK_MFMA_ASM
+    const lp_u32x4 a4 = __builtin_bit_cast(lp_u32x4, a);
+    if constexpr (__is_same(T, BF16))
+        asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %3" : "=&v"(d) : "v"(a4), "a"(b), "v"(c));
+    else
+        asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %3" : "=&v"(d) : "v"(a4), "a"(b), "v"(c));
+#else
+    d = mfma32<T>(a, b, c);
+#endif
+}
+// d = a . b  (TEXT rows: no C operand)
+template <typename T>
+__device__ __forceinline__ void lp_qk_zero(f32x16& d, const uint4& a, const LpQ& b, const f32x16& zero16) {
+#if LP_QK_MFMA_ASM
+    (void)zero16;
+    const lp_u32x4 a4 = __builtin_bit_cast(lp_u32x4, a);
+    if constexpr (__is_same(T, BF16))
+        asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(d) : "v"(a4), "a"(b));
+    else
+        asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=&v"(d) : "v"(a4), "a"(b));
+#else
+    d = mfma32<T>(a, b, zero16);
+#endif
+}
+// d += a . b
+template <typename T>
+__device__ __forceinline__ void lp_qk_acc(f32x16& d, const uint4& a, const LpQ& b) {
+#if LP_QK_MFMA_ASM
+    const lp_u32x4 a4 = __builtin_bit_cast(lp_u32x4, a);
+    if constexpr (__is_same(T, BF16))
+        asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(d) : "v"(a4), "a"(b));
+    else
+        asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(d) : "v"(a4), "a"(b));
+#else
+    d = mfma32<T>(a, b, d);
+#endif
+}
+// (asm form) the scores of an item were written by MFMAs the compiler cannot see: before VALU code reads them with fewer
+// than two MFMA issue times in between (blocks without P.V MFMAs behind the QK^T ones)
+__device__ __forceinline__ void lp_qk_settle() {
+#if LP_QK_MFMA_ASM
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+#endif
+}
+// (asm form) behind VALU writes to a C operand (the exact path's new -m~) and in front of the next MFMA reading it
+__device__ __forceinline__ void lp_qk_c_written() {
+#if LP_QK_MFMA_ASM
+    asm volatile("s_nop 3" ::: "memory");
+#endif
+}
+// (asm form) keep the 16 copies of -m~ a register tuple of their own: seen as 16 equal values the tuple is rebuilt with 16
+// moves in front of every item
+__device__ __forceinline__ void lp_cinit_pin(f32x16& c) {
+#if LP_QK_MFMA_ASM
+    asm volatile("" : "+v"(c));
+#else
+    (void)c;
+#endif
+}
+
 struct LpState {
-    uint4 qf[8];
+    LpQ qf[8];
     f32x16 o[4];
     float l;       // whole-row running sum (identical in the two lanes that share a row)
     float neg_m;   // -m~
@@ -67,6 +149,58 @@ struct LpState {
 template <typename T, bool TEXT>
 __device__ __forceinline__ void lp_exact(LpState& st, const f32x16& s, uint4 (&pf)[2], float& psum, float qk_scale,
                                          f32x16* pend) {
+#if LP_QK_MFMA_ASM
+    // Same arithmetic as below, written for the 512-register kernel: (a) no value arrays (16 + 16 temporaries here pushed
+    // long-lived tuples -- the -m~ C operands -- out of the architectural VGPRs for the WHOLE main loop); (b) O lives in
+    // the accumulator registers and is rescaled IN PLACE there: written as plain `o *= f2`, hipcc keeps a rescaled copy in
+    // VGPRs and pays for it on the hot path (v_accvgpr moves at the join).
+    float tmax = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) tmax = fmaxf(tmax, TEXT ? s[r] * qk_scale + st.neg_m : s[r]);
+    tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+    const bool move = (tmax > 0.f) || (st.l + psum < lp_tiny<T>());
+    const float delta = (move && tmax > -1e30f) ? fmaxf(ceilf(tmax), -120.f) : 0.f;
+    const float f2 = __builtin_amdgcn_exp2f(-delta);
+    const float old_neg_m = st.neg_m;
+    st.neg_m -= delta;
+    st.l *= f2;
+    // s_nop: the last P.V MFMA of an accumulator may still be in flight, and nothing inside an asm statement is covered by
+    // the compiler's hazard recogniser; the s_nop behind the last write covers v_accvgpr_write -> MFMA srcC
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float t_;
+            asm volatile("v_accvgpr_read_b32 %1, %0\n\tv_mul_f32 %1, %1, %2\n\ts_nop 0\n\tv_accvgpr_write_b32 %0, %1"
+                         : "+a"(st.o[i][r]), "=&v"(t_)
+                         : "v"(f2));
+        }
+    asm volatile("s_nop 3" ::: "memory");
+    if (!TEXT) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) st.cinit[r] = st.neg_m;
+        lp_cinit_pin(st.cinit);
+        if (pend) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) (*pend)[r] -= delta;
+        }
+    }
+    psum = 0.f;
+    uint32_t w[8];
+#pragma unroll
+    for (int r = 0; r < 16; r += 2) {
+        const float e0 = __builtin_amdgcn_exp2f((TEXT ? s[r] * qk_scale + old_neg_m : s[r]) - delta);
+        const float e1 = __builtin_amdgcn_exp2f((TEXT ? s[r + 1] * qk_scale + old_neg_m : s[r + 1]) - delta);
+        psum += e0;
+        psum += e1;
+        w[r >> 1] = pack2<T>(e0, e1);
+    }
+    psum += __shfl_xor(psum, 32);
+    pf[0] = make_uint4(w[0], w[1], w[2], w[3]);
+    pf[1] = make_uint4(w[4], w[5], w[6], w[7]);
+    lp_qk_c_written();
+#else
     float v[16];
     float tmax = -INFINITY;
 #pragma unroll
@@ -87,6 +221,7 @@ __device__ __forceinline__ void lp_exact(LpState& st, const f32x16& s, uint4 (&p
     if (!TEXT) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) st.cinit[r] = st.neg_m;
+        lp_cinit_pin(st.cinit);
         if (pend) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) (*pend)[r] -= delta;
@@ -102,6 +237,7 @@ __device__ __forceinline__ void lp_exact(LpState& st, const f32x16& s, uint4 (&p
     psum += __shfl_xor(psum, 32);
     pf[0] = make_uint4(pack2<T>(e[0], e[1]), pack2<T>(e[2], e[3]), pack2<T>(e[4], e[5]), pack2<T>(e[6], e[7]));
     pf[1] = make_uint4(pack2<T>(e[8], e[9]), pack2<T>(e[10], e[11]), pack2<T>(e[12], e[13]), pack2<T>(e[14], e[15]));
+#endif
 }
 
 // One basic block of the pipeline (see the header).  HALF: which 32-key half of the 64-key tiles kt (item i) and vt
@@ -199,8 +335,8 @@ __device__ __forceinline__ void lp_bb(LpState& st, const unsigned char* kt, cons
         }                                                                                                             \
         if ((M_) < 8) {                                                                                               \
             if (DO_QK) {                                                                                              \
-                if ((M_) == 0) { if (TEXT) LP_MFMA(sn, frk[(M_) & 7], st.qf[(M_) & 7], zero16); else LP_MFMA(sn, frk[(M_) & 7], st.qf[(M_) & 7], st.cinit); } \
-                else LP_MFMA(sn, frk[(M_) & 7], st.qf[(M_) & 7], sn);                                                 \
+                if ((M_) == 0) { if (TEXT) lp_qk_zero<T>(sn, frk[(M_) & 7], st.qf[(M_) & 7], zero16); else lp_qk_first<T>(sn, frk[(M_) & 7], st.qf[(M_) & 7], st.cinit); } \
+                else lp_qk_acc<T>(sn, frk[(M_) & 7], st.qf[(M_) & 7]);                                                \
             }                                                                                                         \
         } else if (DO_PV) {                                                                                           \
             LP_MFMA(st.o[((M_) - 8) & 3], frv[(M_) & 7], pf_old[((M_) - 8) >> 2], st.o[((M_) - 8) & 3]);              \
@@ -234,6 +370,7 @@ __device__ __forceinline__ void lp_bb(LpState& st, const unsigned char* kt, cons
 #undef LP_SLOT
 #undef LP_MFMA
 #undef LP_LGKM
+    if (DO_QK && !DO_PV) lp_qk_settle();
     if (DO_SM) {
         const auto sw_ = __builtin_amdgcn_permlane32_swap(__float_as_uint(half_), __float_as_uint(half_), false, false);
         float psum = __uint_as_float(sw_[0]) + __uint_as_float(sw_[1]);   // both half-lanes: the row's 32 keys
@@ -265,9 +402,10 @@ __device__ __forceinline__ void lp_slow_tile(LpState& st, const unsigned char* k
             uint4 ka[8];
 #pragma unroll
             for (int ds = 0; ds < 8; ++ds) ka[ds] = *reinterpret_cast<const uint4*>(kt + k_addr[ds] + half * 8192);
-            s = mfma32<T>(ka[0], st.qf[0], st.cinit);   // S - m~
+            lp_qk_first<T>(s, ka[0], st.qf[0], st.cinit);   // S - m~
 #pragma unroll
-            for (int ds = 1; ds < 8; ++ds) s = mfma32<T>(ka[ds], st.qf[ds], s);
+            for (int ds = 1; ds < 8; ++ds) lp_qk_acc<T>(s, ka[ds], st.qf[ds]);
+            lp_qk_settle();
         }
         if (amp_on) {
 #pragma unroll

@@ -178,8 +178,11 @@ def dense_varlen(q, k, v, cu_seqlens, sm_scale, dtype):
 # ----------------------------------------------------------------------------- whole op (a11)
 def block_sparse_attention(query, key, value, top_k, dtype, cu_seqlens_q=None, text_blocks=2, text_amp=0.0,
                            block_neighbor_list=None, shape_xfuse=False, p_remain_rates=0.5, flavour="hy",
-                           first_frame_blocks=0, block=128, return_mask=False):
-    """query/key/value [B,S,H,D] float32 arrays holding `dtype` values.  flavour: "hy" | "i2v" | "wan"."""
+                           first_frame_blocks=0, block=128, return_mask=False, pooled=None):
+    """query/key/value [B,S,H,D] float32 arrays holding `dtype` values.  flavour: "hy" | "i2v" | "wan".
+    pooled = (qp [B,H,nimg,D], kp [B,H,nb,D]): block means to select from instead of pooling q / k here (:216-217) -- a
+    test hands in the HIP pooling kernel's own output, so that a 1-ulp difference of a pooled mean (fp32 summation order)
+    cannot flip a block of the selection and the comparison of the attention output can demand EVERY row."""
     q = np.transpose(query, (0, 2, 1, 3))
     k = np.transpose(key, (0, 2, 1, 3))
     v = np.transpose(value, (0, 2, 1, 3))
@@ -212,8 +215,13 @@ def block_sparse_attention(query, key, value, top_k, dtype, cu_seqlens_q=None, t
     mask = None
     if nimg > 0:
         q_img = q[:, :, :nimg * block]
-        mask = build_block_mask(q_img, k, top_k, nimg, nb, p_remain_rates, text_blocks, block_neighbor_list, dtype,
-                                first_frame_blocks=first_frame_blocks, block=block)
+        if pooled is not None:
+            mask, _ = build_block_mask_from_pooled(np.asarray(pooled[0], np.float32), np.asarray(pooled[1], np.float32),
+                                                   top_k, nimg, nb, p_remain_rates, text_blocks, block_neighbor_list,
+                                                   dtype, first_frame_blocks=first_frame_blocks)
+        else:
+            mask = build_block_mask(q_img, k, top_k, nimg, nb, p_remain_rates, text_blocks, block_neighbor_list, dtype,
+                                    first_frame_blocks=first_frame_blocks, block=block)
         outs.append(sparse_rows(q_img, k, v, seqlens, mask, sm_scale, dtype, text_amp, nimg, block))
     if text_blocks > 0:
         outs.append(text_rows(q[:, :, nimg * block:], k, v, sm_scale, dtype))

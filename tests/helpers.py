@@ -141,3 +141,27 @@ def assert_ulp_close(a, b, dtype, max_frac=1e-3, max_ulps=1, rowwise=False):
         ulp = np.exp2(np.floor(np.log2(np.maximum(mag[diff], 1e-30))) - mant)
         worst = (np.abs(a[diff] - b[diff]) / ulp).max()
         assert worst <= max_ulps * 1.001, f"difference of {worst:.2f} ulp (allowed {max_ulps})"
+
+
+def hip_pooled(q, k, text_blocks, dev, bf16=False):
+    """The block means the AttenCarve op selects from, computed by the HIP pooling kernel exactly as the op does it (q / k
+    [B,S,H,128] torch tensors, zero-padded to whole 128-token blocks like the padding flavours do): -> (qp [B,H,nimg,128],
+    kp [B,H,nb,128]) as fp32 numpy arrays for oracle.attention.block_sparse_attention(pooled=...).  With them the oracle
+    selects from the SAME pooled values as the kernel under test, so the whole-op comparisons can demand every row."""
+    from jenga_amd import _capi
+    B, S, H, D = q.shape
+    pad = (128 - S % 128) % 128
+    qd, kd = q.to(dev), k.to(dev)
+    if bf16:
+        qd, kd = qd.to(torch.bfloat16), kd.to(torch.bfloat16)
+    if pad:
+        qd = torch.nn.functional.pad(qd, [0, 0, 0, 0, 0, pad])
+        kd = torch.nn.functional.pad(kd, [0, 0, 0, 0, 0, pad])
+    nb = (S + pad) // 128
+    nimg = nb - text_blocks
+    if nimg <= 0:
+        return None
+    qp = _capi.block_pool(qd.contiguous(), nimg)
+    kp = _capi.block_pool(kd.contiguous(), nb)
+    torch.cuda.synchronize()
+    return qp.float().cpu().numpy(), kp.float().cpu().numpy()

@@ -44,7 +44,7 @@ def test_bench_line_helpers_and_keys():
     import bench
     src = open(os.path.join(ROOT, "bench.py")).read()
     for key in ('"roofline_secondary"', '"loop"', '"power"', '"traffic_provenance"', '"cpu_baseline"', '"extra"',
-                '"dense_reference"', '"attn_rotate"', '"wan14b"'):
+                '"dense_reference"', '"attn_other_kernel"', '"wan14b"'):
         assert f"res[{key}]" in src or f"{key}:" in src or f"[{key}]" in src or f"setdefault({key}" in src, key
     # one computed forward at the 720p shape: 1.57 PFLOP of GEMMs
     fl = bench.hy_gemm_flops_per_computed_step(115200, 256, 20, 40)

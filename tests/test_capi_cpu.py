@@ -15,17 +15,14 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def test_library_builds_and_loads():
     build.build()
     L = _capi.lib()
-    assert L.jenga_abi_version() == 3
+    assert L.jenga_abi_version() == 4
 
 
 def _declared():
-    """(product symbols, experiment symbols) declared by include/jenga_amd.h."""
+    """symbols declared by include/jenga_amd.h."""
     header = open(os.path.join(ROOT, "include", "jenga_amd.h")).read()
-    m = re.search(r"#ifdef JENGA_EXPERIMENTS(.*?)#endif /\* JENGA_EXPERIMENTS \*/", header, re.S)
-    assert m, "experiments section not found"
-    exp = set(re.findall(r"\b(jenga_[a-z0-9_]+)\s*\(", m.group(1)))
-    prod = set(re.findall(r"\b(jenga_[a-z0-9_]+)\s*\(", header[:m.start()] + header[m.end():]))
-    return prod, exp - prod
+    assert "JENGA_EXPERIMENTS" not in header          # (round 5: no experiments section, no experiments library)
+    return set(re.findall(r"\b(jenga_[a-z0-9_]+)\s*\(", header))
 
 
 def _exported(path):
@@ -34,23 +31,23 @@ def _exported(path):
 
 
 def test_header_symbols_exported():
-    declared, experiments = _declared()
+    declared = _declared()
     exported = _exported(_capi.LIB_PATH)
     assert declared, "no declarations parsed"
     assert declared <= exported, f"missing: {declared - exported}"
     assert declared == set(_capi.SIGNATURES), "ctypes binding out of sync with the header"
-    assert experiments == set(_capi.EXPERIMENT_SIGNATURES)
-    if os.path.basename(_capi.LIB_PATH) == "libjenga_amd.so":
-        # the product library carries no experiment: measured-and-rejected kernels live in libjenga_amd_exp.so only
-        assert not (experiments & exported), experiments & exported
-        assert len(build.SOURCES) <= 7 and not any("experiments" in s for s, _ in build.SOURCES)
+    assert not os.path.isdir(os.path.join(ROOT, "jenga_amd", "csrc", "experiments"))
 
 
-def test_experiments_library_is_a_superset_when_built():
-    if not os.path.exists(build.LIB_EXP):
-        pytest.skip("libjenga_amd_exp.so not built (python -m jenga_amd.build --experiments)")
-    declared, experiments = _declared()
-    assert (declared | experiments) <= _exported(build.LIB_EXP)
+def test_library_is_rebuilt_when_a_source_changes(tmp_path, monkeypatch):
+    """build.needs_build compares a content hash of csrc/ + the header + build.py with the stamp written next to the library
+    (not mtimes): the prebuilt .so that travels with a snapshot is kept only if it was built from the sources beside it."""
+    assert not build.needs_build()
+    real = build.source_digest()
+    monkeypatch.setattr(build, "source_digest", lambda: "0" * 64)
+    assert build.needs_build()
+    monkeypatch.setattr(build, "source_digest", lambda: real)
+    assert not build.needs_build()
 
 
 def test_no_cpu_fallback():
@@ -118,7 +115,6 @@ def test_ctypes_signatures_match_the_header_parameter_by_parameter():
         return {"int64_t": "i64", "int": "int", "float": "float", "size_t": "size", "double": "double"}[t]
 
     sigs = dict(_capi.SIGNATURES)
-    sigs.update(_capi.EXPERIMENT_SIGNATURES)
     for name, (_res, args) in sigs.items():
         m = re.search(r"\b(?:int64_t|int|size_t|const char\s*\*)\s*" + name + r"\s*\(([^;]*?)\)\s*;", header, re.S)
         assert m, f"{name}: declaration not found"
@@ -126,22 +122,6 @@ def test_ctypes_signatures_match_the_header_parameter_by_parameter():
         assert len(params) == len(args), f"{name}: header has {len(params)} parameters, ctypes {len(args)}"
         for i, (p_, a_) in enumerate(zip(params, args)):
             assert kind_of(p_) == kinds[a_], f"{name}: parameter {i} ({p_.strip()!r}) bound as {a_.__name__}"
-
-
-def test_attention_mode_switch():
-    """_capi.set_attention_mode: the deterministic default (ascending list walk) and the opt-in throughput mode
-    (JENGA_ATTN_ROTATE) differ in exactly that flag."""
-    from jenga_amd import _capi
-    before = _capi.ATTN_DEFAULT_FLAGS
-    try:
-        assert _capi.set_attention_mode("throughput") & _capi.ATTN_ROTATE
-        assert not (_capi.set_attention_mode("deterministic") & _capi.ATTN_ROTATE)
-        assert _capi.ATTN_DEFAULT_FLAGS == before & ~_capi.ATTN_ROTATE
-        import pytest
-        with pytest.raises(ValueError):
-            _capi.set_attention_mode("fast")
-    finally:
-        _capi.ATTN_DEFAULT_FLAGS = before
 
 
 def test_attention_flag_constants_match_the_header():
@@ -152,10 +132,11 @@ def test_attention_flag_constants_match_the_header():
     from jenga_amd import _capi
     hdr = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "jenga_amd.h")).read()
     defs = {m.group(1): int(m.group(2)) for m in re.finditer(r"#define\s+JENGA_ATTN_(\w+)\s+(\d+)", hdr)}
-    assert defs == {"XCD_REMAP": 1, "PINGPONG": 2, "BALANCE": 4, "LP": 8, "COHORT": 32, "ROTATE": 128}
+    assert defs == {"XCD_REMAP": 1, "BALANCE": 4, "LP": 8}
     for name, val in defs.items():
         assert getattr(_capi, "ATTN_" + name) == val, name
     assert _capi.ATTN_SORTED == 16 and _capi.ATTN_PAIR == 64          # Python-side routing bits: not in the C header
     if "JENGA_ATTN_FLAGS" not in os.environ:
-        assert _capi.ATTN_DEFAULT_FLAGS & ~_capi.ATTN_ROTATE == (_capi.ATTN_XCD_REMAP | _capi.ATTN_BALANCE | _capi.ATTN_LP
-                                                                  | _capi.ATTN_SORTED)
+        assert _capi.ATTN_DEFAULT_FLAGS in (_capi.ATTN_LP_FLAGS, _capi.ATTN_PAIR_FLAGS)
+    assert _capi.ATTN_LP_FLAGS == _capi.ATTN_XCD_REMAP | _capi.ATTN_BALANCE | _capi.ATTN_LP | _capi.ATTN_SORTED
+    assert _capi.ATTN_PAIR_FLAGS == _capi.ATTN_XCD_REMAP | _capi.ATTN_BALANCE | _capi.ATTN_SORTED | _capi.ATTN_PAIR

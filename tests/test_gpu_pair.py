@@ -1,5 +1,5 @@
-"""GPU (-m gpu): the pair kernel (csrc/bsattn2.hip: two query blocks per workgroup, merged lists, one wave per SIMD)
-against the oracle, against the round-1 kernel it replaces, and its list merge against plain Python sets."""
+"""GPU (-m gpu): the pair kernel (csrc/bsattn5.hip: two query blocks per workgroup, merged lists, one wave per SIMD, 64 query
+rows per wave) against the oracle, against the round-1 kernel, and its list merge against plain Python sets."""
 import numpy as np
 import pytest
 import torch
@@ -23,9 +23,6 @@ def lists_from_mask(mask_bool, device):
 
 @pytest.mark.parametrize("nq,nb,density", [(8, 10, 0.4), (9, 9, 0.3), (1, 5, 0.5), (21, 300, 0.3), (6, 2050, 0.25)])
 def test_pair_merge_vs_sets(dev, nq, nb, density):
-    from jenga_amd import _capi as _c
-    if not _c.has_experiments():
-        pytest.skip("jenga_pair_merge is part of the experiments library")
     from jenga_amd import _capi
     gen = torch.Generator().manual_seed(nq * 1000 + nb)
     B, H = 1, 3
@@ -95,14 +92,12 @@ CASES = [
 ]
 
 
-NEW_KERNELS = {"pair": 1 | 64, "lp": 9, "lp_pair": 1 | 8 | 64}   # flags: XCD remap | (8 = JENGA_ATTN_LP, the default
-#     kernel; 64 = the pair kernel, 8 | 64 = the 8-wave LP pair: experiments, libjenga_amd_exp.so only)
+NEW_KERNELS = {"pair": 1 | 64, "pair_default": 1 | 4 | 16 | 64, "lp": 9}   # flags: XCD remap | (8 = JENGA_ATTN_LP; 64 = the pair
+#     kernel, Python-side routing bit; 4 = the balanced launch)
 
 
 def _need(kern):
-    from jenga_amd import _capi
-    if NEW_KERNELS[kern] & 64 and not _capi.has_experiments():
-        pytest.skip("experiment kernel: needs JENGA_LIB=libjenga_amd_exp.so (python -m jenga_amd.build --experiments)")
+    pass
 
 
 @pytest.mark.parametrize("kern", list(NEW_KERNELS))
@@ -114,8 +109,6 @@ def test_pair_kernel_vs_oracle_and_legacy(dev, case, kern):
     from jenga_amd import _capi
     from oracle import attention as oa
     seed, H, nq_img, tb, dt, density, overlap, valid_text, amp = case
-    if kern == "lp_pair" and not tb:
-        pytest.skip("the LP pair experiment does not take masked image blocks in unshared lists")
     q, k, v, mask = _rand_case(seed, H, nq_img, tb, dt, density, overlap)
     seqlen = nq_img * 128 + valid_text if tb else nq_img * 128 - 19     # no text: the last image block is padded
     o_new = _run(q, k, v, mask, seqlen, amp, nq_img, dev, flags=NEW_KERNELS[kern])

@@ -51,8 +51,11 @@ def main():
                     help="experiment: every query block keeps a random 31.6 %% of the kv blocks [0, WINDOW) only")
     ap.add_argument("--k-head-major", action="store_true", help="K (and Q) stored [B,H,S,D]: contiguous 16 KiB K tiles")
     ap.add_argument("--flags", type=int, default=None,
-                    help="attention flags (_capi.ATTN_*): 1 = XCD remap, 8 = LP kernel (default 9), 16 = kept-count-aware "
-                         "order, 0 / 1 = round-1 kernel; experiments library only: 2 = ping-pong, 64 = pair, 72 = LP pair")
+                    help="attention flags (_capi.ATTN_*): 1 = XCD remap, 4 = balanced launch, 8 = LP kernel, 16 = kept-count-aware "
+                         "order (29 = the LP default), 64 = pair kernel (69 = its default), 0 / 1 = round-1 kernel")
+    ap.add_argument("--also-flags", type=int, nargs="*", default=[],
+                    help="more flag sets timed on the SAME tensors and lists in the same process (A/B on one box); each is "
+                         "reported under also[<flags>] with its max |o - o_first|")
     ap.add_argument("--pair-overlap", type=float, default=-1.0,
                     help=">= 0: synthetic lists -- every odd query block shares this fraction of its list with the even "
                          "block in front of it (what Hilbert-adjacent blocks of a trained model look like); same counts")
@@ -158,6 +161,21 @@ def main():
     res["attn_frac_of_2.5PF"] = res["attn_TFLOPs"] / 2500
     res["dense_equiv_TFLOPs"] = 4 * S * S * 128 * H / (ms * 1e-3) / 1e12
     res["finite"] = bool(torch.isfinite(o.float()).all().item())
+    for fl2 in a.also_flags:
+        ms2, o2 = timed(lambda: _capi.bsattn_fwd(q, k, vt, seqlens, idx, cnt, nimg, 128 ** -0.5, 0.0, nimg,
+                                                 xcd_remap=not a.no_xcd, flags=fl2), a.iters)
+        d = (o2.float() - o.float()).abs()
+        res.setdefault("also", {})[str(fl2)] = dict(attn_ms=ms2, attn_TFLOPs=flops / (ms2 * 1e-3) / 1e12,
+                                                    frac=flops / (ms2 * 1e-3) / 1e12 / 2500,
+                                                    max_abs_diff_vs_first=float(d.max().item()),
+                                                    mean_abs_diff_vs_first=float(d.mean().item()),
+                                                    finite=bool(torch.isfinite(o2.float()).all().item()))
+        del o2, d
+    # second pass of the first set: the board reaches its power steady state over the run, order effects show here
+    if a.also_flags:
+        ms3, _ = timed(lambda: _capi.bsattn_fwd(q, k, vt, seqlens, idx, cnt, nimg, 128 ** -0.5, 0.0, nimg,
+                                                xcd_remap=not a.no_xcd, flags=fl), a.iters)
+        res["attn_ms_second_pass"] = ms3
     print(json.dumps(res))
 
 

@@ -1,0 +1,32 @@
+#!/bin/bash
+# GPU sessions of round 5 (run through gpurun): bash tools/gpu_r05.sh <stage>
+cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd /root/repo
+export TMPDIR=/tmp
+O=gpurun_out/r05_$1; mkdir -p $O
+case "$1" in
+A)  # first run of the pair kernel: parity, then LP vs pair on one box (flat lists / lists like the driver workload's), then the loop
+  timeout 900 python -m pytest tests/test_gpu_pair.py tests/test_gpu_order.py -x -q -m gpu > $O/pytest_pair.log 2>&1; tail -5 $O/pytest_pair.log
+  timeout 600 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "sparse_kernel" > $O/pytest_parity.log 2>&1; tail -3 $O/pytest_parity.log
+  timeout 300 python tools/bench_attn.py --drop 0.7 --iters 40 --attn-only --flags 29 --also-flags 85 65 > $O/ab_flat.json 2> $O/ab_flat.err; tail -c 1200 $O/ab_flat.json
+  timeout 300 python tools/bench_attn.py --drop 0.7 --iters 40 --attn-only --coherent 3 --gain 2 --flags 29 --also-flags 85 > $O/ab_coh.json 2> $O/ab_coh.err; tail -c 900 $O/ab_coh.json
+  timeout 300 python tools/bench_attn.py --drop 0.7 --iters 40 --attn-only --pair-overlap 0.75 --flags 29 --also-flags 85 > $O/ab_ov75.json 2> $O/ab_ov75.err; tail -c 900 $O/ab_ov75.json
+  timeout 600 python bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-dense-ref --no-wan-extra > $O/bench6.json 2> $O/bench6.err; tail -c 3000 $O/bench6.json
+  ;;
+B)  # pair kernel v2 (V^T ring of three, work-aware order): parity, A/B, counters of both kernels on the same lists, the loop
+  timeout 900 python -m pytest tests/test_gpu_pair.py tests/test_gpu_order.py -x -q -m gpu > $O/pytest_pair.log 2>&1; tail -4 $O/pytest_pair.log
+  timeout 200 python tools/debug_pair.py > $O/debug.log 2>&1; grep -c "bad (qblock, head)=\[\]" $O/debug.log; grep -v "bad (qblock, head)=\[\]" $O/debug.log | head
+  timeout 300 python tools/bench_attn.py --drop 0.7 --iters 40 --attn-only --flags 29 --also-flags 85 > $O/ab_flat.json 2> $O/ab_flat.err; python tools/ab_print.py $O/ab_flat.json
+  timeout 300 python tools/bench_attn.py --drop 0.7 --iters 40 --attn-only --coherent 3 --gain 2 --flags 29 --also-flags 85 69 > $O/ab_coh.json 2> $O/ab_coh.err; python tools/ab_print.py $O/ab_coh.json
+  timeout 300 python tools/bench_attn.py --drop 0.8 --iters 40 --attn-only --coherent 3 --gain 2 --flags 29 --also-flags 85 > $O/ab_coh08.json 2> $O/ab_coh08.err; python tools/ab_print.py $O/ab_coh08.json
+  timeout 600 bash tools/pmc_attn2.sh r05_pair_coh --drop 0.7 --iters 2 --attn-only --coherent 3 --gain 2 --flags 85 > $O/pmc_pair.log 2>&1; grep -A14 '"derived"' $O/pmc_pair.log | head -24
+  timeout 600 bash tools/pmc_attn2.sh r05_lp_coh --drop 0.7 --iters 2 --attn-only --coherent 3 --gain 2 --flags 29 > $O/pmc_lp.log 2>&1; grep -A14 '"derived"' $O/pmc_lp.log | head -24
+  JENGA_ATTN_FLAGS=85 timeout 600 python bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-dense-ref --no-wan-extra --no-secondary > $O/bench6_pair.json 2> $O/bench6_pair.err; python tools/ab_print.py $O/bench6_pair.json
+  ;;
+C)  # elimination builds of the pair kernel (wrong results, clock only): what the LDS-DMA issue and the step barrier cost
+  A="--drop 0.7 --iters 30 --attn-only --coherent 3 --gain 2 --flags 85"
+  for lib in ${LIBS:-base nodma nobar nodmabar}; do
+    if [ "$lib" = base ]; then unset JENGA_LIB; else export JENGA_LIB=$PWD/alt_libs/$lib.so; fi
+    timeout 200 python tools/bench_attn.py $A > $O/$lib.json 2> $O/$lib.err; echo $lib; python tools/ab_print.py $O/$lib.json | tail -1
+  done
+  ;;
+esac

@@ -32,10 +32,18 @@ def kernels(text, pat=""):
 def loops_of(lines):
     labels = {l[:-1]: i for i, l in enumerate(lines) if l.endswith(":")}
     res = []
+    far = None      # target of a long jump being assembled (s_getpc / s_add_u32 (.Ltarget-.Lpost_getpc) / s_setpc_b64)
     for i, l in enumerate(lines):
         b = re.match(r"s_c?branch\S*\s+(\S+)", l)
         if b and b.group(1) in labels and labels[b.group(1)] < i:
             res.append((labels[b.group(1)], i))
+        f = re.match(r"s_add_u32 \S+ \S+ \((\.LBB\S+)-\.Lpost_getpc\d+\)", l.replace(",", ""))
+        if f:
+            far = f.group(1)
+        if l.startswith("s_setpc_b64") and far is not None:
+            if far in labels and labels[far] < i:
+                res.append((labels[far], i))
+            far = None
     return res
 
 
@@ -50,6 +58,25 @@ def main_loop_reloads(lines, mfma_per_iteration=192):
     a, b = best
     first = next(t for t in range(a, b) if "mfma" in lines[t])
     return [(t - a, lines[t]) for t in range(first, b + 1) if lines[t].startswith("scratch_")]
+
+
+def hot_path(lines, cold_marker="v_ceil_f32"):
+    """The instructions of `lines` (one loop) outside the basic blocks that contain `cold_marker` -- for the attention
+    kernels: the exact max-first softmax blocks (the only users of ceilf), entered on a wave-wide ballot."""
+    bbs, cur = [], []
+    for x in lines:
+        if x.endswith(":"):
+            if cur:
+                bbs.append(cur)
+            cur = []
+        else:
+            cur.append(x)
+            if x.startswith("s_cbranch") or x.startswith("s_branch") or x.startswith("s_setpc"):
+                bbs.append(cur)
+                cur = []
+    if cur:
+        bbs.append(cur)
+    return [x for bb in bbs if not any(cold_marker in y for y in bb) for x in bb]
 
 
 def main():
