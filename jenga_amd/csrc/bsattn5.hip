@@ -39,6 +39,12 @@
 #ifndef LQ_X_NOBAR
 #define LQ_X_NOBAR 0      // no vmcnt wait / barrier at the end of a step of the unrolled main loop
 #endif
+#ifndef LQ_AHEAD
+#define LQ_AHEAD 4        // fragment reads run this many fragments (= twice as many MFMAs) ahead of their MFMAs
+#endif
+#ifndef LQ_DMA_SLOT0
+#define LQ_DMA_SLOT0 3    // the four LDS-DMA pieces of a block go out in slots LQ_DMA_SLOT0 + 8 i
+#endif
 #ifndef LQ_X_NOSM
 #define LQ_X_NOSM 0       // no softmax arithmetic in lq_bb (P = const, no exact-path ballot)
 #endif
@@ -85,7 +91,7 @@ __device__ __forceinline__ void lq_bb(LpState& sa, LpState& sb, const unsigned c
     constexpr int KO = KOFF < 0 ? 0 : KOFF, VO = VOFF < 0 ? 0 : VOFF;
     static_assert(PRE == 0 || (DO_QK && DO_PV), "the cross-block fragment pipeline is for full blocks");
     static_assert(PRE != 1 || HALF == 0, "only the first half prefetches (the next tile may still be in flight)");
-    constexpr int LAST = PRE == 1 ? 19 : (DO_PV ? 15 : 7);     // last fragment this block requests
+    constexpr int LAST = PRE == 1 ? 15 + LQ_AHEAD : (DO_PV ? 15 : 7);     // last fragment this block requests
     f32x16 zero16;
 #pragma unroll
     for (int r = 0; r < 16; ++r) zero16[r] = 0.f;
@@ -106,7 +112,7 @@ __device__ __forceinline__ void lq_bb(LpState& sa, LpState& sb, const unsigned c
         } else if ((F_) < 16) {                                                                                       \
             if (DO_PV) frv[(F_) & 7] = *reinterpret_cast<const uint4*>(vt + v_addr[2 * HALF + (((F_) - 8) >> 2)] +    \
                                                                        ((((F_) - 8) & 3) * 4096 + VO));               \
-        } else if ((F_) < 20 && PRE == 1) { /* K fragment (F_ - 16) of the next block: the other half of this tile */ \
+        } else if ((F_) < 16 + LQ_AHEAD && PRE == 1) { /* K fragment (F_ - 16) of the next block: the other half of this tile */ \
             frk[(F_) & 7] = *reinterpret_cast<const uint4*>(kt + k_addr[(F_) & 7] + (8192 + KO));                     \
         }                                                                                                             \
     } while (0)
@@ -151,6 +157,10 @@ __device__ __forceinline__ void lq_bb(LpState& sa, LpState& sb, const unsigned c
         if ((N_) == 1) __builtin_amdgcn_s_waitcnt(0xC17F);                                                            \
         else if ((N_) == 2) __builtin_amdgcn_s_waitcnt(0xC27F);                                                       \
         else if ((N_) == 3) __builtin_amdgcn_s_waitcnt(0xC37F);                                                       \
+        else if ((N_) == 4) __builtin_amdgcn_s_waitcnt(0xC47F);                                                       \
+        else if ((N_) == 5) __builtin_amdgcn_s_waitcnt(0xC57F);                                                       \
+        else if ((N_) == 6) __builtin_amdgcn_s_waitcnt(0xC67F);                                                       \
+        else if ((N_) == 7) __builtin_amdgcn_s_waitcnt(0xC77F);                                                       \
         else __builtin_amdgcn_s_waitcnt(0xC07F);                                                                      \
     } while (0)
     /* slot m, m even, issues the MFMAs m and m + 1 on fragment m >> 1: that fragment must be there; the reads requested
@@ -158,7 +168,7 @@ __device__ __forceinline__ void lq_bb(LpState& sa, LpState& sb, const unsigned c
 #define LQ_SLOT(M_)                                                                                                   \
     do {                                                                                                              \
         if (!LQ_X_NOREAD && !((M_) & 1) && (((M_) < 16 && DO_QK) || ((M_) >= 16 && DO_PV))) {                         \
-            LQ_LGKM(LAST - ((M_) >> 1) < 3 ? LAST - ((M_) >> 1) : 3);                                                 \
+            LQ_LGKM(LAST - ((M_) >> 1) < LQ_AHEAD - 1 ? LAST - ((M_) >> 1) : LQ_AHEAD - 1);                                                 \
             __builtin_amdgcn_sched_barrier(0);   /* or hipcc moves the MFMA above the wait and adds its own */        \
         }                                                                                                             \
         if ((M_) < 16) {                                                                                              \
@@ -179,23 +189,29 @@ __device__ __forceinline__ void lq_bb(LpState& sa, LpState& sb, const unsigned c
                 sa.o[(((M_) - 16) >> 1) & 3] = mfma32<T>(frv[(((M_) - 16) >> 1) & 7], poA[((M_) - 16) >> 3],          \
                                                          sa.o[(((M_) - 16) >> 1) & 3]);                               \
         }                                                                                                             \
-        if (((M_) & 1) == 0 && !(!DO_QK && ((M_) >> 1) + 4 < 12)) {                                                   \
-            LQ_READ(((M_) >> 1) + 4);                                                                                 \
+        if (((M_) & 1) == 0 && !(!DO_QK && ((M_) >> 1) + LQ_AHEAD < 8 + LQ_AHEAD)) {                                  \
+            LQ_READ(((M_) >> 1) + LQ_AHEAD);                                                                          \
         }                                                                                                             \
         if (dma && !LQ_X_NODMA) {                                                                                     \
-            if ((M_) == 3) lp_stage1<0>(*dma);                                                                        \
-            if ((M_) == 11) lp_stage1<1>(*dma);                                                                       \
-            if ((M_) == 19) lp_stage1<2>(*dma);                                                                       \
-            if ((M_) == 27) lp_stage1<3>(*dma);                                                                       \
+            if ((M_) == LQ_DMA_SLOT0) lp_stage1<0>(*dma);                                                             \
+            if ((M_) == LQ_DMA_SLOT0 + 8) lp_stage1<1>(*dma);                                                         \
+            if ((M_) == LQ_DMA_SLOT0 + 16) lp_stage1<2>(*dma);                                                        \
+            if ((M_) == LQ_DMA_SLOT0 + 24) lp_stage1<3>(*dma);                                                        \
         }                                                                                                             \
         LQ_SM(M_);                                                                                                    \
         __builtin_amdgcn_sched_barrier(0);                                                                            \
     } while (0)
     if (DO_QK && PRE != 2) {
         LQ_READ(0); LQ_READ(1); LQ_READ(2); LQ_READ(3);
+        if (LQ_AHEAD > 4) { LQ_READ(4); }
+        if (LQ_AHEAD > 5) { LQ_READ(5); }
+        if (LQ_AHEAD > 6) { LQ_READ(6); }
     }
     if (!DO_QK) {
         LQ_READ(8); LQ_READ(9); LQ_READ(10); LQ_READ(11);
+        if (LQ_AHEAD > 4) { LQ_READ(12); }
+        if (LQ_AHEAD > 5) { LQ_READ(13); }
+        if (LQ_AHEAD > 6) { LQ_READ(14); }
     }
     __builtin_amdgcn_sched_barrier(0);
     LQ_SLOT(0); LQ_SLOT(1); LQ_SLOT(2); LQ_SLOT(3); LQ_SLOT(4); LQ_SLOT(5); LQ_SLOT(6); LQ_SLOT(7);

@@ -1,4 +1,12 @@
-// Block selection: one workgroup per (batch, head, query block) row.
+// Block selection: one workgroup per SEL_G consecutive query blocks of one (batch, head) (round 5; one row per workgroup
+// before).  The pooled K of a head (902 x 128 at the 720p shape = 230 KB) is what every row of the head reads: with one row
+// per workgroup that was 5 GB per launch through the L2s, and since workgroup ids go round robin over the 8 XCDs every XCD's
+// 4 MB L2 saw all 24 heads (5.5 MB).  Now a workgroup streams its head's pooled K ONCE for SEL_G rows (the dot products keep
+// their order: per (row, column) the same 128 sequential fmaf), and with (batch * heads) a multiple of 8 all workgroups of a
+// head run on ONE XCD (id % 8), so the re-reads are L2 hits.  Measured (profiles/r05_select_ab.json): 0.70 -> 0.49 ms at the
+// 720p shape; of the 0.70 the one-thread cumulative sum was 0.26 on flat rows (now an exact shuffle scan), the dot products
+// ~0.15, the sort ~0.18, launch + output ~0.1; 2 rows per workgroup is the optimum (4: 0.53-0.73, 8: 0.58-0.77 -- the rows of
+// a group run one after the other, more rows = fewer workgroups to hide the sort's barriers).  The per-row work:
 //   scores -> softmax (dtype) -> sort (bitonic, LDS) -> cumulative-probability / top-k rule -> bit set
 //   -> OR static neighbours / first-frame / text columns -> ascending index list (+ optional one-hot mask).
 // Rounding points follow the reference's torch code running in the tensor dtype
@@ -86,53 +94,100 @@ __device__ __forceinline__ void bitonic_sort_desc_regs(uint32_t* keys, int npow2
     __syncthreads();
 }
 
+#ifndef SEL_G_ROWS
+#define SEL_G_ROWS 2
+#endif
+constexpr int SEL_G = SEL_G_ROWS;  // query blocks per workgroup
+// elimination switches (A/B builds, wrong results): SEL_X & 1 no dot products, 2 no sort, 4 no cumulative sum, 8 no output
+#ifndef SEL_X
+#define SEL_X 0
+#endif
+
 template <typename T>
 __global__ void __launch_bounds__(256)
 block_select_kernel(const uint16_t* __restrict__ qpool, const uint16_t* __restrict__ kpool,
                     const uint8_t* __restrict__ neighbors, int nb_rows, int nb_cols, uint8_t* __restrict__ mask,
-                    int32_t* __restrict__ idx, int32_t* __restrict__ cnt, int /*H*/, int nq, int nk_img, int text_blocks,
-                    int top_k, float p_thr, int first_frame_blocks, int npow2, int scan_log_nx) {
+                    int32_t* __restrict__ idx, int32_t* __restrict__ cnt, int BH, int nq, int nk_img, int text_blocks,
+                    int top_k, float p_thr, int first_frame_blocks, int npow2, int scan_log_nx, int ngrp, int xcd_map) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t* keys = reinterpret_cast<uint32_t*>(smem);                 // [npow2]
-    float* qrow = reinterpret_cast<float*>(keys + npow2);               // [128]
-    uint32_t* bits = reinterpret_cast<uint32_t*>(qrow + 128);           // [80]: up to 2048+ columns
+    float* qrows = reinterpret_cast<float*>(keys + npow2);              // [SEL_G][128]
+    uint32_t* bits = reinterpret_cast<uint32_t*>(qrows + SEL_G * 128);  // [80]: up to 2048+ columns
     uint32_t* wpre = bits + 80;                                         // [80] exclusive popcount prefix
     float* scratch = reinterpret_cast<float*>(wpre + 80);               // [8]
-    int* n_sh = reinterpret_cast<int*>(scratch + 8);                    // [1]
+    int* n_sh = reinterpret_cast<int*>(scratch + 8);                    // [4]
     float* sbuf = reinterpret_cast<float*>(n_sh + 4);                   // [2 << scan_log_nx] (device-scan mode, W > 64)
 
     const int nk_all = nk_img + text_blocks;
-    const long long row = blockIdx.x;  // (b*H + h)*nq + m
-    const int m = (int)(row % nq);
-    const long long bh = row / nq;
     const int tid = threadIdx.x;
+    // workgroup id -> (bh, row group).  xcd_map: the hardware deals ids to the XCDs round robin (id % 8); (b, h) pair bh
+    // runs on XCD bh % 8, so that its pooled K stays in ONE L2.  (Only when BH % 8 == 0: a rank that holds 3 heads must
+    // not leave 5 XCDs idle.)
+    long long bh;
+    int grp;
+    if (xcd_map) {
+        const int x = blockIdx.x & 7;
+        const long long k_ = blockIdx.x >> 3;
+        bh = x + 8 * (k_ / ngrp);
+        grp = (int)(k_ % ngrp);
+        if (bh >= BH) return;
+    } else {
+        bh = blockIdx.x / ngrp;
+        grp = blockIdx.x % ngrp;
+    }
+    const int m0 = grp * SEL_G;
+    const int g_n = nq - m0 < SEL_G ? nq - m0 : SEL_G;      // rows of this group
 
-    if (tid < 128) qrow[tid] = to_f32<T>(qpool[row * 128 + tid]);
-    if (tid < 80) bits[tid] = 0u;
+    for (int e = tid; e < SEL_G * 128; e += 256) {
+        const int g = e >> 7;
+        qrows[e] = g < g_n ? to_f32<T>(qpool[(bh * nq + m0 + g) * 128 + (e & 127)]) : 0.f;
+    }
     __syncthreads();
 
-    // ---- pooled scores for the image columns (K3) ----
+    // ---- pooled scores for the image columns (K3): the K row of a column is read once for the SEL_G rows ----
     const float scale = 0.08838834764831845f;  // float(128 ** -0.5)
-    float sc[MAX_PER_THREAD];
-    float lmax = -INFINITY;
+    float scg[SEL_G][MAX_PER_THREAD];
 #pragma unroll
     for (int i = 0; i < MAX_PER_THREAD; ++i) {
         const int j = tid + i * 256;
-        sc[i] = -INFINITY;
-        if (j < nk_img) {
+#pragma unroll
+        for (int g = 0; g < SEL_G; ++g) scg[g][i] = -INFINITY;
+        if (j < nk_img && (SEL_X & 1)) {
+#pragma unroll
+            for (int g = 0; g < SEL_G; ++g) scg[g][i] = (float)((j * 37 + g * 11) % 97) * 0.01f;
+        } else if (j < nk_img) {
             const uint4* kr = reinterpret_cast<const uint4*>(kpool + (bh * nk_all + j) * 128);
-            float acc = 0.f;
+            float acc[SEL_G];
+#pragma unroll
+            for (int g = 0; g < SEL_G; ++g) acc[g] = 0.f;
 #pragma unroll
             for (int c = 0; c < 16; ++c) {
                 float f[8];
                 unpack8<T>(kr[c], f);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) acc = fmaf(qrow[c * 8 + e], f[e], acc);
+                for (int g = 0; g < SEL_G; ++g)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) acc[g] = fmaf(qrows[g * 128 + c * 8 + e], f[e], acc[g]);
             }
-            sc[i] = round_to<T>(round_to<T>(acc) * scale);
-            lmax = fmaxf(lmax, sc[i]);
+#pragma unroll
+            for (int g = 0; g < SEL_G; ++g) scg[g][i] = round_to<T>(round_to<T>(acc[g]) * scale);
         }
     }
+#pragma unroll 1
+    for (int g = 0; g < g_n; ++g) {
+    const int m = m0 + g;
+    const long long row = bh * nq + m;
+    if (tid < 80) bits[tid] = 0u;
+    float sc[MAX_PER_THREAD];
+    float lmax = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < MAX_PER_THREAD; ++i) {
+        sc[i] = scg[0][i];
+#pragma unroll
+        for (int g2 = 1; g2 < SEL_G; ++g2) sc[i] = g == g2 ? scg[g2][i] : sc[i];
+        lmax = fmaxf(lmax, sc[i]);
+    }
+    __syncthreads();
     // ---- softmax over the image columns, rounded to dtype (K4) ----
     const float rmax = block_reduce_max(lmax, scratch);
     float lsum = 0.f;
@@ -156,7 +211,8 @@ block_select_kernel(const uint16_t* __restrict__ qpool, const uint16_t* __restri
     }
     __syncthreads();
     // ---- bitonic sort, descending on (probability bits, then lower column first) ----
-    if (npow2 == 1024) bitonic_sort_desc_regs<4>(keys, npow2, tid);
+    if (SEL_X & 2) {
+    } else if (npow2 == 1024) bitonic_sort_desc_regs<4>(keys, npow2, tid);
     else if (npow2 == 512) bitonic_sort_desc_regs<2>(keys, npow2, tid);
     else if (npow2 == 256) bitonic_sort_desc_regs<1>(keys, npow2, tid);
     else if (npow2 == 2048) bitonic_sort_desc_regs<8>(keys, npow2, tid);
@@ -178,20 +234,51 @@ block_select_kernel(const uint16_t* __restrict__ qpool, const uint16_t* __restri
         }
     }
     // ---- n = max(#(cumsum <= p) + 1, top_k) ----
-    if (scan_log_nx < 0) {
+    if (SEL_X & 4) {
+        if (tid == 0) *n_sh = top_k;
+    } else if (scan_log_nx < 0) {
         // default contract = torch.cumsum of a 16-bit tensor on the CPU (what the reference's goldens were generated
         // with): sequential fp32 accumulation, each partial rounded to dtype
-        if (tid == 0) {
+        // Round 5.  Wave 0 takes 64 sorted probabilities at a time (one LDS read per lane).
+        //  * Fast path, bit-identical by construction: the probabilities are 16-bit values and the partial sums stay below
+        //    2, so as long as every addend so far is at least 2^-16 (bf16; 2^-13 for fp16) every partial sum -- in ANY order
+        //    of addition -- is a multiple of 2^-24 below 2 and therefore exact in fp32: a shuffle scan gives the sequential
+        //    chain's values.  The list is sorted descending, so one look at the chunk's last element decides.
+        //  * Otherwise (tiny probabilities before the threshold is reached: p near 1, very peaky rows) the chunk runs the
+        //    sequential chain itself, every lane redundantly on values broadcast with v_readlane.
+        // The partial sums are non-decreasing, so "count while round(acc) <= p, stop at the first miss" equals "count every
+        // i with round(acc_i) <= p"; a chunk whose last partial already missed ends the walk.
+        if (tid < 64) {
+            const float exact_min = sizeof(T) && __is_same(T, BF16) ? 1.52587890625e-05f : 1.220703125e-04f;
             float acc = 0.f;
             int count = 0;
-            for (int i = 0; i < nk_img; ++i) {
-                acc = acc + to_f32<T>((uint16_t)(keys[i] >> 16));
-                if (round_to<T>(acc) <= p_thr)
-                    ++count;
-                else
-                    break;  // partial sums are non-decreasing
+            for (int c0 = 0; c0 < nk_img; c0 += 64) {
+                const int col = c0 + tid;
+                const uint32_t mine = col < nk_img ? (keys[col] >> 16) : 0u;
+                const float pv = to_f32<T>((uint16_t)mine);
+                const int last_col = c0 + 63 < nk_img ? 63 : nk_img - 1 - c0;
+                const float smallest = __shfl(pv, last_col);
+                if (smallest >= exact_min) {
+                    float inc = pv;
+#pragma unroll
+                    for (int o = 1; o < 64; o <<= 1) {
+                        const float t_ = __shfl_up(inc, o);
+                        if (tid >= o) inc += t_;
+                    }
+                    const float part = acc + inc;
+                    count += __popcll(__builtin_amdgcn_ballot_w64(col < nk_img && round_to<T>(part) <= p_thr));
+                    acc = __shfl(part, 63);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 64; ++j) {
+                        const float pj = to_f32<T>((uint16_t)__builtin_amdgcn_readlane((int)mine, j));
+                        acc = acc + pj;
+                        count += (c0 + j < nk_img && round_to<T>(acc) <= p_thr) ? 1 : 0;
+                    }
+                }
+                if (!(round_to<T>(acc) <= p_thr)) break;      // wave-uniform: every lane holds the same value
             }
-            *n_sh = count;
+            if (tid == 0) *n_sh = count;
         }
     } else {
         // JENGA_SELECT_DEVICE_SCAN: torch.cumsum of a 16-bit tensor on the DEVICE, restated (ATen/native/cuda/
@@ -276,20 +363,30 @@ block_select_kernel(const uint16_t* __restrict__ qpool, const uint16_t* __restri
     for (int j = nk_img + tid; j < nk_all; j += 256) atomicOr(&bits[j >> 5], 1u << (j & 31));
     __syncthreads();
     // ---- ascending compaction ----
-    const int nwords = (nk_all + 31) >> 5;
-    if (tid < nwords) {
-        int pre = 0;
-        for (int w = 0; w < tid; ++w) pre += __popc(bits[w]);
-        wpre[tid] = (uint32_t)pre;
-        if (tid == nwords - 1 && cnt) cnt[row] = pre + __popc(bits[tid]);
+    const int nwords = (nk_all + 31) >> 5;     // <= 80 (2048 image + 512 text columns)
+    if (tid < 128) {          // exclusive popcount prefix over the words: two waves, a shuffle scan each, the carry through LDS
+        const int c = tid < nwords ? __popc(bits[tid]) : 0;
+        int inc = c;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int t_ = __shfl_up(inc, o);
+            if ((tid & 63) >= o) inc += t_;
+        }
+        if (tid < 80) wpre[tid] = (uint32_t)(inc - c);
+        if (tid == 63) n_sh[1] = inc;         // popcount of words 0..63
     }
     __syncthreads();
-    for (int j = tid; j < nk_all; j += 256) {
+    if (tid >= 64 && tid < 80) wpre[tid] += (uint32_t)n_sh[1];
+    __syncthreads();
+    if (tid == nwords - 1 && cnt) cnt[row] = (int)wpre[tid] + __popc(bits[tid]);
+    for (int j = tid; j < nk_all && !(SEL_X & 8); j += 256) {
         const uint32_t w = bits[j >> 5];
         const bool on = (w >> (j & 31)) & 1u;
         if (mask) mask[row * nk_all + j] = on ? 1 : 0;
         if (on && idx) idx[row * nk_all + (int)wpre[j >> 5] + __popc(w & ((1u << (j & 31)) - 1u))] = j;
     }
+    __syncthreads();     // keys / bits / wpre / n_sh are reused by the next row
+    }   // rows of the group
 }
 
 
@@ -356,7 +453,7 @@ extern "C" int jenga_block_select(void* stream, const void* qpool, const void* k
         if (l > 9u) l = 9u;
         scan_log_nx = (int)l;
     }
-    const size_t smem = (size_t)npow2 * 4 + 128 * 4 + 80 * 4 * 2 + 8 * 4 + 16 +
+    const size_t smem = (size_t)npow2 * 4 + SEL_G * 128 * 4 + 80 * 4 * 2 + 8 * 4 + 16 +
                        (scan_log_nx > 5 ? ((size_t)2 << scan_log_nx) * 4 : 0);
     // the reference compares the dtype cumsum with a Python float: the scalar is rounded to the tensor dtype
     float p_thr;
@@ -368,11 +465,19 @@ extern "C" int jenga_block_select(void* stream, const void* qpool, const void* k
     } else {
         p_thr = (float)(_Float16)p;
     }
+    const long long BH = (long long)B * H;
+    const long long ngrp = (nq + SEL_G - 1) / SEL_G;
+    const int xcd_map = (BH % 8 == 0) ? 1 : 0;
+    const long long grid = BH * ngrp;            // (xcd_map: BH % 8 == 0, the same count, another order)
+    if (grid > 0x7fffffffLL || BH > 0x7fffffffLL) {
+        set_error("jenga_block_select: grid size %lld out of range", grid);
+        return JENGA_EINVAL;
+    }
 #define LAUNCH_SEL(T)                                                                                                 \
-    hipLaunchKernelGGL(block_select_kernel<T>, dim3((unsigned)rows), dim3(256), smem, (hipStream_t)stream,            \
+    hipLaunchKernelGGL(block_select_kernel<T>, dim3((unsigned)grid), dim3(256), smem, (hipStream_t)stream,            \
                        (const uint16_t*)qpool, (const uint16_t*)kpool, neighbors, (int)nb_rows, (int)nb_cols, mask,   \
-                       idx, cnt, (int)H, (int)nq, (int)nk_img, (int)text_blocks, (int)top_k, p_thr,                   \
-                       (int)first_frame_blocks, npow2, scan_log_nx)
+                       idx, cnt, (int)BH, (int)nq, (int)nk_img, (int)text_blocks, (int)top_k, p_thr,                  \
+                       (int)first_frame_blocks, npow2, scan_log_nx, (int)ngrp, xcd_map)
     if (dtype == JENGA_BF16) LAUNCH_SEL(BF16); else LAUNCH_SEL(FP16);
 #undef LAUNCH_SEL
     hipError_t e = hipGetLastError();

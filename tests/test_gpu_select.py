@@ -248,3 +248,101 @@ def test_device_scan_mode_equals_torch_device_cumsum(dev, H, nq, nimg, dt):
                              flat_kept_device_scan=int(cnt[0, 0, 0]), flat_kept_cpu_semantics=int(cnt_cpu[0, 0, 0]))
         assert same >= 0.99, (p, same)
     _record("cumsum_device_scan.json", {f"H{H}_nq{nq}_n{nimg}_{dt}": rec})
+
+
+def _stage_shape_properties(dev, flavour, grid, H, valid_text, rate, p, text_amp, tag, seed):
+    """Full-size property + sampled-row check of one stage shape through the public op (HY: S % 128 == 0, text_blocks 2;
+    I2V: ragged S padded to whole blocks, text_blocks 4):
+      (a) V == 1 -> every valid row is 1 within a bf16 ulp, rows at or behind the kv length are 0 (HY) / sliced off;
+      (b) mask invariants: neighbours and text columns kept, at least top_k image blocks per row;
+      (c) kept lists vs the oracle's selection from the HIP pooled means on sampled query blocks (Hamming 0);
+      (d) sampled query blocks of the real op vs the oracle's sparse_rows on their kept blocks (text_amp, kv-length mask)."""
+    from jenga_amd import gilbert as G
+    from jenga_amd.modules import attention_block_sparse as op
+    from oracle import attention as oa
+    t, h, w = grid
+    S_img = t * h * w
+    tb = 2 if flavour == "hy" else 4
+    S_txt = 256 if flavour == "hy" else 512
+    S = S_img + S_txt
+    pad = (128 - S % 128) % 128
+    nb = (S + pad) // 128
+    nimg = nb - tb
+    assert flavour != "hy" or pad == 0
+    nbm = G.gilbert_block_neighbor_mapping(t, h, w, as_tensor=True)
+    assert nbm.shape[0] == nimg, (nbm.shape, nimg)
+    g = torch.Generator(device=dev).manual_seed(seed)
+    cent = torch.randn(1, nb, 1, H, 128, generator=g, device=dev) * 0.8
+    q = (torch.randn(1, nb, 128, H, 128, generator=g, device=dev) + cent[:, torch.randint(0, nimg, (nb,), device=dev)])
+    k = torch.randn(1, nb, 128, H, 128, generator=g, device=dev) + cent
+    q = q.view(1, nb * 128, H, 128)[:, :S].to(torch.bfloat16).contiguous()
+    k = k.view(1, nb * 128, H, 128)[:, :S].to(torch.bfloat16).contiguous()
+    top_k = int((1 - rate) * nimg)
+    seqlen = S_img + valid_text
+    cu = torch.tensor([0, seqlen, S], dtype=torch.int32, device=dev)
+    fn = op.block_sparse_attention if flavour == "hy" else op.block_sparse_attention_i2v
+    kw = dict(cu_seqlens_q=cu, cu_seqlens_kv=cu, text_blocks=tb, text_amp=text_amp, block_neighbor_list=nbm,
+              p_remain_rates=p, shape_xfuse=True)
+    ones = torch.ones(1, S, H, 128, device=dev, dtype=torch.bfloat16)
+    o1, mask = fn(q, k, ones, top_k, return_mask=True, **kw)
+    assert o1.shape == (1, S, H, 128)
+    text0 = nimg * 128                        # first row of the text query blocks (every text row sees every key, no mask)
+    lim = min(seqlen, text0)
+    assert torch.all((o1[:, :lim].float() - 1).abs() <= 2 ** -7), (o1[:, :lim].float() - 1).abs().max().item()
+    assert torch.all(o1[:, lim:text0] == 0)                                       # image-block rows behind the kv length
+    assert torch.all((o1[:, text0:].float() - 1).abs() <= 2 ** -7)
+    m = mask.bool()
+    assert m.shape == (1, H, nimg, nb)
+    assert (m[..., :nimg] & nbm.to(dev)[None, None]).sum() == nbm.sum() * H      # neighbours kept
+    assert m[..., nimg:].all()                                                    # text columns kept
+    assert int(m[..., :nimg].sum(-1).min()) >= min(top_k, nimg)
+    # (c)
+    qp_ = torch.nn.functional.pad(q, [0, 0, 0, 0, 0, pad])
+    kp_ = torch.nn.functional.pad(k, [0, 0, 0, 0, 0, pad])
+    rows = list(range(0, nimg, max(1, nimg // 12))) + [0, 1, nimg - 2, nimg - 1]
+    _compare_with_oracle_from_pooled(dev, qp_, kp_, nimg, tb, top_k, p, nbm, 0, rows, tag)
+    # (d)
+    v = torch.randn(1, S, H, 128, generator=g, device=dev).to(torch.bfloat16)
+    o = fn(q, k, v, top_k, **kw)
+    vp_ = torch.nn.functional.pad(v, [0, 0, 0, 0, 0, pad])
+    mc = m.cpu().numpy()
+    worst = 0.0
+    for (hh, mq) in [(0, 0), (1, nimg // 3), (0, nimg - 1), (1, nimg // 2 + 1), (H - 1, 7)]:
+        blocks = np.nonzero(mc[0, hh, mq])[0].tolist()
+        n = len(blocks)
+        assert blocks[-tb:] == list(range(nimg, nb))
+        kk = torch.cat([kp_[0, b * 128:(b + 1) * 128, hh] for b in blocks]).float().cpu().numpy()[None, None]
+        vv = torch.cat([vp_[0, b * 128:(b + 1) * 128, hh] for b in blocks]).float().cpu().numpy()[None, None]
+        qq = qp_[0, mq * 128:(mq + 1) * 128, hh].float().cpu().numpy()[None, None]
+        # the kept image blocks lie entirely in front of the kv length except (I2V) the last image block, which holds the
+        # first text tokens; behind them come the tb text blocks: compacted kv length = whole blocks + what is left
+        full = sum(1 for b in blocks if (b + 1) * 128 <= seqlen)
+        part = [b for b in blocks if b * 128 < seqlen < (b + 1) * 128]
+        assert blocks[:full] == [b for b in blocks if (b + 1) * 128 <= seqlen]
+        seq_c = full * 128 + (seqlen - part[0] * 128 if part else 0)
+        ref = oa.sparse_rows(qq, kk, vv, [seq_c], np.ones((1, 1, 1, n), bool), 128 ** -0.5, "bfloat16", text_amp, n - tb)
+        rows_valid = min(128, max(0, seqlen - mq * 128))
+        got = o[0, mq * 128:mq * 128 + rows_valid, hh].float().cpu().numpy()
+        err = float(np.abs(got - ref[0, 0, :rows_valid]).max()) if rows_valid else 0.0
+        worst = max(worst, err)
+        assert err <= 2e-2, (tag, hh, mq, err)
+    _record("stage_shapes_full_size.json", {tag: dict(grid=list(grid), flavour=flavour, S=S, blocks=nb, image_blocks=nimg,
+                                                       top_k=top_k, p=p, text_amp=text_amp, heads=H,
+                                                       sampled_rows_max_abs_err=worst)})
+
+
+@pytest.mark.parametrize("case", [
+    # BASELINE.json configs[2] (Turbo), stage 0: 32x33x60 = 495 image blocks, sa-drop 0.75, text_amp = -log2(sqrt(1980/3600))
+    ("hy", (32, 33, 60), 2, 64, 0.75, 0.3, 0.431, "turbo_stage0_495blk_amp0.431"),
+    # configs[4] (3-stage), stage 0 at res-rate 0.5: 32x22x40 = 220 image blocks, text_amp = -log2(sqrt(880/3600)) = 1.016
+    ("hy", (32, 22, 40), 2, 256, 0.75, 0.3, 1.016, "stage_res0.5_220blk_amp1.016"),
+    # configs[4], I2V flavour at its 720p x 129-frame token count: 33x45x80 = 118 800 image tokens + 512 text tokens =
+    # 119 312, NOT a multiple of 128 (padded to 933 blocks; the last image block holds the first text tokens), text_blocks 4
+    ("i2v", (33, 45, 80), 2, 300, 0.85, 0.3, 0.0, "i2v_720p_129f_933blk_tb4"),
+], ids=lambda c: c[-1])
+def test_stage_shapes_of_configs_3_and_5_at_full_size(dev, case):
+    """the 495-block and 220-block stages, the stage-0 text_amp at full size, and I2V text_blocks = 4 at
+    the 720p I2V token count with a ragged S were only touched by bench.py runs.  Reference lines:
+    pipeline_hunyuan_video_prores.py:577, 697-767 (stage shapes, text_amp), hyvideo_i2v/...diffres.py:323-328 (padding)."""
+    flavour, grid, H, valid_text, rate, p, amp, tag = case
+    _stage_shape_properties(dev, flavour, grid, H, valid_text, rate, p, amp, tag, seed=21 + grid[1])

@@ -22,6 +22,21 @@ B)  # pair kernel v2 (V^T ring of three, work-aware order): parity, A/B, counter
   timeout 600 bash tools/pmc_attn2.sh r05_lp_coh --drop 0.7 --iters 2 --attn-only --coherent 3 --gain 2 --flags 29 > $O/pmc_lp.log 2>&1; grep -A14 '"derived"' $O/pmc_lp.log | head -24
   JENGA_ATTN_FLAGS=85 timeout 600 python bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-dense-ref --no-wan-extra --no-secondary > $O/bench6_pair.json 2> $O/bench6_pair.err; python tools/ab_print.py $O/bench6_pair.json
   ;;
+D)  # selection kernel + the hardened parity tests
+  timeout 1200 python -m pytest tests/test_gpu_select.py -x -q -m gpu > $O/pytest_select.log 2>&1; tail -4 $O/pytest_select.log
+  timeout 1200 python -m pytest tests/test_gpu_parity.py -x -q -m gpu > $O/pytest_parity.log 2>&1; tail -4 $O/pytest_parity.log
+  timeout 200 python tools/bench_attn.py --drop 0.7 --iters 20 > $O/sel_flat.json 2> $O/sel_flat.err; python -c "import json;d=json.loads(open('$O/sel_flat.json').read().strip().splitlines()[-1]);print('select_ms',d['select_ms'],'pool_ms',d['pool_ms'])"
+  timeout 200 python tools/bench_attn.py --drop 0.7 --iters 20 --coherent 3 --gain 2 > $O/sel_coh.json 2> $O/sel_coh.err; python -c "import json;d=json.loads(open('$O/sel_coh.json').read().strip().splitlines()[-1]);print('select_ms',d['select_ms'],'pool_ms',d['pool_ms'])"
+  python __graft_entry__.py --smoke 2>&1 | tail -2
+  ;;
+E)  # selection kernel: rows per workgroup and elimination builds (clock only)
+  for lib in ${LIBS:-base g1 g2 g8 sx1 sx2 sx4 sx8 sx15}; do
+    if [ "$lib" = base ]; then unset JENGA_LIB; else export JENGA_LIB=$PWD/alt_libs/$lib.so; fi
+    for L in "--drop 0.7" "--drop 0.7 --coherent 3 --gain 2"; do
+      timeout 100 python tools/bench_attn.py $L --iters 20 --flags 29 2> $O/$lib.err | python -c "import json,sys;d=json.loads(sys.stdin.read().strip().splitlines()[-1]);print('$lib', '$L', 'select_ms %.4f kept %.1f' % (d['select_ms'], d['kept_mean']))"
+    done
+  done
+  ;;
 C)  # elimination builds of the pair kernel (wrong results, clock only): what the LDS-DMA issue and the step barrier cost
   A="--drop 0.7 --iters 30 --attn-only --coherent 3 --gain 2 --flags 85"
   for lib in ${LIBS:-base nodma nobar nodmabar}; do
