@@ -96,6 +96,9 @@ def parse():
     ap.add_argument("--no-wan-extra", action="store_true",
                     help="skip the short Wan2.1-14B leg (one forward at each drop rate, after the timed region) that puts a "
                          "configs[3] number into the default N=1 record")
+    ap.add_argument("--no-xgmi-extras", action="store_true",
+                    help="N > 1: skip the legs behind the timed region that fill `roofline_xgmi` (the exchanges timed alone, one "
+                         "computed step per stage without the fabric, rank 0's single-rank steps for `efficiency`)")
     ap.add_argument("--no-other-kernel-ref", action="store_true",
                     help="skip the computed steps re-run after the timed region with the OTHER attention kernel (LP <-> pair)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -814,14 +817,27 @@ def main():
         if dist_on:
             # every rank timed candidates on its own: adopt rank 0's choices everywhere, so that the replicated text stream
             # sees the same arithmetic on every rank (the imported index replaces each rank's plan; no further timing)
-            try:
-                rec = _capi.linear_export_choices() if rank == 0 else None
-                box = [rec]
-                dist.broadcast_object_list(box, src=0)
-                _capi.linear_import_choices(box[0])
-            except Exception as e:      # noqa: BLE001 - a measurement convenience must not end the run
-                print(f"bench.py: rank {rank}: adopting rank 0's GEMM choices failed ({e!r}); every rank keeps its own",
-                      file=sys.stderr)
+            # (every rank ALWAYS enters both collectives: a failed export travels as None, a failed import is counted)
+            rec = None
+            if rank == 0:
+                try:
+                    rec = _capi.linear_export_choices()
+                except Exception as e:      # noqa: BLE001 - a measurement convenience must not end the run
+                    print(f"bench.py: exporting rank 0's GEMM choices failed ({e!r})", file=sys.stderr)
+            box = [rec]
+            dist.broadcast_object_list(box, src=0)
+            ok_ = 0
+            if box[0] is not None:
+                try:
+                    _capi.linear_import_choices(box[0])
+                    ok_ = 1
+                except Exception as e:      # noqa: BLE001
+                    print(f"bench.py: rank {rank}: adopting rank 0's GEMM choices failed ({e!r})", file=sys.stderr)
+            okt = torch.tensor([ok_], device=dev, dtype=torch.int32)
+            dist.all_reduce(okt, op=dist.ReduceOp.MIN)
+            gemm_choices_synced = bool(okt.item())
+    if "gemm_choices_synced" not in locals():
+        gemm_choices_synced = None       # (single rank, or no candidate timing: nothing to synchronise)
     for w in range(a.warmup):
         run_step(computed_steps[0] if w % 2 == 0 else computed_steps[-1])   # computed steps: fills previous_residual
     barrier()
@@ -897,6 +913,97 @@ def main():
         finally:
             _capi.ATTN_DEFAULT_FLAGS = flags0
             _capi.ATTN_PROFILE = None
+
+    # ---- N > 1: what the exchange costs, measured (NOT in the timed region).  Reference: xdit_ring_atten.py:118-131,
+    #      212-217 (6 all-to-alls per layer); here per layer: Q|K, V, O all-to-alls + the text all-gather (ulysses.py)
+    xgmi_raw = None
+    if dist_on and not a.no_xgmi_extras and a.preset != "dense":
+        sp_blocks = [b for b in list(model.double_blocks) + list(model.single_blocks) if b.hybrid_seq_parallel_attn]
+        ex0 = sp_blocks[0].hybrid_seq_parallel_attn.exchange()
+        Hh_, D_ = model.heads_num, 128
+        Hn_ = Hh_ // world
+        xgmi_raw = {"mode": ex0.mode, "stages": [], "bytes_counted": sum(b.hybrid_seq_parallel_attn.exchange().bytes_out for b in sp_blocks),
+                    "exchange_calls_counted": sum(b.hybrid_seq_parallel_attn.exchange().calls for b in sp_blocks)}
+        for k in range(len(stages)):
+            S_img_k = stages[k]["h2l"].numel()
+            S_loc_k = S_img_k // world
+            mk_ = lambda *shape: torch.empty(shape, dtype=torch.bfloat16, device=dev)
+            snd = [mk_(world, S_loc_k, Hn_, D_) for _ in range(4)]
+            rcv = [mk_(world, S_loc_k, Hn_, D_) for _ in range(4)]
+            tx, tall = mk_(1, n_txt, Hn_, D_), mk_(world, 1, n_txt, Hn_, D_)
+            bytes_layer = 4 * snd[0].numel() * 2 * (world - 1) // world + tx.numel() * 2 * (world - 1)
+
+            def one_layer():
+                ws = ex0.all_to_all(rcv[:2], snd[:2]) + ex0.all_to_all(rcv[2:3], snd[2:3])
+                for w_ in ws:
+                    w_.wait()
+                ws = ex0.all_to_all(rcv[3:4], snd[3:4])
+                wt = ex0.all_gather(tall, tx)
+                for w_ in ws:
+                    w_.wait()
+                wt.wait()
+            for _ in range(3):
+                one_layer()
+            barrier()
+            reps = 20
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                one_layer()
+            e1.record()
+            barrier()
+            alone_ms = e0.elapsed_time(e1) / reps
+            # one computed step of this stage with the real exchange and one with every transfer replaced by a local copy
+            i_k = next(i for i in computed_steps if stage_of(i, split) == k and i not in forced)
+
+            def timed_step():
+                barrier()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                run_step(i_k)
+                e1.record()
+                barrier()
+                tt_ = torch.tensor([e0.elapsed_time(e1)], device=dev, dtype=torch.float64)
+                dist.all_reduce(tt_, op=dist.ReduceOp.MAX)
+                return float(tt_.item())
+            with_ms = timed_step()
+            saved = [b.hybrid_seq_parallel_attn._exchange for b in sp_blocks]
+            nofab = ulysses.NoFabricExchange(world, rank)
+            for b in sp_blocks:
+                b.hybrid_seq_parallel_attn._exchange = nofab
+            try:
+                without_ms = timed_step()
+            finally:
+                for b, e_ in zip(sp_blocks, saved):
+                    b.hybrid_seq_parallel_attn._exchange = e_
+            xgmi_raw["stages"].append(dict(stage=k, S_loc=S_loc_k, bytes_out_per_layer=bytes_layer, exchange_alone_ms=alone_ms,
+                                           step_ms=with_ms, step_ms_without_fabric=without_ms))
+        # rank 0 alone: the single-rank model on the same box, one computed + one skipped step per stage (`efficiency`)
+        n1 = {}
+        if rank == 0:
+            saved_sp = [b.hybrid_seq_parallel_attn for b in sp_blocks]
+            for b in sp_blocks:
+                b.hybrid_seq_parallel_attn = None
+            try:
+                for k in range(len(stages)):
+                    i_c = next(i for i in computed_steps if stage_of(i, split) == k and i not in forced)
+                    i_s = next((i for i in range(50) if stage_of(i, split) == k and i not in computed_steps), None)
+                    run_step(i_c)                      # plans for the full-M GEMM shapes, the residual cache
+                    torch.cuda.synchronize()
+                    for key_, i_ in (("c", i_c), ("s", i_s)):
+                        if i_ is None:
+                            continue
+                        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                        e0.record()
+                        run_step(i_)
+                        e1.record()
+                        torch.cuda.synchronize()
+                        n1[(k, key_)] = e0.elapsed_time(e1)
+            finally:
+                for b, sp_ in zip(sp_blocks, saved_sp):
+                    b.hybrid_seq_parallel_attn = sp_
+        barrier()
+        xgmi_raw["n1"] = n1
 
     cls = {}
     for i, e0, e1 in evs:
@@ -1039,6 +1146,53 @@ def main():
             "note": "one computed step per stage after the timed region; estimate = the timed run's skipped-step classes + "
                     "these computed-step times x their counts"}
     res["loop"] = loop
+    if gemm_choices_synced is not None:
+        res["config"]["gemm_choices_synchronized_across_ranks"] = gemm_choices_synced
+    if xgmi_raw is not None:
+        LINK_GBPS = 153.6                      # one xGMI link, one direction (MI355X_MICROARCH.md: 7 links x ~153 GB/s per GPU)
+        layers = len(model.double_blocks) + len(model.single_blocks)
+        st_recs = []
+        for sr in xgmi_raw["stages"]:
+            ach = sr["bytes_out_per_layer"] / max(sr["exchange_alone_ms"], 1e-9) / 1e6
+            exposed = max(0.0, sr["step_ms"] - sr["step_ms_without_fabric"])
+            st_recs.append({"stage": sr["stage"], "S_loc": sr["S_loc"], "bytes_out_per_rank_per_layer": sr["bytes_out_per_layer"],
+                            "exchange_alone_ms_per_layer": round(sr["exchange_alone_ms"], 4),
+                            "achieved_GBps_per_rank": round(ach, 1),
+                            "frac_of_peak": round(ach / max((world - 1) * LINK_GBPS, 1e-9), 4) if world > 1 else None,
+                            "computed_step_ms": round(sr["step_ms"], 2),
+                            "computed_step_ms_without_fabric": round(sr["step_ms_without_fabric"], 2),
+                            "exposed_ms_per_computed_step": round(exposed, 2),
+                            "hidden_frac": round(1.0 - exposed / max(layers * sr["exchange_alone_ms"], 1e-9), 4)})
+        n1 = xgmi_raw["n1"]
+        n1_spv = None
+        if n1:
+            def n1_ms(key):
+                if key in n1:
+                    return n1[key]
+                same = [v for kk, v in n1.items() if kk[1] == key[1]]
+                return same[-1] if same else 0.0
+            n1_spv = sum(n * n1_ms(key) for key, n in counts.items()) / 1e3
+        res["roofline_xgmi"] = {
+            "bound": "xgmi", "ranks": world, "backend": "nccl (RCCL)", "exchange_mode": xgmi_raw["mode"],
+            "exchange": "per layer: Q|K all-to-all, V all-to-all, O all-to-all, text all-gather (jenga_amd/modules/ulysses.py; "
+                        "reference xdit_ring_atten.py:118-131, 212-217)",
+            "algorithmic_bytes": "bytes leaving a rank per layer = 4 x (N-1)/N x S_loc x H x 128 x 2 (Q, K, V, O) + (N-1) x "
+                                 "S_txt x H/N x 128 x 2 (text rows of the rank's heads to every peer)",
+            "peak_GBps_per_rank": round(max(world - 1, 0) * LINK_GBPS, 1), "peak_source": "(N-1) links x 153.6 GB/s, one direction "
+                                  "(MI355X_MICROARCH.md: 7 x ~153 GB/s per GPU; a full mesh, every peer message rides its own link)",
+            "unit": "GB/s", "stages": st_recs,
+            "how": "exchange_alone: the layer's four collectives with buffers of the layer's shapes, nothing else on the GPU, 20 "
+                   "repetitions between two HIP events (the compute stream only waits for RCCL's stream, so the elapsed time "
+                   "IS the time on RCCL's stream); exposed: one computed step with the real exchange minus the same step with "
+                   "every transfer replaced by a local copy (NoFabricExchange), max over ranks; hidden_frac = 1 - exposed / "
+                   "(layers x exchange_alone)",
+            "bytes_out_counted_rank0_all_steps": xgmi_raw["bytes_counted"], "exchange_calls_counted_rank0": xgmi_raw["exchange_calls_counted"],
+            "n1_same_session": None if n1_spv is None else {
+                "s_per_video": round(n1_spv, 3),
+                "how": "rank 0, the other ranks idle: the single-rank model (all heads, whole sequence) on the same box, one "
+                       "computed and one skipped step per stage x their counts in the 50-step schedule"},
+            "efficiency": None if n1_spv is None else round(n1_spv / max(world * sec_per_video, 1e-9), 4),
+            "efficiency_note": "T_1 / (N x T_N) with T_1 from n1_same_session; the driver computes its own from its per-N runs"}
     if power_rec is not None:
         res["power"] = power_rec
     if dense_ms is not None:

@@ -295,7 +295,7 @@ def sp_qkv_prologue(xq, xk, xv, wq, wk, cos, sin, out_q, out_k, out_v, heads_per
                     s_rope=None, eps=1e-6):
     """Sequence-parallel prologue: per-head RMSNorm + RoPE of Q and K and the Ulysses head scatter of Q, K, V in one
     launch.  xq, xk, xv [B,S,H,128] with the SAME strides (any S).  Outputs, all of one shape and stride set:
-      peer-major send buffers [N,B,S,H/N,128] (contiguous; head0 = 0, all heads), or
+      peer-major send buffers [N,B,S,H/N,128] (head0 = 0, all heads; contiguous or any 16-byte-aligned strides), or
       [B,S,n_heads,128] views (any strides) receiving the head window [head0, head0 + n_heads) -- a rank's own slice
       of the replicated text rows, written in place behind the gathered image rows.
     Either (xq, xk, out_q, out_k) or (xv, out_v) may be None: the blocks run the Q|K and the V GEMM separately and post
@@ -319,8 +319,10 @@ def sp_qkv_prologue(xq, xk, xv, wq, wk, cos, sin, out_q, out_k, out_v, heads_per
     if o0.dim() == 5:
         N = o0.shape[0]
         if head0 != 0 or n_heads != H or tuple(o0.shape) != (N, B, S, Hn, 128) or N * Hn != H \
-                or not o0.is_contiguous():
-            raise ValueError("sp_qkv_prologue: peer-major outputs must be contiguous [N, B, S, H/N, 128]")
+                or o0.stride(4) != 1 or any(st % 8 for st in o0.stride()[:4]):
+            raise ValueError("sp_qkv_prologue: peer-major outputs must be [N, B, S, H/N, 128] (unit inner stride; the "
+                             "other strides multiples of 8 elements: contiguous, or the head-group-major view of the "
+                             "pipelined sequence-parallel call)")
         o_sp, o_sb, o_ss, o_sh = o0.stride(0), o0.stride(1), o0.stride(2), o0.stride(3)
     else:
         if tuple(o0.shape) != (B, S, n_heads, 128) or n_heads > Hn or head0 % Hn + n_heads > Hn:

@@ -29,6 +29,13 @@ its own independent GEMMs between posting and `finish()`; `finish(while_out=...)
 exchange.  The reference issues everything on one stream (xdit_ring_atten.py:118-131, 212-217).  `forward` (reference
 signature) and `forward_qkv` are begin + post + finish in one call.
 
+Round 5: (a) `JENGA_ULYSSES_PIPELINE=1` / `UlyssesAttenCarve(pipeline=True)`: the rank's H/N heads are exchanged and attended
+ONE HEAD AT A TIME -- head g's attention runs while head g+1's Q, K, V are still in flight and head g's O exchange rides
+under head g+1's attention; the fallback DESIGN.md section 6 names for a fabric that sustains less than the exchange needs.
+Selection and attention are per head, so the result is bit-identical to the unpipelined call (tests/test_gpu_ulysses.py);
+the price is H/N attention launches of one head each (launch tails), which is why it is opt-in.  (b) every exchange object
+counts the bytes that leave the rank (`bytes_out`, `calls`): bench.py's `roofline_xgmi` record reads them.
+
 The exchange object is injectable (`exchange=`): tests drive N simulated ranks in one process on one GPU with an exchange
 that really permutes the chunks (tests/test_gpu_ulysses.py, test_gpu_sp_dit.py), bench.py --simulate-ranks replays the
 transfers as side-stream delays, the world_size-2 gloo test and tests/test_gpu_rccl.py exercise the collectives themselves.
@@ -166,6 +173,8 @@ class DistExchange:
         self.mode = mode or os.environ.get("JENGA_ULYSSES_EXCHANGE", "p2p")
         if self.mode not in ("p2p", "a2a"):
             raise ValueError("JENGA_ULYSSES_EXCHANGE must be 'p2p' (one grouped exchange) or 'a2a'")
+        self.bytes_out = 0       # bytes that left this rank through this object (algorithmic: (N-1)/N of every send buffer)
+        self.calls = 0
 
     def size(self):
         return dist.get_world_size(self.group)
@@ -177,6 +186,8 @@ class DistExchange:
         """recvs[i], sends[i]: [N, ...] contiguous, chunk p of sends[i] goes to rank p and chunk p of recvs[i] comes
         from rank p -- for ALL i in one grouped exchange ("p2p") or one all_to_all_single per tensor ("a2a")."""
         N, r = self.size(), self.rank()
+        self.calls += 1
+        self.bytes_out += sum(sd.numel() * sd.element_size() for sd in sends) * (N - 1) // N
         if N == 1:
             for rc, sd in zip(recvs, sends):
                 rc.copy_(sd)
@@ -194,11 +205,40 @@ class DistExchange:
 
     def all_gather(self, out, x):
         """out [N, ...] <- x from every rank."""
+        self.calls += 1
+        self.bytes_out += x.numel() * x.element_size() * (self.size() - 1)
         if self.size() == 1:
             out[0].copy_(x)
             return _Done()
         x = x.contiguous()   # (gloo wants the output as the inputs stacked along dim 0 of the INPUT's rank)
         return dist.all_gather_into_tensor(out.view((-1,) + tuple(x.shape[1:])), x, group=self.group, async_op=True)
+
+
+class NoFabricExchange:
+    """Measurement aid (bench.py `roofline_xgmi.exposed_ms`): the exchanges of one rank of an N-rank job with every
+    transfer replaced by a local copy of the same shape -- same kernels, same launch structure, no fabric.  The RESULTS are
+    wrong by construction (every peer's chunk is a copy of this rank's); only the clock is read: step time with the real
+    exchange minus step time with this one = the exchange time the step could not hide."""
+
+    def __init__(self, n, rank=0):
+        self.n, self.r = n, rank
+        self.bytes_out = 0
+        self.calls = 0
+
+    def size(self):
+        return self.n
+
+    def rank(self):
+        return self.r
+
+    def all_to_all(self, recvs, sends):
+        for rc, sd in zip(recvs, sends):
+            rc.copy_(sd)
+        return [_Done()]
+
+    def all_gather(self, out, x):
+        out.copy_(x.unsqueeze(0).expand_as(out))
+        return _Done()
 
 
 def _wait_all(works):
@@ -234,9 +274,11 @@ class UlyssesAttenCarve(torch.nn.Module):
       prologue_fn(xq, xk, xv, wq, wk, cos, sin, (oq, ok, ov), H/N, head0, n_heads, s_rope)"""
 
     def __init__(self, group=None, select_fn=None, attend_fn=None, pack_fn=None, unpack_fn=None, exchange=None,
-                 prologue_fn=None):
+                 prologue_fn=None, pipeline=None):
         super().__init__()
         self.group = group
+        # one head at a time (module docstring, round 5); default from JENGA_ULYSSES_PIPELINE
+        self.pipeline = (os.environ.get("JENGA_ULYSSES_PIPELINE", "0") == "1") if pipeline is None else bool(pipeline)
         self.select_fn = select_fn or _hip_select
         self.attend_fn = attend_fn or _hip_attend
         self.pack_fn = pack_fn or _pack_heads
@@ -252,7 +294,16 @@ class UlyssesAttenCarve(torch.nn.Module):
     # ---- local stages ------------------------------------------------------------------------------------------
     def stage_out(self, o_recv, txt_all, N, S_loc, S_txt, dtype, device, out=None):
         """o_recv [N,S_loc,Hn,D] (chunk p = my tokens, rank p's heads), txt_all [N,1,S_txt,Hn,D] -> [1,S_loc+S_txt,H,D]
-        (written into `out` when given: may be a strided view, e.g. the left part of linear2's concat buffer)."""
+        (written into `out` when given: may be a strided view, e.g. the left part of linear2's concat buffer).
+        Pipelined call: lists of per-head tensors (Hn entries with one head each); head g of every peer p is head
+        p * Hn + g of the result -- a strided head view of it."""
+        if isinstance(o_recv, (list, tuple)):
+            G, D = len(o_recv), o_recv[0].shape[-1]
+            result = out if out is not None else torch.empty((1, S_loc + S_txt, N * G, D), dtype=dtype, device=device)
+            for g in range(G):
+                self.unpack_fn(o_recv[g].view(N, 1, S_loc, 1, D), N, result[:, :S_loc, g::G])
+                self.unpack_fn(txt_all[g], N, result[:, S_loc:, g::G])
+            return result
         Hn, D = o_recv.shape[-2:]
         result = out if out is not None else torch.empty((1, S_loc + S_txt, N * Hn, D), dtype=dtype, device=device)
         self.unpack_fn(o_recv.view(N, 1, S_loc, Hn, D), N, result[:, :S_loc])
@@ -326,42 +377,69 @@ class PendingAttenCarve:
         self.B, self.S_loc, self.H, self.S_txt, self.D = B, S_loc, H, S_txt, D
         self.Hn, self.S_img = H // N, S_loc * N
         self.dtype, self.device = dtype, device
+        # head groups: 1 (all H/N heads of the rank in one exchange / one attention launch) or, pipelined, H/N groups of one
+        # head.  Everything is allocated group-major -- [G, B, S, hg, D] attention inputs, [G, N, B, S_loc, hg, D] send
+        # buffers -- so that a group's chunks are contiguous messages; with G == 1 that IS the round-4 layout.
+        self.G = self.Hn if (sp.pipeline and self.Hn > 1) else 1
+        self.hg = self.Hn // self.G
         mk = lambda shape: torch.empty(shape, dtype=dtype, device=device)
-        self.fulls = [mk((B, self.S_img + S_txt, self.Hn, D)) for _ in range(3)]
-        self.recvs = [f[0, :self.S_img].view(N, S_loc, self.Hn, D) for f in self.fulls]
+        self.alloc = [mk((self.G, B, self.S_img + S_txt, self.hg, D)) for _ in range(3)]
+        self.fulls = [[a[g] for a in self.alloc] for g in range(self.G)]                  # [g][q|k|v] -> [B, S, hg, D]
+        self.recvs = [[f[0, :self.S_img].view(N, S_loc, self.hg, D) for f in fg] for fg in self.fulls]
         self.sends = [None, None, None]
         self.w_qk = self.w_v = None
 
     def _send_buffers(self, which):
         for i in which:
-            self.sends[i] = torch.empty((self.N, self.B, self.S_loc, self.Hn, self.D), dtype=self.dtype,
+            self.sends[i] = torch.empty((self.G, self.N, self.B, self.S_loc, self.hg, self.D), dtype=self.dtype,
                                         device=self.device)
-        return [self.sends[i] for i in which]
+        return [self._peer_major(self.sends[i]) for i in which]
 
-    def _views(self, which):
-        return [self.sends[i].view(self.N, self.S_loc, self.Hn, self.D) for i in which]
+    def _peer_major(self, t):
+        """[G, N, B, S_loc, hg, D] -> the [N, B, S_loc, H/N, D] view the prologue kernel writes through its strides
+        (contiguous for G == 1; for one head per group the head axis IS the group axis)."""
+        return t[0] if self.G == 1 else t[:, :, :, :, 0].permute(1, 2, 3, 0, 4)
+
+    def _text_view(self, i):
+        """[B, S_txt, H/N, D] view of the text rows of attention input i over all groups."""
+        a = self.alloc[i]
+        return a[0][:, self.S_img:] if self.G == 1 else a[:, :, self.S_img:, 0].permute(1, 2, 0, 3)
+
+    def _views(self, which, g):
+        return [self.sends[i][g].view(self.N, self.S_loc, self.hg, self.D) for i in which]
+
+    def _post(self, which):
+        """One exchange per head group, in group order: group g's messages are complete before group g + 1's."""
+        return [self.ex.all_to_all([self.recvs[g][i] for i in which], self._views(which, g)) for g in range(self.G)]
 
     def post_qk(self, q, k, norm_w, freqs_cis):
         cos, sin = freqs_cis
         oq, ok = self._send_buffers((0, 1))
         self.sp.prologue_fn(q, k, None, norm_w[0], norm_w[1], cos, sin, [oq, ok, None], self.Hn, 0, self.H, self.S_loc)
-        self.w_qk = self.ex.all_to_all(self.recvs[:2], self._views((0, 1)))
+        self.w_qk = self._post((0, 1))
 
     def post_v(self, v):
         (ov,) = self._send_buffers((2,))
         self.sp.prologue_fn(None, None, v, None, None, None, None, [None, None, ov], self.Hn, 0, self.H, 0)
-        self.w_v = self.ex.all_to_all(self.recvs[2:], self._views((2,)))
+        self.w_v = self._post((2,))
 
     def post_qkv(self, q, k, v, norm_w, freqs_cis):
         cos, sin = freqs_cis
         outs = self._send_buffers((0, 1, 2))
         self.sp.prologue_fn(q, k, v, norm_w[0], norm_w[1], cos, sin, outs, self.Hn, 0, self.H, self.S_loc)
-        # Q + K first, V behind them on the communication stream (the V transfer overlaps pooling + selection)
-        self.w_qk = self.ex.all_to_all(self.recvs[:2], self._views((0, 1)))
-        self.w_v = self.ex.all_to_all(self.recvs[2:], self._views((2,)))
+        # Q + K first, V behind them on the communication stream (the V transfer overlaps pooling + selection); pipelined:
+        # group by group, so that head g is complete before head g + 1 starts to arrive
+        if self.G == 1:
+            self.w_qk = self._post((0, 1))
+            self.w_v = self._post((2,))
+        else:
+            self.w_qk, self.w_v = [], []
+            for g in range(self.G):
+                self.w_qk.append(self.ex.all_to_all([self.recvs[g][0], self.recvs[g][1]], self._views((0, 1), g)))
+                self.w_v.append(self.ex.all_to_all([self.recvs[g][2]], self._views((2,), g)))
 
     def put_text(self, q, k, v, norm_w):
-        outs = [f[:, self.S_img:] for f in self.fulls]
+        outs = [self._text_view(i) for i in range(3)]
         if v.stride() == q.stride():
             self.sp.prologue_fn(q, k, v, norm_w[0], norm_w[1], None, None, outs, self.Hn, self.r * self.Hn, self.Hn, 0)
         else:       # Q|K and V come from two GEMM outputs with different row strides: one launch each
@@ -372,42 +450,51 @@ class PendingAttenCarve:
 
     def post_packed(self, query, key, value, jq, jk, jv):
         """The reference-signature path: already normalised / rotated tensors, separate pack kernels."""
+        if self.G != 1:
+            raise RuntimeError("the reference-signature call (forward) has no head-group pipeline: use begin() / forward_qkv")
         hs = slice(self.r * self.Hn, (self.r + 1) * self.Hn)
         for i, (t, joint) in enumerate(((query, jq), (key, jk), (value, jv))):
-            self.sends[i] = self.sp.pack_fn(t, self.N)
-            self.fulls[i][:, self.S_img:] = joint[:, :, hs]    # text is replicated on every rank: slice my heads
-        self.w_qk = self.ex.all_to_all(self.recvs[:2], self._views((0, 1)))
-        self.w_v = self.ex.all_to_all(self.recvs[2:], self._views((2,)))
+            self.sends[i] = self.sp.pack_fn(t, self.N).view(1, self.N, self.B, self.S_loc, self.Hn, self.D)
+            self.fulls[0][i][:, self.S_img:] = joint[:, :, hs]    # text is replicated on every rank: slice my heads
+        self.w_qk = self._post((0, 1))
+        self.w_v = self._post((2,))
 
     def finish(self, *, top_k=0, text_amp=0.0, block_neighbor_list=None, p_remain_rates=0.0, cu_seqlens_q=None,
                out=None, while_out=None):
         if self.w_qk is None or self.w_v is None:
             raise RuntimeError("PendingAttenCarve.finish(): Q, K and V have not all been posted")
         sp, ex, N = self.sp, self.ex, self.N
-        q_all, k_all, v_all = self.fulls
-        S_img, S_loc, S_txt, Hn, D = self.S_img, self.S_loc, self.S_txt, self.Hn, self.D
+        S_img, S_loc, S_txt, hg, D = self.S_img, self.S_loc, self.S_txt, self.hg, self.D
         dev, dt = self.device, self.dtype
         # cu_seqlens = [0, n_valid_text + S_img, S] (xdit_ring_atten.py:105,183-184) -- stays on the device
         seqlens = (cu_seqlens_q[1:2].to(torch.int64) - S_loc + S_img).to(device=dev, dtype=torch.int32)
-        _wait_all(self.w_qk)
-        idx, cnt = sp.select_fn(q_all, k_all, top_k, S_txt // 128, p_remain_rates, block_neighbor_list)
-        _wait_all(self.w_v)                                    # the V transfer overlapped pooling + selection
-        o = sp.attend_fn(q_all, k_all, v_all, idx, cnt, seqlens, S_txt // 128, text_amp)
-        # ---- exchange out: image rows (already peer-major: chunk p = rank p's tokens) back to sequence shards;
-        #      text rows gathered over heads (the reference repeats them N times and all-to-alls, :206-217)
-        o_img = o[0, :S_img].reshape(N, S_loc, Hn, D)
-        if not o_img.is_contiguous():
-            o_img = o_img.contiguous()
-        o_recv = torch.empty((N, S_loc, Hn, D), dtype=dt, device=dev)
-        txt_all = torch.empty((N, self.B, S_txt, Hn, D), dtype=dt, device=dev)
-        w_o = ex.all_to_all([o_recv], [o_img])
-        w_t = ex.all_gather(txt_all, o[:, S_img:])
+        o_recvs, txt_alls, waits = [], [], []
+        for g in range(self.G):
+            q_all, k_all, v_all = self.fulls[g]
+            _wait_all(self.w_qk[g])
+            idx, cnt = sp.select_fn(q_all, k_all, top_k, S_txt // 128, p_remain_rates, block_neighbor_list)
+            _wait_all(self.w_v[g])                                 # the V transfer overlapped pooling + selection
+            o = sp.attend_fn(q_all, k_all, v_all, idx, cnt, seqlens, S_txt // 128, text_amp)
+            # ---- exchange out: image rows (already peer-major: chunk p = rank p's tokens) back to sequence shards;
+            #      text rows gathered over heads (the reference repeats them N times and all-to-alls, :206-217).
+            #      Pipelined: head g's O exchange is in flight while head g + 1 is attended
+            o_img = o[0, :S_img].reshape(N, S_loc, hg, D)
+            if not o_img.is_contiguous():
+                o_img = o_img.contiguous()
+            o_recv = torch.empty((N, S_loc, hg, D), dtype=dt, device=dev)
+            txt_all = torch.empty((N, self.B, S_txt, hg, D), dtype=dt, device=dev)
+            waits.append((ex.all_to_all([o_recv], [o_img]), ex.all_gather(txt_all, o[:, S_img:])))
+            o_recvs.append(o_recv)
+            txt_alls.append(txt_all)
         if while_out is not None:
             while_out()                                        # the caller's work that needs neither O nor its buffers
-        _wait_all(w_o)
-        w_t.wait()
-        self.sends = self.fulls = self.recvs = None
-        return sp.stage_out(o_recv, txt_all, N, S_loc, S_txt, dt, dev, out=out)
+        for w_o, w_t in waits:
+            _wait_all(w_o)
+            w_t.wait()
+        self.sends = self.fulls = self.recvs = self.alloc = None
+        if self.G == 1:
+            return sp.stage_out(o_recvs[0], txt_alls[0], N, S_loc, S_txt, dt, dev, out=out)
+        return sp.stage_out(o_recvs, txt_alls, N, S_loc, S_txt, dt, dev, out=out)
 
 
 # name the reference uses (jenga_hyvideo_multigpu.py:181)

@@ -76,11 +76,16 @@ CASES = [
     (4, (3, 24, 64), 512, True, True),      # I2V token_replace: 1152 tokens = 9 blocks, S_loc = 288, 4 text blocks
     (8, (4, 40, 80), 256, False, False),    # the reference-signature path (separate norm / RoPE / pack kernels)
     (2, (3, 24, 64), 512, True, False),
+    # round 5, JENGA_ULYSSES_PIPELINE: the rank's H/N heads exchanged and attended one head at a time (4 / 2 head groups)
+    (2, (4, 16, 32), 256, False, True, True),
+    (4, (3, 24, 64), 512, True, True, True),
+    (2, (4, 40, 80), 256, False, True, True),
 ]
+CASES = [c if len(c) == 6 else c + (False,) for c in CASES]
 
 
-@pytest.mark.parametrize("N,latent,n_txt,i2v,fused", CASES)
-def test_sp_forward_n_ranks_equals_single_rank(dev, N, latent, n_txt, i2v, fused):
+@pytest.mark.parametrize("N,latent,n_txt,i2v,fused,pipe", CASES)
+def test_sp_forward_n_ranks_equals_single_rank(dev, N, latent, n_txt, i2v, fused, pipe):
     from jenga_amd import dit
     from jenga_amd.modules import ulysses
     base = _model(dev)
@@ -136,7 +141,7 @@ def test_sp_forward_n_ranks_equals_single_rank(dev, N, latent, n_txt, i2v, fused
             ulysses.set_thread_sp_group(SimGroup(world, rank))
             ex = SimExchange(world, rank)      # ONE exchange per rank: its call counter orders the collectives
             for blk in list(m.double_blocks) + list(m.single_blocks):
-                sp = ulysses.UlyssesAttenCarve(exchange=ex)
+                sp = ulysses.UlyssesAttenCarve(exchange=ex, pipeline=pipe)
                 blk.hybrid_seq_parallel_attn = sp if fused else _ReferenceSignatureOnly(sp)
             c, s = configure(m)
             results[rank] = run_steps(m, c, s)
@@ -171,7 +176,9 @@ def test_sp_forward_n_ranks_equals_single_rank(dev, N, latent, n_txt, i2v, fused
     # the residual cache of a rank is its LOCAL shard (jenga_hyvideo_multigpu.py:296-305)
     for r in range(N):
         assert models[r].previous_residual.shape[1] == S_img // N
-    _record(f"N{N}_{'i2v' if i2v else 't2v'}_{'fused' if fused else 'unfused'}", rec)
+    if pipe:      # per-head selection and attention: the pipelined call must reproduce the single-rank forward bit for bit
+        assert all(st["bit_exact"] for st in rec["steps"]), rec["steps"]
+    _record(f"N{N}_{'i2v' if i2v else 't2v'}_{'fused' if fused else 'unfused'}{'_pipelined' if pipe else ''}", rec)
 
 
 def test_first_frame_mask_on_a_chunked_order_matches_the_unchunked_mask(dev):

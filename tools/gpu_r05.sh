@@ -29,6 +29,16 @@ D)  # selection kernel + the hardened parity tests
   timeout 200 python tools/bench_attn.py --drop 0.7 --iters 20 --coherent 3 --gain 2 > $O/sel_coh.json 2> $O/sel_coh.err; python -c "import json;d=json.loads(open('$O/sel_coh.json').read().strip().splitlines()[-1]);print('select_ms',d['select_ms'],'pool_ms',d['pool_ms'])"
   python __graft_entry__.py --smoke 2>&1 | tail -2
   ;;
+F)  # sequence-parallel path: head-group pipeline parity, the xgmi record on a world of one rank, simulated 8 ranks
+  timeout 1500 python -m pytest tests/test_gpu_sp_dit.py tests/test_gpu_ulysses.py tests/test_gpu_rccl.py tests/test_gpu_dit.py -x -q -m gpu > $O/pytest_sp.log 2>&1; tail -4 $O/pytest_sp.log
+  JENGA_BENCH_FORCE_DIST=1 timeout 900 python bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-dense-ref > $O/bench_force_dist.json 2> $O/bench_force_dist.err; python -c "
+import json;d=json.loads(open('$O/bench_force_dist.json').read().strip().splitlines()[-1]);print('value',d['value']);print(json.dumps(d.get('roofline_xgmi'),indent=0)[:1500])"
+  L="--steps 6 --warmup 2 --no-cpu-baseline --no-dense-ref --no-secondary --no-wan-extra --simulate-ranks 8"
+  for G in 300 150; do
+    timeout 600 python bench.py $L --sim-exchange-gbps $G > $O/sim8_x$G.json 2> $O/sim8_x$G.err; python -c "import json;d=json.loads(open('$O/sim8_x$G.json').read().strip().splitlines()[-1]);print('sim8 x$G plain    ',d['value'])"
+    JENGA_ULYSSES_PIPELINE=1 timeout 600 python bench.py $L --sim-exchange-gbps $G > $O/sim8_x${G}_pipe.json 2> $O/sim8_x${G}_pipe.err; python -c "import json;d=json.loads(open('$O/sim8_x${G}_pipe.json').read().strip().splitlines()[-1]);print('sim8 x$G pipelined',d['value'])"
+  done
+  ;;
 E)  # selection kernel: rows per workgroup and elimination builds (clock only)
   for lib in ${LIBS:-base g1 g2 g8 sx1 sx2 sx4 sx8 sx15}; do
     if [ "$lib" = base ]; then unset JENGA_LIB; else export JENGA_LIB=$PWD/alt_libs/$lib.so; fi
