@@ -1148,6 +1148,10 @@ def main():
     res["loop"] = loop
     if gemm_choices_synced is not None:
         res["config"]["gemm_choices_synchronized_across_ranks"] = gemm_choices_synced
+        mm = torch.tensor([_capi.linear_import_mismatches()], device=dev, dtype=torch.int64)
+        if dist_on:
+            dist.all_reduce(mm, op=dist.ReduceOp.MAX)
+        res["config"]["gemm_choice_solution_index_mismatches_max_over_ranks"] = int(mm.item())
     if xgmi_raw is not None:
         LINK_GBPS = 153.6                      # one xGMI link, one direction (MI355X_MICROARCH.md: 7 links x ~153 GB/s per GPU)
         layers = len(model.double_blocks) + len(model.single_blocks)

@@ -161,11 +161,17 @@ int jenga_linear(void* stream, const void* x, const void* w, const void* bias, c
  * heuristic's first candidates when it first meets a shape; ranks timing on their own may choose differently, and the
  * replicated text stream (models_mul_block_gc_ha_multigpu.py:196-214: every rank computes the same text rows) would then
  * no longer be bit-identical across ranks.  export: the calling device's plans as records of 12 int64 (M, N, K, x stride,
- * w stride, ldc, out stride, epilogue, mode, dtype, workspace bytes, index of the chosen algorithm in the heuristic's
- * list); returns the number of plans (records beyond `capacity` are not written; records may be NULL to count).
+ * w stride, ldc, out stride, epilogue, mode, dtype, workspace bytes, the chosen algorithm -- packed, see below);
+ * returns the number of plans (records beyond `capacity` are not written; records may be NULL to count).
  * import: those choices are used from now on for these shapes on every device of this process, without timing. */
 int64_t jenga_linear_export_choices(int64_t* records, int64_t capacity);
 int jenga_linear_import_choices(const int64_t* records, int64_t n);
+/* (ABI 4) the last record field is packed: list index | (candidate count the list was requested with) << 8 | (hipBLASLt
+ * solution index + 1) << 16.  The importer re-queries the heuristic with the EXPORTER's count (the list is not
+ * prefix-stable across counts) and takes the algorithm with the exported solution index, the list position only as the
+ * fallback.  jenga_linear_import_mismatches: plans rebuilt from an import so far whose solution index is not the exported
+ * one (0 = every rank runs rank 0's algorithms). */
+int64_t jenga_linear_import_mismatches(void);
 
 
 /* jenga_qk_norm_rope_pool: jenga_rmsnorm_rope for Q AND K plus the two jenga_block_pool passes of a

@@ -62,6 +62,7 @@ SIGNATURES = {
     "jenga_cross_attn_fwd": (_i32, [_vp] * 5 + [_i64] * 14 + [_f32, _i32]),
     "jenga_linear_export_choices": (_i64, [_vp, _i64]),
     "jenga_linear_import_choices": (_i32, [_vp, _i64]),
+    "jenga_linear_import_mismatches": (_i64, []),
     "jenga_pair_merge": (_i32, [_vp, _vp, _vp] + [_i64] * 4 + [_vp, _vp]),
     "jenga_bsattn_pair_fwd": (_i32, [_vp] * 9 + [_i64] * 13 + [_f32, _f32, _i64, _i32, _i32]),
 }
@@ -490,16 +491,25 @@ def gelu_tanh(x, out=None):
 
 ACT_NONE, ACT_GELU_TANH = 0, 1
 BIAS_F32 = 256      # OR-ed into jenga_linear's `act`: the bias vector is float32
-_GEMM_WORKSPACE = {}
+_GEMM_WORKSPACE = __import__("collections").OrderedDict()
+_GEMM_WORKSPACE_MAX = 8         # scratch buffers kept per process (64 MiB each), least recently used evicted
 
 
 def _gemm_workspace(device):
     """One 64 MiB scratch buffer per (device, stream): two jenga_linear calls in flight on different streams (the
-    sequence-parallel blocks issue GEMMs beside the exchange stream) must not share split-K scratch."""
+    sequence-parallel blocks issue GEMMs beside the exchange stream) must not share split-K scratch.  Bounded: at most
+    _GEMM_WORKSPACE_MAX buffers are kept (threads simulating ranks, short-lived side streams); an evicted buffer goes back
+    to torch's caching allocator, which hands it out again in stream order of the stream it was allocated on -- the stream
+    that used it -- so a GEMM still in flight on it is not disturbed."""
     key = (str(device), torch.cuda.current_stream(device).cuda_stream)
-    if key not in _GEMM_WORKSPACE:
-        _GEMM_WORKSPACE[key] = torch.empty(64 << 20, dtype=torch.uint8, device=device)
-    return _GEMM_WORKSPACE[key]
+    buf = _GEMM_WORKSPACE.get(key)
+    if buf is None:
+        buf = _GEMM_WORKSPACE[key] = torch.empty(64 << 20, dtype=torch.uint8, device=device)
+        while len(_GEMM_WORKSPACE) > _GEMM_WORKSPACE_MAX:
+            _GEMM_WORKSPACE.popitem(last=False)
+    else:
+        _GEMM_WORKSPACE.move_to_end(key)
+    return buf
 
 
 def linear_export_choices():
@@ -516,6 +526,12 @@ def linear_import_choices(records):
     if rec.dim() != 2 or rec.shape[1] != 12:
         raise ValueError("linear_import_choices: records must be int64 [n, 12]")
     _check(lib().jenga_linear_import_choices(ctypes.c_void_p(rec.data_ptr()), rec.shape[0]), "jenga_linear_import_choices")
+
+
+def linear_import_mismatches():
+    """Plans rebuilt from imported choices so far whose hipBLASLt solution index is not the exported one (0 = this rank runs
+    the exporting rank's algorithms)."""
+    return int(lib().jenga_linear_import_mismatches())
 
 
 def linear(x, weight, bias=None, act=ACT_NONE, gate=None, res=None, out=None):

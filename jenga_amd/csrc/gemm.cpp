@@ -12,6 +12,7 @@
 // call torch makes for nn.Linear.
 #include <hip/hip_runtime.h>
 #include <hipblaslt/hipblaslt.h>
+#include <hipblaslt/hipblaslt-ext.hpp>
 
 #include <cstdlib>
 #include <map>
@@ -33,7 +34,9 @@ struct Plan {
     hipblasLtMatrixLayout_t A = nullptr, B = nullptr, C = nullptr, D = nullptr;
     hipblasLtMatmulAlgo_t algo;
     size_t workspace = 0;
-    int choice = 0;      // index of the algorithm in the heuristic's list (what export / import carry between ranks)
+    int choice = 0;      // index of the algorithm in the heuristic's list ...
+    int want = 1;        // ... that was requested with this many candidates (the list is not prefix-stable across requests)
+    int sol = -1;        // hipBLASLt's solution index of the algorithm (hipblaslt_ext::getIndexFromAlgo), -1 unknown
     void destroy() {
         if (desc) hipblasLtMatmulDescDestroy(desc);
         if (A) hipblasLtMatrixLayoutDestroy(A);
@@ -66,7 +69,11 @@ constexpr int SHAPE_FIELDS = 11;
 std::mutex g_mu;
 std::map<int, hipblasLtHandle_t> g_handles;
 std::map<Key, Plan> g_plans;
-std::map<Shape, int> g_forced;     // imported choices (jenga_linear_import_choices): no timing, take this index
+struct Forced {
+    int choice, want, sol;
+};
+std::map<Shape, Forced> g_forced;  // imported choices (jenga_linear_import_choices): no timing, take this algorithm
+int g_import_mismatches = 0;       // plans rebuilt from an import whose solution index is not the exported one
 
 #define LT_TRY(call)                                                             \
     do {                                                                         \
@@ -165,12 +172,18 @@ extern "C" int jenga_linear(void* stream, const void* x, const void* w, const vo
             cap = hipStreamCaptureStatusNone;
         }
         if (cap != hipStreamCaptureStatusNone) want = 1;
-        int forced = -1;
+        // An imported choice is (list index, the candidate count the EXPORTER asked the heuristic for, solution index): the
+        // list is re-queried with the exporter's count -- hipBLASLt does not promise that a shorter request returns a prefix
+        // of a longer one -- and the algorithm is then looked up by its solution index; the list position is the fallback.
+        int forced = -1, forced_sol = -1;
         auto fi = g_forced.find(shape);
         if (fi != g_forced.end()) {
-            forced = fi->second;
-            want = forced + 1 > 32 ? 32 : forced + 1;
+            forced = fi->second.choice;
+            forced_sol = fi->second.sol;
+            want = fi->second.want < forced + 1 ? forced + 1 : fi->second.want;
+            if (want > 32) want = 32;
         }
+        const int asked = want;
         hipblasLtMatmulHeuristicResult_t hr[32];
         int found = 0;
         const hipblasStatus_t hs =
@@ -182,9 +195,18 @@ extern "C" int jenga_linear(void* stream, const void* x, const void* w, const vo
         }
         int best = 0;
         if (forced >= 0) {
-            if (forced < found && hr[forced].state == HIPBLAS_STATUS_SUCCESS &&
-                hr[forced].workspaceSize <= (size_t)workspace_bytes)
+            int by_sol = -1;
+            if (forced_sol >= 0)
+                for (int i = 0; i < found && by_sol < 0; ++i)
+                    if (hr[i].state == HIPBLAS_STATUS_SUCCESS && hr[i].workspaceSize <= (size_t)workspace_bytes &&
+                        hipblaslt_ext::getIndexFromAlgo(hr[i].algo) == forced_sol)
+                        by_sol = i;
+            if (by_sol >= 0)
+                best = by_sol;
+            else if (forced < found && hr[forced].state == HIPBLAS_STATUS_SUCCESS &&
+                     hr[forced].workspaceSize <= (size_t)workspace_bytes)
                 best = forced;       // (a list that came out shorter here than on the exporting rank: first pick)
+            if (forced_sol >= 0 && hipblaslt_ext::getIndexFromAlgo(hr[best].algo) != forced_sol) ++g_import_mismatches;
         } else if (found > 1 && res != out) {   // (in place, every extra launch would add the residual once more)
             const float one_ = 1.0f, zero_ = 0.0f;
             const void* alpha_ = gate ? (const void*)gate : (const void*)&one_;
@@ -217,6 +239,8 @@ extern "C" int jenga_linear(void* stream, const void* x, const void* w, const vo
         p.algo = hr[best].algo;
         p.workspace = hr[best].workspaceSize;
         p.choice = best;
+        p.want = asked;
+        p.sol = hipblaslt_ext::getIndexFromAlgo(p.algo);
         it = g_plans.emplace(key, p).first;
         g.keep = true;
     }
@@ -239,7 +263,8 @@ extern "C" int jenga_linear(void* stream, const void* x, const void* w, const vo
 
 // Algorithm choices across the ranks of a job: every rank may time candidates on its own (JENGA_GEMM_CANDIDATES), but
 // the replicated text stream must see the SAME arithmetic on every rank, so rank 0 exports its choices -- records of
-// 12 int64: the 11 shape-key fields + the index in the heuristic's list -- and every rank imports them (which drops the
+// 12 int64: the 11 shape-key fields + (index in the heuristic's list | the candidate count that list was requested with << 8
+// | (hipBLASLt solution index + 1) << 16) -- and every rank imports them (which drops the
 // rank's own plans for those shapes; the next call rebuilds them from the imported index, no timing).
 extern "C" int64_t jenga_linear_export_choices(int64_t* records, int64_t capacity) {
     std::lock_guard<std::mutex> lock(g_mu);
@@ -250,7 +275,9 @@ extern "C" int64_t jenga_linear_export_choices(int64_t* records, int64_t capacit
         if (kv.first.first != dev) continue;
         if (records && n < capacity) {
             shape_to_array(kv.first.second, records + n * (SHAPE_FIELDS + 1));
-            records[n * (SHAPE_FIELDS + 1) + SHAPE_FIELDS] = kv.second.choice;
+            // choice | requested candidate count << 8 | (solution index + 1) << 16   (0 in the upper part: unknown)
+            records[n * (SHAPE_FIELDS + 1) + SHAPE_FIELDS] =
+                (int64_t)kv.second.choice | ((int64_t)kv.second.want << 8) | ((int64_t)(kv.second.sol + 1) << 16);
         }
         ++n;
     }
@@ -265,13 +292,15 @@ extern "C" int jenga_linear_import_choices(const int64_t* records, int64_t n) {
     std::lock_guard<std::mutex> lock(g_mu);
     for (int64_t i = 0; i < n; ++i) {
         const int64_t* r = records + i * (SHAPE_FIELDS + 1);
-        if (r[SHAPE_FIELDS] < 0 || r[SHAPE_FIELDS] >= 32) {
-            set_error("jenga_linear_import_choices: record %lld has choice %lld outside [0, 32)", (long long)i,
-                      (long long)r[SHAPE_FIELDS]);
+        const int64_t packed = r[SHAPE_FIELDS];
+        const int choice = (int)(packed & 0xff), want_ = (int)((packed >> 8) & 0xff), sol_ = (int)(packed >> 16) - 1;
+        if (packed < 0 || choice >= 32 || want_ > 32) {
+            set_error("jenga_linear_import_choices: record %lld has choice %d / requested count %d outside [0, 32]", (long long)i,
+                      choice, want_);
             return JENGA_EINVAL;
         }
         const Shape s{r[0], r[1], r[2], r[3], r[4], r[5], r[6], (int)r[7], (int)r[8], (int)r[9], r[10]};
-        g_forced[s] = (int)r[SHAPE_FIELDS];
+        g_forced[s] = Forced{choice, want_ < 1 ? choice + 1 : want_, sol_};
         for (auto it = g_plans.begin(); it != g_plans.end();) {
             if (it->first.second == s) {
                 it->second.destroy();
@@ -282,4 +311,9 @@ extern "C" int jenga_linear_import_choices(const int64_t* records, int64_t n) {
         }
     }
     return JENGA_OK;
+}
+
+extern "C" int64_t jenga_linear_import_mismatches(void) {
+    std::lock_guard<std::mutex> lock(g_mu);
+    return g_import_mismatches;
 }

@@ -32,11 +32,19 @@ def my_parallel_attention(hybrid_seq_parallel_attn, q, k, v, img_q_len, img_kv_l
 
 
 def parallel_attention(hybrid_seq_parallel_attn, q, k, v, img_q_len, img_kv_len, cu_seqlens_q, cu_seqlens_kv):
-    """attenion.py:198-247: the sequence-parallel attention of the NON-Jenga model files (hyvideo/modules/models.py:216,
-    381).  The Jenga entry scripts import the name (jenga_hyvideo.py:19) but their blocks call my_parallel_attention
-    (models_mul_block_gc_ha_multigpu.py:276, 483); it exists here so that those imports resolve and says so when called."""
-    raise NotImplementedError("parallel_attention belongs to the non-Jenga HunyuanVideo blocks; the Jenga blocks call "
-                              "my_parallel_attention (jenga_amd.modules.attention.my_parallel_attention)")
+    """attenion.py:198-251: the DENSE sequence-parallel attention (no AttenCarve: yunchang's LongContextAttention over
+    image + valid text, then a separate flash call among the padding tokens, sliced by cu_seqlens on the host).  Callers in
+    the reference: the non-Jenga blocks (hyvideo/modules/models.py:216, 381) and -- in their sequence-parallel branch
+    only -- the Jenga I2V blocks (hyvideo_i2v/modules/models_mul.py:265, 484), i.e. the reference has no Jenga-aware
+    sequence parallelism for I2V.  Not part of the AttenCarve path: the name
+    exists so that the entry scripts' imports resolve (jenga_hyvideo.py:19), and a call says what to use instead.  I2V
+    sequence parallelism WITH AttenCarve is jenga_amd.dit's own path (JengaHYVideoDiT with i2v_condition_type =
+    "token_replace" and UlyssesAttenCarve on the blocks; tests/test_gpu_sp_dit.py)."""
+    raise NotImplementedError(
+        "parallel_attention is the reference's dense (non-Jenga) sequence-parallel attention (attenion.py:198-251) and is "
+        "not implemented: the T2V Jenga blocks call my_parallel_attention; the reference's I2V blocks reach this function "
+        "only with sequence parallelism on, where they run WITHOUT AttenCarve -- use jenga_amd.dit.JengaHYVideoDiT "
+        "(i2v_condition_type='token_replace') with jenga_amd.modules.ulysses.UlyssesAttenCarve for I2V on several GPUs")
 
 
 _DENSE_LISTS = {}
