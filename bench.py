@@ -31,7 +31,7 @@ sys.path.insert(0, ROOT)
 
 MFMA_PEAK_TFLOPS = 2500.0  # dense bf16, /opt/skills/guides/MI355X_MICROARCH.md
 FLOPS_PER_PAIR = 4 * 128 ** 3  # one 128x128 query block against one 128-key block, head_dim 128: QK^T + PV
-PMC_FILE = "r04_pmc_bsattn_lp_balance.json"   # the counter passes `roofline.traffic` is derived from (profiles/)
+PMC_FILE = "r05_pmc_bsattn_lp_rates.json"   # the counter passes `roofline.traffic` is derived from (profiles/): per drop rate
 
 
 PRESETS = {   # scripts/hyvideo_jenga_{base,turbo,flash,3stage}.sh and scripts/hyvideo_multigpu_jenga_*.sh
@@ -50,6 +50,27 @@ PRESETS = {   # scripts/hyvideo_jenga_{base,turbo,flash,3stage}.sh and scripts/h
     "dense": dict(res=[1.0, 1.0], steps=[0.5, 1.0], rates=[0.0, 0.0], shifts=[7, 7], p=0.3, skip=False),
 }
 
+
+
+ATTN_ALGORITHMIC_BYTES = 4 * 115456 * 24 * 128 * 2 + 24 * 900 * 902 * 4      # Q + K + V + O of one launch + the kept lists (config 2)
+
+
+def traffic_bytes_per_pair(pmc, rate, shared_frac):
+    """Memory-side bytes per kept block pair of the LP kernel at drop rate `rate`, from the committed counter passes
+    (profiles/PMC_FILE): the passes of the nearest measured rate, interpolated linearly in adjacent_shared_frac between its
+    'flat' and 'coh' points (clamped to them).  -> dict(bytes_per_pair, rate, points) or None."""
+    rates = pmc.get("rates") or {}
+    if not rates or rate is None:
+        return None
+    key = min(rates, key=lambda r: abs(float(r) - float(rate)))
+    flat, coh = rates[key]["flat"], rates[key]["coh"]
+    f0, f1 = flat["adjacent_shared_frac"], coh["adjacent_shared_frac"]
+    x = f0 if shared_frac is None or shared_frac != shared_frac else min(max(shared_frac, f0), f1)
+    w = (x - f0) / max(f1 - f0, 1e-9)
+    b = flat["traffic_bytes_per_kept_pair"] * (1 - w) + coh["traffic_bytes_per_kept_pair"] * w
+    return {"bytes_per_pair": b, "rate": float(key),
+            "points": {"flat": [round(f0, 3), round(flat["traffic_bytes_per_kept_pair"])],
+                       "coh": [round(f1, 3), round(coh["traffic_bytes_per_kept_pair"])], "at_shared_frac": round(x, 3)}}
 
 
 def attn_kernel_name():
@@ -770,6 +791,8 @@ def main():
         model.curve_sel, model.linear_to_hilbert, model.hilbert_order = st["curve"], st["l2h"], st["h2l"]
         model.cnt = i
         model.sa_drop_rate = a.rates[k]
+        if _capi.ATTN_PROFILE is not None:
+            _capi.ATTN_PROFILE.tag = a.rates[k]
         model.text_amp = st["text_amp"]
         model.start_stage = i in forced
         tval = sched.timesteps[i:i + 1].to(dev)
@@ -1032,20 +1055,35 @@ def main():
     # HBM-side bytes per launch: the per-kept-pair figure of the committed PMC passes (profiles/, separate rocprofv3
     # --pmc runs of this kernel on this workload; recipe tools/pmc_attn2.sh) x this run's kept pairs per launch
     traffic = traffic_tbps = None
+    traffic_per_rate = {}
     pmc_rel = os.path.join("profiles", PMC_FILE)
     try:
         pmc = json.load(open(os.path.join(ROOT, pmc_rel)))
     except FileNotFoundError:
         pmc = None
         print(f"bench.py: {pmc_rel} not found: roofline.traffic stays null", file=sys.stderr)
-    if pmc is not None and ps["launches"] > 0:
-        d_ = pmc["derived"]
-        per_pair = d_.get("traffic_bytes_per_kept_pair")
-        if per_pair is None:      # older records carry the per-launch total and the pair count of the PMC run
-            per_pair = d_["traffic_bytes_per_launch"] / d_["kept_block_pairs_per_launch"]
-        traffic = int(per_pair * ps["pairs"] / ps["launches"])
-        if ps["total_ms"] > 0:
-            traffic_tbps = round(traffic / (ps["total_ms"] / ps["launches"] * 1e-3) / 1e12, 3)
+    lq_kernel = bool(_capi.ATTN_DEFAULT_FLAGS & _capi.ATTN_PAIR)
+    if pmc is not None and ps["launches"] > 0 and not lq_kernel:
+        shared_now = ps.get("adjacent_shared_frac")
+        tot_bytes = 0.0
+        for tag, bt in ps.get("by_tag", {}).items():
+            pr = traffic_bytes_per_pair(pmc, tag, shared_now)
+            if pr is None:
+                continue
+            b_ = pr["bytes_per_pair"] * bt["pairs"]
+            tot_bytes += b_
+            per_launch = b_ / max(bt["launches"], 1)
+            traffic_per_rate[str(tag)] = {
+                "launches": bt["launches"], "avg_launch_ms": round(bt["total_ms"] / max(bt["launches"], 1), 3),
+                "kept_block_pairs_per_launch": bt["pairs"] // max(bt["launches"], 1),
+                "bytes_per_kept_pair": round(pr["bytes_per_pair"]), "pmc_points": pr["points"], "pmc_rate_used": pr["rate"],
+                "traffic_per_launch": int(per_launch),
+                "traffic_TBps": round(per_launch / max(bt["total_ms"] / max(bt["launches"], 1) * 1e-3, 1e-12) / 1e12, 3),
+                "ratio_to_algorithmic_bytes": round(per_launch / ATTN_ALGORITHMIC_BYTES, 1)}
+        if tot_bytes > 0:
+            traffic = int(tot_bytes / ps["launches"])
+            if ps["total_ms"] > 0:
+                traffic_tbps = round(traffic / (ps["total_ms"] / ps["launches"] * 1e-3) / 1e12, 3)
     flops = ps["pairs"] * FLOPS_PER_PAIR
     ach = flops / (ps["total_ms"] * 1e-3) / 1e12 if ps["total_ms"] > 0 else 0.0
     # ---- whole-loop arithmetic: attention FLOPs of the realised lists (this rank's launches) + the dense linear algebra
@@ -1105,11 +1143,17 @@ def main():
         "roofline": {"kernel": attn_kernel_name(), "bound": "mfma", "achieved": round(ach, 1),
                      "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_PEAK_TFLOPS, 4),
                      "traffic": traffic, "traffic_TBps": traffic_tbps,
-                     "traffic_provenance": "derived, not read in this run: a committed per-kept-pair constant x this run's pairs",
+                     "traffic_provenance": "derived, not read in this run: committed per-kept-pair constants (one per drop "
+                                           "rate) x this run's pairs, launch by launch",
                      "traffic_source": f"{pmc_rel}: memory-side bytes per kept block pair from separate rocprofv3 --pmc "
-                                       "passes of this kernel on this workload (FETCH_SIZE / WRITE_SIZE with the guide's "
-                                       "gfx950 corrections), x this run's pairs per launch; traffic_TBps = traffic / "
-                                       "avg_launch_ms (the fabric roof beside the MFMA one: ~8 TB/s)",
+                                       "passes of this kernel at sa-drop 0.7 and 0.8 on one box (FETCH_SIZE / WRITE_SIZE with the "
+                                       "guide's gfx950 corrections; lists with little and with much overlap between adjacent "
+                                       "query blocks, interpolated at this run's adjacent_shared_frac); traffic = mean over the "
+                                       "timed launches; traffic_TBps = traffic / avg_launch_ms (the fabric roof beside the MFMA "
+                                       "one: ~8 TB/s)",
+                     "traffic_per_rate": traffic_per_rate,
+                     "traffic_ratio_to_algorithmic_bytes": None if traffic is None else round(traffic / ATTN_ALGORITHMIC_BYTES, 1),
+                     "algorithmic_bytes_per_launch": ATTN_ALGORITHMIC_BYTES,
                      "launches": ps["launches"],
                      "avg_launch_ms": round(ps["total_ms"] / max(ps["launches"], 1), 3),
                      "kept_block_pairs_per_launch": ps["pairs"] // max(ps["launches"], 1),

@@ -79,10 +79,19 @@ class AttnProfile:
         self.pairs = None       # device int64 scalar: kept (q-block, kv-block) pairs over all recorded launches
         self.launches = 0
         self.last_lists = None  # (idx, cnt) of the most recent launch with image query blocks
+        self.tag = None         # set by the caller (bench.py: the step's sa-drop rate); recorded per launch
+        self.per_launch = []    # (tag, device scalar: pairs of the launch), aligned with `events`
 
     def summary(self):
         ms = sum(a.elapsed_time(b) for a, b in self.events)
         out = dict(launches=self.launches, total_ms=ms, pairs=int(self.pairs.item()) if self.pairs is not None else 0)
+        by_tag = {}
+        for (tag, pr), (a, b) in zip(self.per_launch, self.events):
+            t = by_tag.setdefault(tag, dict(launches=0, total_ms=0.0, pairs=0))
+            t["launches"] += 1
+            t["total_ms"] += a.elapsed_time(b)
+            t["pairs"] += int(pr.item()) if torch.is_tensor(pr) else int(pr)
+        out["by_tag"] = by_tag
         if self.last_lists is not None:
             # share of a query block's kept image kv blocks that the NEXT query block of the same head keeps too
             # (how coherent the lists are: ~0.35 for random lists at 30 % density, ~0.9 for a trained model's)
@@ -745,6 +754,7 @@ def bsattn_fwd(q, k, vt, seqlens, idx, cnt, nq_img, sm_scale, text_amp, text_blo
             pairs = B * H * (n_blocks - nq_img) * n_blocks
             tot = (cnt.sum(dtype=torch.int64) if cnt is not None else 0) + pairs
             prof.pairs = tot if prof.pairs is None else prof.pairs + tot
+            prof.per_launch.append((prof.tag, tot))
             if idx is not None and nq_img > 1:
                 prof.last_lists = (idx, cnt)
     return out

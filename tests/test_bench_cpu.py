@@ -21,12 +21,18 @@ def test_bare_gpus_n_relaunches_under_torch_distributed_run():
 
 def test_pmc_record_carries_the_per_pair_traffic_bench_reads():
     import bench
-    d = json.load(open(os.path.join(ROOT, "profiles", bench.PMC_FILE)))["derived"]
-    per_pair = d.get("traffic_bytes_per_kept_pair")
-    if per_pair is None:
-        per_pair = d["traffic_bytes_per_launch"] / d["kept_block_pairs_per_launch"]
-    # one kept pair stages a 64 KiB K/V block pair at most once: the figure must be of that order
-    assert 8e3 < per_pair <= 70e3
+    pmc = json.load(open(os.path.join(ROOT, "profiles", bench.PMC_FILE)))
+    assert set(pmc["rates"]) >= {"0.7", "0.8"}          # both drop rates of the Base preset, one box
+    for rate in (0.7, 0.8):
+        lo = bench.traffic_bytes_per_pair(pmc, rate, 0.0)
+        hi = bench.traffic_bytes_per_pair(pmc, rate, 1.0)
+        mid = bench.traffic_bytes_per_pair(pmc, rate, 0.71)
+        # one kept pair stages a 64 KiB K/V block pair at most once: the figure must be of that order, and more overlap
+        # between adjacent query blocks means more L2 hits, i.e. fewer memory-side bytes
+        assert 8e3 < hi["bytes_per_pair"] <= mid["bytes_per_pair"] <= lo["bytes_per_pair"] <= 70e3
+        assert mid["rate"] == rate
+    assert bench.traffic_bytes_per_pair(pmc, 0.75, 0.5)["rate"] in (0.7, 0.8)
+    assert abs(bench.ATTN_ALGORITHMIC_BYTES / 2.86e9 - 1) < 0.03
 
 
 def test_presets_cover_the_reference_scripts_and_dense():
@@ -43,7 +49,7 @@ def test_bench_line_helpers_and_keys():
     model of a computed step matches the hand count, and the source assembles the keys."""
     import bench
     src = open(os.path.join(ROOT, "bench.py")).read()
-    for key in ('"roofline_secondary"', '"loop"', '"power"', '"traffic_provenance"', '"cpu_baseline"', '"extra"',
+    for key in ('"roofline_secondary"', '"loop"', '"power"', '"traffic_provenance"', '"traffic_per_rate"', '"roofline_xgmi"', '"cpu_baseline"', '"extra"',
                 '"dense_reference"', '"attn_other_kernel"', '"wan14b"'):
         assert f"res[{key}]" in src or f"{key}:" in src or f"[{key}]" in src or f"setdefault({key}" in src, key
     # one computed forward at the 720p shape: 1.57 PFLOP of GEMMs (SURVEY.md 8 a12)

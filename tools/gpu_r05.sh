@@ -29,6 +29,12 @@ D)  # selection kernel + the hardened parity tests
   timeout 200 python tools/bench_attn.py --drop 0.7 --iters 20 --coherent 3 --gain 2 > $O/sel_coh.json 2> $O/sel_coh.err; python -c "import json;d=json.loads(open('$O/sel_coh.json').read().strip().splitlines()[-1]);print('select_ms',d['select_ms'],'pool_ms',d['pool_ms'])"
   python __graft_entry__.py --smoke 2>&1 | tail -2
   ;;
+G)  # counter passes of the default kernel at both drop rates of the Base preset, one box (roofline.traffic_per_rate)
+  for R in 0.7 0.8; do
+    timeout 900 bash tools/pmc_attn2.sh r05_lp_flat_$R --drop $R --iters 2 --attn-only --flags 29 > $O/pmc_flat_$R.log 2>&1; grep -E "per_kept_pair|l2_hit|mfma_busy|effective_clock" $O/pmc_flat_$R.log
+    timeout 900 bash tools/pmc_attn2.sh r05_lp_coh_$R --drop $R --iters 2 --attn-only --coherent 3 --gain 2 --flags 29 > $O/pmc_coh_$R.log 2>&1; grep -E "per_kept_pair|l2_hit|mfma_busy|effective_clock" $O/pmc_coh_$R.log
+  done
+  ;;
 F)  # sequence-parallel path: head-group pipeline parity, the xgmi record on a world of one rank, simulated 8 ranks
   timeout 1500 python -m pytest tests/test_gpu_sp_dit.py tests/test_gpu_ulysses.py tests/test_gpu_rccl.py tests/test_gpu_dit.py -x -q -m gpu > $O/pytest_sp.log 2>&1; tail -4 $O/pytest_sp.log
   JENGA_BENCH_FORCE_DIST=1 timeout 900 python bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-dense-ref > $O/bench_force_dist.json 2> $O/bench_force_dist.err; python -c "
