@@ -205,14 +205,21 @@ def test_linear_choices_export_import_roundtrip(dev):
     rec = _capi.linear_export_choices()
     assert rec.dim() == 2 and rec.shape[1] == 12 and rec.shape[0] >= 1
     mine = [r for r in rec.tolist() if r[0] == 640 and r[1] == 768 and r[2] == 512]
-    assert mine and 0 <= mine[0][11] < 32
+    # (ABI 4) the last field is packed: list index | requested candidate count << 8 | (hipBLASLt solution index + 1) << 16
+    packed = mine[0][11]
+    choice, want, sol = packed & 0xff, (packed >> 8) & 0xff, (packed >> 16) - 1
+    assert 0 <= choice < 32 and 1 <= want <= 32 and choice < want and sol >= 0, (choice, want, sol)
+    before = _capi.linear_import_mismatches()
     _capi.linear_import_choices(rec)                     # drops the plans; the next call rebuilds them from the record
     y1 = _capi.linear(x, w, b, act=_capi.ACT_GELU_TANH)
     assert torch.equal(y0, y1)
-    assert _capi.linear_export_choices().shape[0] >= 1
+    assert _capi.linear_import_mismatches() == before    # the rebuilt plan runs the exported solution
+    rec2 = _capi.linear_export_choices()
+    mine2 = [r for r in rec2.tolist() if r[0] == 640 and r[1] == 768 and r[2] == 512]
+    assert mine2 and (mine2[0][11] >> 16) - 1 == sol
     with pytest.raises(_capi.JengaError):
         bad = rec.clone()
-        bad[0, 11] = 99
+        bad[0, 11] = 99 | (8 << 8)
         _capi.linear_import_choices(bad)
     with pytest.raises(ValueError):
         _capi.linear_import_choices(torch.zeros(3, 5, dtype=torch.int64))

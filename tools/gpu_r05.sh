@@ -29,6 +29,11 @@ D)  # selection kernel + the hardened parity tests
   timeout 200 python tools/bench_attn.py --drop 0.7 --iters 20 --coherent 3 --gain 2 > $O/sel_coh.json 2> $O/sel_coh.err; python -c "import json;d=json.loads(open('$O/sel_coh.json').read().strip().splitlines()[-1]);print('select_ms',d['select_ms'],'pool_ms',d['pool_ms'])"
   python __graft_entry__.py --smoke 2>&1 | tail -2
   ;;
+H)  # the driver's command at HEAD (default flags), then the same command under rocprofv3 --kernel-trace --stats, then the full GPU suite
+  timeout 900 python bench.py > $O/bench_default.json 2> $O/bench_default.err; python tools/ab_print.py $O/bench_default.json
+  timeout 1200 bash tools/prof_bench.sh r05_default > $O/prof.log 2>&1; head -12 gpurun_out/prof_r05_default/kernel_stats.csv | cut -c1-150
+  timeout 2400 python -m pytest tests -x -q -m gpu > $O/pytest_gpu.log 2>&1; tail -3 $O/pytest_gpu.log
+  ;;
 G)  # counter passes of the default kernel at both drop rates of the Base preset, one box (roofline.traffic_per_rate)
   for R in 0.7 0.8; do
     timeout 900 bash tools/pmc_attn2.sh r05_lp_flat_$R --drop $R --iters 2 --attn-only --flags 29 > $O/pmc_flat_$R.log 2>&1; grep -E "per_kept_pair|l2_hit|mfma_busy|effective_clock" $O/pmc_flat_$R.log
