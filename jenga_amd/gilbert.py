@@ -21,7 +21,8 @@ def _dev(device):
 
 def _mapping(t, h, w, sliced, transpose_order, as_tensor, device):
     if transpose_order is not None:
-        raise NotImplementedError("transpose_order is unused by every Jenga entry script and is not supported")
+        # gilbert.py:436-438, 484-486: with an axis order BOTH mappings are the transposed 3-D curve (the sliced variant too)
+        return transpose_gilbert_mapping([t, h, w], transpose_order, as_tensor=as_tensor, device=device)
     l2h, h2l = _capi.gilbert_map(int(t), int(h), int(w), sliced, _dev(device))
     if as_tensor:
         return l2h, h2l
@@ -37,8 +38,7 @@ def sliced_gilbert_mapping(t, h, w, transpose_order=None, as_tensor=False, devic
 
 
 def _neighbors(t, h, w, block_size, sliced, transpose_order, as_tensor, device):
-    if transpose_order is not None:
-        raise NotImplementedError("transpose_order is not supported")
+    # (transpose_order is accepted and ignored, as in the reference: gilbert.py:597-677 / 679-766 never read it)
     l2h, _ = _capi.gilbert_map(int(t), int(h), int(w), sliced, _dev(device))
     nb = _capi.gilbert_neighbors(int(t), int(h), int(w), int(block_size), l2h)
     return nb if as_tensor else nb.cpu()
@@ -54,12 +54,26 @@ def sliced_gilbert_block_neighbor_mapping(t, h, w, block_size=128, transpose_ord
 
 
 def transpose_gilbert_mapping(dims, order=None, as_tensor=False, device=None):
-    """gilbert.py:274-330 (imported by jenga_hyvideo.py:24 / jenga_hyi2v.py:26, called by no entry script): with the
-    default axis order it is gilbert_mapping(*dims); other orders are not supported."""
+    """gilbert.py:274-330: the curve of the axis-permuted cuboid.  (t', h', w') = dims[order]; the voxel with coordinates c
+    in the original axis order gets gilbert_xyz2d(c[order[2]], c[order[1]], c[order[0]], w', h', t').  The HIP kernel
+    computes the curve of the (t', h', w') cuboid (one thread per voxel); the axis permutation of the result is an index
+    view (arange.view(t', h', w').permute(...)) -- integer plumbing, no arithmetic."""
     if len(dims) != 3:
         raise ValueError("Dimensions must be three-dimensional")
-    if order is not None and list(order) != [0, 1, 2]:
-        if len(order) != 3 or set(order) != {0, 1, 2}:
-            raise ValueError("order must be a permutation of 0,1,2")
-        raise NotImplementedError("only the default axis order [0, 1, 2] is supported (no Jenga entry script passes another)")
-    return _mapping(dims[0], dims[1], dims[2], False, None, as_tensor, device)
+    order = [0, 1, 2] if order is None else [int(o) for o in order]
+    if len(order) != 3 or set(order) != {0, 1, 2}:
+        raise ValueError("order must be a permutation of 0,1,2")
+    if order == [0, 1, 2]:
+        return _mapping(dims[0], dims[1], dims[2], False, None, as_tensor, device)
+    dev = _dev(device)
+    tp, hp, wp = (int(dims[o]) for o in order)
+    l2h_t, _ = _capi.gilbert_map(tp, hp, wp, False, dev)          # [z' h' w' + y' w' + x'] -> gilbert(x', y', z'; w', h', t')
+    n = tp * hp * wp
+    inv = [order.index(k) for k in range(3)]                       # original axis k is axis inv[k] of the permuted cuboid
+    src = torch.arange(n, device=dev).view(tp, hp, wp).permute(*inv).reshape(-1)
+    l2h = l2h_t[src].contiguous()
+    h2l = torch.empty_like(l2h)
+    h2l[l2h] = torch.arange(n, device=dev, dtype=l2h.dtype)
+    if as_tensor:
+        return l2h, h2l
+    return l2h.cpu().tolist(), h2l.cpu().tolist()

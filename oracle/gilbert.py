@@ -53,6 +53,25 @@ def sliced_gilbert_mapping(t, h, w):
     return l2h, h2l
 
 
+def transpose_gilbert_mapping(dims, order=None):
+    """gilbert.py:274-330: the curve of the axis-permuted cuboid.  (t', h', w') = dims[order]; the voxel with coordinates c
+    (in the ORIGINAL axis order, linear index = row-major over dims) gets gilbert_xyz2d(c[order[2]], c[order[1]],
+    c[order[0]], w', h', t') -- computed point by point with the oracle's own gilbert_xyz2d, as the reference does."""
+    if len(dims) != 3:
+        raise ValueError("Dimensions must be three-dimensional")
+    order = [0, 1, 2] if order is None else list(order)
+    if len(order) != 3 or set(order) != {0, 1, 2}:
+        raise ValueError("order must be a permutation of 0,1,2")
+    t, h, w = (int(dims[o]) for o in order)
+    n = int(dims[0]) * int(dims[1]) * int(dims[2])
+    l2h, h2l = np.empty(n, np.int64), np.empty(n, np.int64)
+    for lin, c in enumerate(np.ndindex(*[int(d) for d in dims])):
+        g = gilbert_xyz2d(c[order[2]], c[order[1]], c[order[0]], w, h, t)
+        l2h[lin] = g
+        h2l[g] = lin
+    return l2h, h2l
+
+
 def block_neighbors(t, h, w, l2h, block_size=128):
     """-> bool [nb, nb] (gilbert.py:597-677; the sliced variant :679-766 differs only in the l2h it colours with)."""
     n = t * h * w

@@ -90,6 +90,21 @@ def gen_gilbert(big):
         small[f"s_{t}_{h}_{w}_h2l"] = np.asarray(h2l, dtype=np.int64)
         small[f"s_{t}_{h}_{w}_nb{bs}"] = nb.numpy()
     np.savez_compressed(os.path.join(OUT, "gilbert_small.npz"), **small)
+    # transpose_order (gilbert.py:274-330; reached through gilbert_mapping / sliced_gilbert_mapping(..., transpose_order=)):
+    # small grids verbatim, every non-identity axis order once; the block-neighbour functions take the argument and ignore it
+    tr = {}
+    for (dims, order) in [((3, 4, 5), (2, 1, 0)), ((3, 4, 5), (1, 0, 2)), ((2, 6, 4), (0, 2, 1)), ((2, 6, 4), (2, 0, 1)),
+                          ((4, 3, 7), (1, 2, 0)), ((1, 5, 3), (2, 1, 0))]:
+        l2h, h2l = g.gilbert_mapping(*dims, transpose_order=list(order))
+        key = "t_%d_%d_%d_o%d%d%d" % (dims + order)
+        tr[key + "_l2h"] = np.asarray(l2h, dtype=np.int64)
+        tr[key + "_h2l"] = np.asarray(h2l, dtype=np.int64)
+        l2s, _ = g.sliced_gilbert_mapping(*dims, transpose_order=list(order))
+        assert list(l2s) == list(l2h)           # the sliced variant falls back to the transposed 3-D curve (:436-438)
+        nb_t = g.gilbert_block_neighbor_mapping(*dims, block_size=8, transpose_order=list(order))
+        nb_0 = g.gilbert_block_neighbor_mapping(*dims, block_size=8)
+        assert bool((nb_t == nb_0).all())       # (:597-677 never reads transpose_order)
+    np.savez_compressed(os.path.join(OUT, "gilbert_transposed.npz"), **tr)
 
     if not big:
         return

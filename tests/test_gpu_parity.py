@@ -49,6 +49,25 @@ def test_gilbert_small_verbatim(golden_dir, dev):
         assert np.array_equal(got, g[key]), key
 
 
+def test_gilbert_transposed_orders_verbatim(golden_dir, dev):
+    """transpose_order through the three public entry points (gilbert.py:274-330, :436-438, :484-486) against goldens
+    generated from the reference; the block-neighbour functions accept the argument and ignore it like the reference."""
+    from jenga_amd import gilbert as G
+    g = np.load(os.path.join(golden_dir, "gilbert_transposed.npz"))
+    for key in g.files:
+        _, t, h, w, o, what = key.split("_")
+        dims, order = (int(t), int(h), int(w)), [int(c) for c in o[1:]]
+        for fn in (lambda: G.transpose_gilbert_mapping(dims, order), lambda: G.gilbert_mapping(*dims, transpose_order=order),
+                   lambda: G.sliced_gilbert_mapping(*dims, transpose_order=order)):
+            l2h, h2l = fn()
+            assert isinstance(l2h, list)
+            assert np.array_equal(np.asarray(l2h if what == "l2h" else h2l, dtype=np.int64), g[key]), key
+    nb_t = G.gilbert_block_neighbor_mapping(3, 4, 5, 8, transpose_order=[2, 1, 0])
+    assert torch.equal(nb_t, G.gilbert_block_neighbor_mapping(3, 4, 5, 8))
+    with pytest.raises(ValueError):
+        G.transpose_gilbert_mapping((2, 2, 2), [0, 1, 1])
+
+
 def test_gilbert_production_grids_sha(golden_dir, dev):
     from jenga_amd import gilbert as G
     d = json.load(open(os.path.join(golden_dir, "gilbert_big_digests.json")))

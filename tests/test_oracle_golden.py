@@ -32,6 +32,19 @@ def test_gilbert_small_verbatim(golden_dir):
         assert np.array_equal(got, g[key]), key
 
 
+def test_gilbert_transposed_orders_verbatim(golden_dir):
+    """transpose_order (gilbert.py:274-330) against goldens generated from the reference, every non-identity axis order."""
+    g = np.load(os.path.join(golden_dir, "gilbert_transposed.npz"))
+    assert len(g.files) == 12
+    for key in g.files:
+        _, t, h, w, o, what = key.split("_")
+        dims, order = (int(t), int(h), int(w)), [int(c) for c in o[1:]]
+        l2h, h2l = og.transpose_gilbert_mapping(dims, order)
+        assert np.array_equal(l2h if what == "l2h" else h2l, g[key]), key
+    with pytest.raises(ValueError):
+        og.transpose_gilbert_mapping((2, 2, 2), [0, 0, 1])
+
+
 def test_gilbert_production_grids_sha(golden_dir):
     d = json.load(open(os.path.join(golden_dir, "gilbert_big_digests.json")))
     for key, v in d.items():
