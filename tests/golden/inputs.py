@@ -60,14 +60,15 @@ def select_inputs(index):
 KERNEL_SPECS = [(2, 4, 2, 70, 0.0, 7), (2, 5, 2, 256, 0.431, 8), (1, 3, 1, 1, 0.25, 9)]
 
 
-def kernel_inputs(index):
-    """-> q [1,H,nb_img*128,128], k, v [1,H,S,128] fp16, mask bool [1,H,nb_img,nb_all], seqlen, text_amp."""
+def kernel_inputs(index, dtype=torch.float16):
+    """-> q [1,H,nb_img*128,128], k, v [1,H,S,128] fp16 (or the same draws rounded to `dtype`), mask bool
+    [1,H,nb_img,nb_all], seqlen, text_amp."""
     H, nb_img, tb, seqlen_txt, amp, seed = KERNEL_SPECS[index]
     gen = torch.Generator().manual_seed(seed)
     S = (nb_img + tb) * 128
-    q = (torch.randn(1, H, nb_img * 128, 128, generator=gen) * 1.2).half()
-    k = (torch.randn(1, H, S, 128, generator=gen) * 1.2).half()
-    v = torch.randn(1, H, S, 128, generator=gen).half()
+    q = (torch.randn(1, H, nb_img * 128, 128, generator=gen) * 1.2).to(dtype)
+    k = (torch.randn(1, H, S, 128, generator=gen) * 1.2).to(dtype)
+    v = torch.randn(1, H, S, 128, generator=gen).to(dtype)
     mask = torch.rand(1, H, nb_img, nb_img + tb, generator=gen) < 0.5
     mask[..., nb_img:] = True
     for i in range(nb_img):

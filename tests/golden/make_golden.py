@@ -14,7 +14,8 @@ the large permutations.  No reference source is copied.  What is called:
   hyvideo/modules/attention_block_triton_diffres.py
                                   _build_block_index_with_importance_optimized (torch, CPU)
                                   _triton_block_sparse_attn_fwd_kernel_onehot via the launcher
-                                  (TRITON_INTERPRET=1, fp16 only -- the interpreter has no bf16)
+                                  (TRITON_INTERPRET=1: fp16 with the stock interpreter; bf16 + fp16 again with
+                                  _bf16_interpreter_shim(), `--only attnbf16` -> attn_exact_cases.npz)
                                   block_sparse_attention (whole op, fp16; the text rows go through a
                                   flash_attn stand-in = torch SDPA, flagged `text_rows_stub` in the npz)
   wan/modules/attention_block_triton_diffres.py
@@ -203,6 +204,108 @@ def gen_attn():
                       text_rows_stub="torch SDPA fp32 stand-in for flash_attn_func (not reference code)")
     np.savez_compressed(os.path.join(OUT, "attn_cases.npz"), **out)
     with open(os.path.join(OUT, "attn_cases.json"), "w") as f:
+        json.dump(meta, f, indent=1, sort_keys=True)
+
+
+def _bf16_interpreter_shim():
+    """Triton 3.6's CPU interpreter keeps bf16 as raw uint16 and does integer arithmetic on it (no `get_bf16`, `tl.dot` on
+    the bit patterns, fp32->bf16 casts that truncate).  This harness-side patch gives the four builder entry points the
+    reference kernel reaches in bf16 their IEEE meaning -- nothing of the kernel itself is restated: its control flow, its
+    rounding POINTS (`(q * qk_scale).to(dtype)`, `p.to(dtype)`, `acc.to(dtype)`) and its fp32 online softmax run from the
+    reference source.  What the shim supplies:
+      * a bf16 scalar constant = RNE(fp32 value)             (semantic.scalar_constant -> builder.get_bf16)
+      * bf16 (op) bf16 = RNE(fp32(a) op fp32(b))             (what LLVM's bf16 legalisation emits on every GPU target)
+      * tl.dot(bf16, bf16) -> fp32: exact products, fp32 sums (np.matmul on the widened operands)
+      * fp32 -> bf16 casts round to nearest even             (the PTX/AMDGCN default for `.to(tl.bfloat16)`)
+      * a Python float kernel ARGUMENT arrives as an fp32 scalar, as the compiled launcher passes it (jit.mangle_type(float)
+        == "fp32"); the stock interpreter leaves it a Python literal, which would make `q * qk_scale` (:88) a bf16 x bf16
+        product with the scale rounded to 8 bits instead of the fp32 product the GPU kernel computes
+    """
+    import triton.language as tl
+    from triton.runtime import interpreter as I
+
+    def widen(u16):
+        return (np.ascontiguousarray(u16).astype(np.uint32) << 16).view(np.float32)
+
+    def rne(f32):
+        u = np.ascontiguousarray(f32, dtype=np.float32).view(np.uint32)
+        out = ((u + (((u >> 16) & 1) + np.uint32(0x7FFF))) >> 16).astype(np.uint16)
+        nan = np.isnan(f32)
+        if np.any(nan):
+            out = np.where(nan, np.uint16(0x7FC0), out)
+        return out
+
+    B = I.InterpreterBuilder
+    B.get_bf16 = lambda self, value: I.TensorHandle(rne(np.array([value], dtype=np.float32)), tl.bfloat16)
+    binary0, cast0, dot0 = B.binary_op, B.cast_impl, B.create_dot
+
+    def binary_op(self, lhs, rhs, op):
+        if lhs.dtype.scalar == tl.bfloat16 and rhs.dtype.scalar == tl.bfloat16:
+            return I.TensorHandle(rne(op(widen(lhs.data), widen(rhs.data))), tl.bfloat16)
+        return binary0(self, lhs, rhs, op)
+
+    def cast_impl(self, src, dst_type):
+        s, d = src.dtype.scalar, dst_type.scalar
+        if s == tl.float32 and d == tl.bfloat16:
+            return I.TensorHandle(rne(src.data), tl.bfloat16)
+        if s == tl.bfloat16 and d == tl.float32:
+            return I.TensorHandle(widen(src.data), tl.float32)
+        assert tl.bfloat16 not in (s, d), (s, d)
+        return cast0(self, src, dst_type)
+
+    def create_dot(self, a, b, d, input_precision, max_num_imprecise_acc):
+        if a.dtype.scalar == tl.bfloat16 or b.dtype.scalar == tl.bfloat16:
+            assert a.dtype.scalar == b.dtype.scalar == tl.bfloat16 and d.data.dtype == np.float32
+            return I.TensorHandle(np.matmul(widen(a.data), widen(b.data), dtype=np.float32) + d.data, d.dtype.scalar)
+        return dot0(self, a, b, d, input_precision, max_num_imprecise_acc)
+
+    B.binary_op, B.cast_impl, B.create_dot = binary_op, cast_impl, create_dot
+    cvt0 = I._implicit_cvt
+
+    def implicit_cvt(arg):
+        if isinstance(arg, float):
+            return tl.tensor(I.TensorHandle(np.array([arg], dtype=np.float32), tl.float32), tl.float32)
+        return cvt0(arg)
+
+    I._implicit_cvt = implicit_cvt
+    for name in ("create_fadd", "create_fmul", "create_fsub", "create_fdiv"):
+        npop = {"create_fadd": np.add, "create_fmul": np.multiply, "create_fsub": np.subtract, "create_fdiv": np.divide}[name]
+        setattr(B, name, (lambda npop: lambda self, lhs, rhs: self.binary_op(lhs, rhs, npop))(npop))
+    # self-check of the shim against torch's own bf16 (RNE casts, bf16 multiply)
+    x = torch.randn(4096, generator=torch.Generator().manual_seed(1)) * 37
+    assert np.array_equal(rne(x.numpy()), x.to(torch.bfloat16).view(torch.uint16).numpy())
+    a, b = x.to(torch.bfloat16), x.flip(0).to(torch.bfloat16)
+    assert np.array_equal(rne(widen(a.view(torch.uint16).numpy()) * widen(b.view(torch.uint16).numpy())),
+                          (a * b).view(torch.uint16).numpy())
+
+
+def gen_attn_bf16():
+    """The reference Triton kernel, bf16 tensors, under the CPU interpreter with _bf16_interpreter_shim() (see there for
+    exactly what the harness supplies).  Same masks / seeds as the fp16 kernel cases of gen_attn(); the bf16 inputs are the
+    same draws rounded to bf16.  The fp16 cases are repeated here ("_fp16") because the shim also hands `qk_scale` over as
+    the fp32 scalar the compiled kernel receives: with that the oracle agrees with the kernel BIT FOR BIT in both dtypes
+    (attn_cases.npz, made by the stock interpreter with an fp16-literal scale, stays as the looser historical check).
+    Outputs stored as raw 16-bit patterns."""
+    _bf16_interpreter_shim()
+    hy = sys.modules["ref_hy_attn"]
+    torch.cuda.device = lambda *_a, **_k: contextlib.nullcontext()
+    out, meta = {}, {}
+    for ci, (H, nb_img, tb, seqlen_txt, amp, seed) in enumerate(inputs.KERNEL_SPECS):
+        for dt, tag in ((torch.bfloat16, ""), (torch.float16, "_fp16")):
+            q, k, v, mask, seqlen, amp = inputs.kernel_inputs(ci, dtype=dt)
+            seqlens = torch.tensor([seqlen], dtype=torch.int32)
+            o = hy._triton_block_sparse_attention_onehot(q, k, v, seqlens, mask, 128 ** -0.5, 128, 128,
+                                                         text_amp=amp, text_block_start=nb_img)
+            assert o.dtype == dt and bool(torch.isfinite(o[:, :, :min(seqlen, o.shape[2])].float()).all())
+            out[f"k{ci}_o{tag}"] = o.contiguous().view(torch.uint16).numpy()      # raw bit patterns, both dtypes
+            meta[f"k{ci}{tag}"] = dict(H=H, nb_img=nb_img, text_blocks=tb, seqlen=seqlen, text_amp=amp,
+                                       dtype=str(dt).split(".")[1], q_sha256=inputs.tensor_sha(q),
+                                       k_sha256=inputs.tensor_sha(k), v_sha256=inputs.tensor_sha(v),
+                                       mask_sha256=inputs.sha(mask.numpy()))
+    meta["harness"] = ("reference kernel source under TRITON_INTERPRET=1 (triton %s); bf16 scalar constant, bf16*bf16, "
+                       "tl.dot(bf16) and fp32->bf16 RNE supplied by make_golden._bf16_interpreter_shim" % __import__("triton").__version__)
+    np.savez_compressed(os.path.join(OUT, "attn_exact_cases.npz"), **out)
+    with open(os.path.join(OUT, "attn_exact_cases.json"), "w") as f:
         json.dump(meta, f, indent=1, sort_keys=True)
 
 
@@ -911,4 +1014,9 @@ if __name__ == "__main__":
         gen_wan_sched()
     if a.only in ("", "signatures"):
         gen_signatures()
+    if a.only in ("", "attnbf16"):       # last: it patches the interpreter's bf16 entry points
+        if "ref_hy_attn" not in sys.modules:
+            _install_flash_stub()
+            _load("ref_hy_attn", "hyvideo/modules/attention_block_triton_diffres.py")
+        gen_attn_bf16()
     print("golden fixtures written to", OUT)

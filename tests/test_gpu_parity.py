@@ -230,6 +230,25 @@ def test_sparse_kernel_vs_triton_interpreter_golden(golden_dir, dev, index):
     assert (err > 2e-3).mean() < 2e-3
 
 
+@pytest.mark.parametrize("flags", [None, 85], ids=["default", "pair"])
+@pytest.mark.parametrize("dt", ["bfloat16", "float16"])
+@pytest.mark.parametrize("index", range(len(inputs.KERNEL_SPECS)))
+def test_sparse_kernel_vs_reference_kernel_in_the_product_dtype(golden_dir, dev, index, dt, flags):
+    """attn_exact_cases.npz = the reference Triton kernel itself (interpreter, fp32 `qk_scale` argument as compiled; the
+    oracle matches it bit for bit, tests/test_oracle_golden.py).  The HIP kernels differ from it only in the order of the
+    fp32 sums inside the MFMA dots and in v_exp_f32 (1 ulp): a few ulps of the storage type at |o| <= 2."""
+    H, nb_img, tb, seqlen_txt, amp, seed = inputs.KERNEL_SPECS[index]
+    tdt = getattr(torch, dt)
+    g = np.load(os.path.join(golden_dir, "attn_exact_cases.npz"))
+    q, k, v, mask, seqlen, amp = inputs.kernel_inputs(index, dtype=tdt)
+    o = _run_kernel(q, k, v, mask, seqlen, amp, nb_img, dev, flags=flags)
+    ref = torch.from_numpy(g[f"k{index}_o" + ("" if dt == "bfloat16" else "_fp16")]).view(tdt).float().numpy()
+    err = np.abs(o - ref)
+    tol = 1.6e-2 if dt == "bfloat16" else 4e-3            # 2 ulp (bf16: 2^-7 at |o| in [1,2)) / 4 ulp (fp16)
+    assert err.max() <= tol, err.max()
+    assert (err > tol / 4).mean() < 2e-3 and err.mean() < tol / 40
+
+
 @pytest.mark.parametrize("dt,flags", [("bfloat16", None), ("float16", None), ("bfloat16", 9), ("float16", 8), ("bfloat16", 25),
                                       ("bfloat16", 0), ("bfloat16", 1), ("float16", 1),
                                       ("bfloat16", 65), ("float16", 64), ("bfloat16", 69)])

@@ -104,6 +104,25 @@ def test_sparse_kernel_matches_triton_interpreter(golden_dir, index):
     assert (np.abs(o - ref) > 1e-3).mean() < 1e-3
 
 
+@pytest.mark.parametrize("dt", ["bfloat16", "float16"])
+@pytest.mark.parametrize("index", range(len(inputs.KERNEL_SPECS)))
+def test_sparse_kernel_bit_exact_with_the_reference_kernel(golden_dir, index, dt):
+    """tests/golden/attn_exact_cases.npz: the reference Triton kernel run from its source under the CPU interpreter, with
+    `qk_scale` handed over as the fp32 scalar the compiled kernel receives and (bf16) the interpreter's missing bf16
+    arithmetic supplied by the harness (make_golden._bf16_interpreter_shim states exactly what).  Same rounding points,
+    same fp32 np.matmul dots -> the oracle has to reproduce every output BIT, in the dtype the product runs in (bf16)."""
+    H, nb_img, tb, seqlen_txt, amp, seed = inputs.KERNEL_SPECS[index]
+    tag = "" if dt == "bfloat16" else "_fp16"
+    meta = json.load(open(os.path.join(golden_dir, "attn_exact_cases.json")))[f"k{index}{tag}"]
+    g = np.load(os.path.join(golden_dir, "attn_exact_cases.npz"))
+    q, k, v, mask, seqlen, amp = inputs.kernel_inputs(index, dtype=getattr(torch, dt))
+    assert meta["dtype"] == dt and inputs.tensor_sha(q) == meta["q_sha256"] and inputs.tensor_sha(k) == meta["k_sha256"]
+    assert inputs.tensor_sha(v) == meta["v_sha256"] and inputs.sha(mask.numpy()) == meta["mask_sha256"], "RNG drift"
+    o = oa.sparse_rows(to_np(q), to_np(k), to_np(v), [seqlen], mask.numpy(), 128 ** -0.5, dt, amp, nb_img)
+    ref = torch.from_numpy(g[f"k{index}_o{tag}"]).view(getattr(torch, dt)).float().numpy()
+    assert np.array_equal(o, ref), (np.abs(o - ref).max(), (o != ref).mean())
+
+
 def test_whole_op_matches_reference(golden_dir):
     s = inputs.OP_SPEC
     meta = json.load(open(os.path.join(golden_dir, "attn_cases.json")))["op"]
