@@ -1,13 +1,26 @@
-// Block selection: one workgroup per SEL_G consecutive query blocks of one (batch, head) (round 5; one row per workgroup
-// before).  The pooled K of a head (902 x 128 at the 720p shape = 230 KB) is what every row of the head reads: with one row
-// per workgroup that was 5 GB per launch through the L2s, and since workgroup ids go round robin over the 8 XCDs every XCD's
-// 4 MB L2 saw all 24 heads (5.5 MB).  Now a workgroup streams its head's pooled K ONCE for SEL_G rows (the dot products keep
-// their order: per (row, column) the same 128 sequential fmaf), and with (batch * heads) a multiple of 8 all workgroups of a
-// head run on ONE XCD (id % 8), so the re-reads are L2 hits.  Measured (profiles/r05_select_ab.json): 0.70 -> 0.49 ms at the
-// 720p shape; of the 0.70 the one-thread cumulative sum was 0.26 on flat rows (now an exact shuffle scan), the dot products
-// ~0.15, the sort ~0.18, launch + output ~0.1; 2 rows per workgroup is the optimum (4: 0.53-0.73, 8: 0.58-0.77 -- the rows of
-// a group run one after the other, more rows = fewer workgroups to hide the sort's barriers).  The per-row work:
-//   scores -> softmax (dtype) -> sort (bitonic, LDS) -> cumulative-probability / top-k rule -> bit set
+// Block selection (K3-5).  One workgroup = 4 consecutive query blocks of one (batch, head).
+//   phase A (the workgroup): the pooled scores of the 4 rows.  The head's pooled K goes through LDS in tiles of 256 columns x
+//     64 channels with coalesced global loads two tiles ahead; a thread owns one column of the tile and runs, per (row,
+//     column), the same 128 sequential fused multiply-adds as ever -- two rows per v_pk_fma_f32 (an IEEE fma per half), the
+//     pooled Q of the 4 rows in SGPR pairs.
+//   phase B: ONE WAVE OWNS ONE ROW and runs softmax -> sort -> kept-count rule -> bit set -> compaction without another
+//     workgroup barrier: the sort is a bitonic network over 16 keys per lane (registers + wave shuffles), the cumulative sum
+//     an exact shuffle scan, the prefix popcount a shuffle scan.
+// With (batch * heads) a multiple of 8 all workgroups of a head run on ONE XCD (id % 8): its pooled K (230 KB) stays in that
+// XCD's L2.
+// History at the 720p shape, 24 heads x 900 x 902, flat / coherent lists (profiles/r05_select_ab.json):
+//   round 4   one row per workgroup, one-thread cumulative sum                                    0.69 / 0.58 ms
+//   round 5a  2 rows per workgroup run one after the other by all 4 waves (sort: 6 barriers per row),
+//             exact shuffle scan, (b, h) -> XCD map                                                0.63 / 0.50
+//   round 5b  wave per row, v_pk_fma_f32, K row read by its own thread (64 lines per load
+//             instruction: the texture path set the pace, 0.225 of the 0.37)                       0.37 / 0.38
+//   round 5c  K through LDS tiles, coalesced, one tile ahead                                       0.33 / 0.33
+//   round 5d  two tiles ahead (111 VGPRs = the 4 waves per SIMD the 32 KB tile allows anyway)      0.28 / 0.29
+//   (8 rows per workgroup, two per wave: 0.40 -- 132 VGPRs, 3 waves per SIMD.)
+// What is left in 5d (elimination builds): global loads still exposed ~0.10, FMAs + staging ~0.06, sort ~0.04,
+// output ~0.03, launch + softmax + bit set the rest.
+// The per-row work:
+//   scores -> softmax (dtype) -> sort -> cumulative-probability / top-k rule -> bit set
 //   -> OR static neighbours / first-frame / text columns -> ascending index list (+ optional one-hot mask).
 // Rounding points follow the reference's torch code running in the tensor dtype
 // (attention_block_triton_diffres.py:221-250); see include/jenga_amd.h.
@@ -18,105 +31,106 @@
 namespace jenga {
 namespace {
 
-__device__ __forceinline__ float block_reduce_max(float v, float* scratch) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
-    if ((threadIdx.x & 63) == 0) scratch[threadIdx.x >> 6] = v;
-    __syncthreads();
-    float r = scratch[0];
-    for (int i = 1; i < (int)(blockDim.x >> 6); ++i) r = fmaxf(r, scratch[i]);
-    __syncthreads();
-    return r;
-}
-__device__ __forceinline__ float block_reduce_sum(float v, float* scratch) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    if ((threadIdx.x & 63) == 0) scratch[threadIdx.x >> 6] = v;
-    __syncthreads();
-    float r = scratch[0];
-    for (int i = 1; i < (int)(blockDim.x >> 6); ++i) r += scratch[i];
-    __syncthreads();
-    return r;
-}
+typedef float sel_f2 __attribute__((ext_vector_type(2)));
 
 constexpr int MAX_PER_THREAD = 8;  // 256 threads x 8 = up to 2048 image key blocks
-
-// Bitonic sort (descending) of npow2 = 256 * E unique 32-bit keys held in LDS, E consecutive keys per thread in
-// registers: compare-exchange distances below E stay inside a thread, distances below 64 * E are wave shuffles, and
-// only the two or three largest distances go through LDS with a barrier (the plain LDS form below pays 55 barriers
-// at 1024 keys).  Keys are unique, so every correct sort gives the same order: results are unchanged bit for bit.
-template <int E>
-__device__ __forceinline__ void bitonic_sort_desc_regs(uint32_t* keys, int npow2, int tid) {
-    uint32_t v[E];
-#pragma unroll
-    for (int r = 0; r < E; ++r) v[r] = keys[tid * E + r];
-    for (int k = 2; k <= npow2; k <<= 1) {
-        int j = k >> 1;
-        for (; j >= E; j >>= 1) {   // partner element lives in thread tid ^ (j / E), same register index
-            const int pj = j / E;
-            uint32_t pv[E];
-            if (pj < 64) {
-#pragma unroll
-                for (int r = 0; r < E; ++r) pv[r] = (uint32_t)__shfl_xor((int)v[r], pj);
-            } else {
-                __syncthreads();
-#pragma unroll
-                for (int r = 0; r < E; ++r) keys[tid * E + r] = v[r];
-                __syncthreads();
-#pragma unroll
-                for (int r = 0; r < E; ++r) pv[r] = keys[(tid ^ pj) * E + r];
-            }
-            const int i0 = tid * E;   // (i & j) and (i & k) do not depend on r here: j, k >= E
-            const bool take_max = (((i0 & j) == 0) == ((i0 & k) == 0));
-#pragma unroll
-            for (int r = 0; r < E; ++r) v[r] = take_max ? (v[r] > pv[r] ? v[r] : pv[r]) : (v[r] < pv[r] ? v[r] : pv[r]);
-        }
-#pragma unroll
-        for (int jj = E / 2; jj > 0; jj >>= 1) {   // inside the thread, compile-time register indices
-            if (jj < k) {
-#pragma unroll
-                for (int r = 0; r < E; ++r) {
-                    if ((r & jj) == 0) {
-                        const int i = tid * E + r;
-                        const bool desc = ((i & k) == 0);
-                        const uint32_t a = v[r], b = v[r | jj];
-                        const bool sw = desc ? (a < b) : (a > b);
-                        v[r] = sw ? b : a;
-                        v[r | jj] = sw ? a : b;
-                    }
-                }
-            }
-        }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int r = 0; r < E; ++r) keys[tid * E + r] = v[r];
-    __syncthreads();
-}
-
-#ifndef SEL_G_ROWS
-#define SEL_G_ROWS 2
+#ifndef SEL_ROWS
+#define SEL_ROWS 4
 #endif
-constexpr int SEL_G = SEL_G_ROWS;  // query blocks per workgroup
+constexpr int SEL_R = SEL_ROWS;    // query blocks (rows) per workgroup; wave w owns rows w, w + 4, ...: a multiple of 4
 // elimination switches (A/B builds, wrong results): SEL_X & 1 no dot products, 2 no sort, 4 no cumulative sum, 8 no output
 #ifndef SEL_X
 #define SEL_X 0
 #endif
 
-template <typename T>
+// LDS traffic between the lanes of ONE wave (a wave's DS operations execute in order; this only keeps the compiler from
+// moving them across the point)
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// Bitonic sort (descending) of 64 * E unique 32-bit keys held by ONE wave, E consecutive keys per lane in registers
+// (element i = lane * E + r): compare-exchange distances below E stay inside a lane, every larger distance is a wave
+// shuffle -- no LDS, no barrier.  The network is the "mirror" form: every merge of two sorted k/2-runs starts by comparing
+// element i with i ^ (k - 1) (the second run read backwards), then i with i ^ j for j = k/4 .. 1; the lower index always
+// keeps the larger key, so an exchange inside a lane is one v_max + one v_min with compile-time registers, and one across
+// lanes is v_max + v_min + a select on a lane-bit mask.  Keys are unique, so every correct sort gives the same order.
+template <int E>
+__device__ __forceinline__ void wave_bitonic_sort_desc(uint32_t (&v)[E], int lane) {
+#pragma unroll
+    for (int k = 2; k <= 64 * E; k <<= 1) {
+        if (k <= E) {
+#pragma unroll
+            for (int r = 0; r < E; ++r) {
+                const int pr = r ^ (k - 1);
+                if (r < pr) {
+                    const uint32_t a = v[r], b = v[pr];
+                    v[r] = a > b ? a : b;
+                    v[pr] = a > b ? b : a;
+                }
+            }
+        } else {
+            const bool take_max = ((lane * E) & (k >> 1)) == 0;
+            uint32_t pv[E];
+#pragma unroll
+            for (int r = 0; r < E; ++r) pv[r] = (uint32_t)__shfl_xor((int)v[E - 1 - r], k / E - 1);
+#pragma unroll
+            for (int r = 0; r < E; ++r) {
+                const uint32_t mx = v[r] > pv[r] ? v[r] : pv[r], mn = v[r] > pv[r] ? pv[r] : v[r];
+                v[r] = take_max ? mx : mn;
+            }
+        }
+#pragma unroll
+        for (int j = k >> 2; j >= 1; j >>= 1) {
+            if (j >= E) {
+                const bool take_max = ((lane * E) & j) == 0;
+                uint32_t pv[E];      // all E shuffles in flight before the first use
+#pragma unroll
+                for (int r = 0; r < E; ++r) pv[r] = (uint32_t)__shfl_xor((int)v[r], j / E);
+#pragma unroll
+                for (int r = 0; r < E; ++r) {
+                    const uint32_t mx = v[r] > pv[r] ? v[r] : pv[r], mn = v[r] > pv[r] ? pv[r] : v[r];
+                    v[r] = take_max ? mx : mn;
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < E; ++r) {
+                    if ((r & j) == 0) {
+                        const uint32_t a = v[r], b = v[r | j];
+                        v[r] = a > b ? a : b;
+                        v[r | j] = a > b ? b : a;
+                    }
+                }
+            }
+        }
+    }
+}
+
+// E = keys per lane; the row is padded to 64 * E >= nk_img keys.
+template <typename T, int E>
 __global__ void __launch_bounds__(256)
 block_select_kernel(const uint16_t* __restrict__ qpool, const uint16_t* __restrict__ kpool,
                     const uint8_t* __restrict__ neighbors, int nb_rows, int nb_cols, uint8_t* __restrict__ mask,
                     int32_t* __restrict__ idx, int32_t* __restrict__ cnt, int BH, int nq, int nk_img, int text_blocks,
-                    int top_k, float p_thr, int first_frame_blocks, int npow2, int scan_log_nx, int ngrp, int xcd_map) {
+                    int top_k, float p_thr, int first_frame_blocks, int scan_log_nx, int ngrp, int xcd_map) {
+    constexpr int NP = 64 * E;                                           // padded row length
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    uint32_t* keys = reinterpret_cast<uint32_t*>(smem);                 // [npow2]
-    float* qrows = reinterpret_cast<float*>(keys + npow2);              // [SEL_G][128]
-    uint32_t* bits = reinterpret_cast<uint32_t*>(qrows + SEL_G * 128);  // [80]: up to 2048+ columns
-    uint32_t* wpre = bits + 80;                                         // [80] exclusive popcount prefix
-    float* scratch = reinterpret_cast<float*>(wpre + 80);               // [8]
-    int* n_sh = reinterpret_cast<int*>(scratch + 8);                    // [4]
-    float* sbuf = reinterpret_cast<float*>(n_sh + 4);                   // [2 << scan_log_nx] (device-scan mode, W > 64)
+    constexpr int BUF_WORDS = SEL_R * NP > 8192 ? SEL_R * NP : 8192;     // phase A's K tile (32 KB), then the row buffers
+    uint32_t* rowbuf = reinterpret_cast<uint32_t*>(smem);                // [SEL_R][NP]: scores (float), then sorted keys
+    uint32_t* bits_all = rowbuf + BUF_WORDS;                             // [SEL_R][80]: up to 2048 + 512 columns
+    uint32_t* wpre_all = bits_all + SEL_R * 80;                          // [SEL_R][80] exclusive popcount prefix
+    float* sbuf_all = reinterpret_cast<float*>(wpre_all + SEL_R * 80);   // [SEL_R][2 << scan_log_nx] (device-scan, W > 64)
 
     const int nk_all = nk_img + text_blocks;
     const int tid = threadIdx.x;
@@ -135,111 +149,147 @@ block_select_kernel(const uint16_t* __restrict__ qpool, const uint16_t* __restri
         bh = blockIdx.x / ngrp;
         grp = blockIdx.x % ngrp;
     }
-    const int m0 = grp * SEL_G;
-    const int g_n = nq - m0 < SEL_G ? nq - m0 : SEL_G;      // rows of this group
+    const int m0 = grp * SEL_R;
+    const int g_n = nq - m0 < SEL_R ? nq - m0 : SEL_R;      // rows of this group
 
-    for (int e = tid; e < SEL_G * 128; e += 256) {
-        const int g = e >> 7;
-        qrows[e] = g < g_n ? to_f32<T>(qpool[(bh * nq + m0 + g) * 128 + (e & 127)]) : 0.f;
-    }
-    __syncthreads();
-
-    // ---- pooled scores for the image columns (K3): the K row of a column is read once for the SEL_G rows ----
-    const float scale = 0.08838834764831845f;  // float(128 ** -0.5)
-    float scg[SEL_G][MAX_PER_THREAD];
+    // ---- phase A: pooled scores for the image columns (K3) ----
+    // The head's pooled K goes through LDS in tiles of 256 columns x 64 channels (one 128-byte line per row): global loads
+    // with 8 consecutive lanes on one line (a thread reading its own 256-byte row touched 64 lines per load instruction and
+    // the texture path, not the FMAs, set the pace: 0.225 of 0.37 ms), the 16-byte chunk c of row r stored at slot
+    // c ^ ((r >> 1) & 7) so that both the stores (8 lanes per row) and the loads (one row per lane) are conflict-free.  The
+    // next tile's global loads are in flight while this one is consumed.  The scores stay in registers until the last tile is
+    // done; then the tile buffer becomes the row buffer.
+    {
+        const float scale = 0.08838834764831845f;  // float(128 ** -0.5)
+        uint4* tile = reinterpret_cast<uint4*>(smem);          // [256 rows][8 slots]
+        // rows past the end of the head repeat the last one (read, never used)
+        const uint4* qr[SEL_R];
 #pragma unroll
-    for (int i = 0; i < MAX_PER_THREAD; ++i) {
-        const int j = tid + i * 256;
+        for (int g = 0; g < SEL_R; ++g)
+            qr[g] = reinterpret_cast<const uint4*>(qpool + (bh * nq + m0 + (g < g_n ? g : g_n - 1)) * 128);
+        const uint4* kbase = reinterpret_cast<const uint4*>(kpool + bh * nk_all * 128);     // 16 chunks per row
+        const int ntile = (nk_img + 255) >> 8;
+        const int lr = tid >> 3, lc = tid & 7;
+        uint4 pre[2][8];                // pass t lives in pre[t & 1]: two passes of global loads in flight
+        auto gload = [&](uint4 (&dst)[8], int t) {       // pass t = (column tile t >> 1, channel half t & 1)
+            const int r0 = (t >> 1) * 256 + lr;
 #pragma unroll
-        for (int g = 0; g < SEL_G; ++g) scg[g][i] = -INFINITY;
-        if (j < nk_img && (SEL_X & 1)) {
-#pragma unroll
-            for (int g = 0; g < SEL_G; ++g) scg[g][i] = (float)((j * 37 + g * 11) % 97) * 0.01f;
-        } else if (j < nk_img) {
-            const uint4* kr = reinterpret_cast<const uint4*>(kpool + (bh * nk_all + j) * 128);
-            float acc[SEL_G];
-#pragma unroll
-            for (int g = 0; g < SEL_G; ++g) acc[g] = 0.f;
-#pragma unroll
-            for (int c = 0; c < 16; ++c) {
-                float f[8];
-                unpack8<T>(kr[c], f);
-#pragma unroll
-                for (int g = 0; g < SEL_G; ++g)
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) acc[g] = fmaf(qrows[g * 128 + c * 8 + e], f[e], acc[g]);
+            for (int s_ = 0; s_ < 8; ++s_) {
+                const int r = r0 + s_ * 32;
+                dst[s_] = (r < nk_img && !(SEL_X & 1)) ? kbase[(long long)r * 16 + (t & 1) * 8 + lc] : make_uint4(0u, 0u, 0u, 0u);
             }
+        };
+        float scv[MAX_PER_THREAD][SEL_R];
+        gload(pre[0], 0);
+        gload(pre[1], 1);        // (ntile >= 1: both halves of the first tile exist)
 #pragma unroll
-            for (int g = 0; g < SEL_G; ++g) scg[g][i] = round_to<T>(round_to<T>(acc[g]) * scale);
-        }
-    }
-#pragma unroll 1
-    for (int g = 0; g < g_n; ++g) {
-    const int m = m0 + g;
-    const long long row = bh * nq + m;
-    if (tid < 80) bits[tid] = 0u;
-    float sc[MAX_PER_THREAD];
-    float lmax = -INFINITY;
+        for (int ct = 0; ct < MAX_PER_THREAD; ++ct) {
+            if (ct * 256 < NP && ct < ntile) {
+                sel_f2 acc[SEL_R / 2];
 #pragma unroll
-    for (int i = 0; i < MAX_PER_THREAD; ++i) {
-        sc[i] = scg[0][i];
+                for (int g2 = 0; g2 < SEL_R / 2; ++g2) acc[g2] = (sel_f2){0.f, 0.f};
 #pragma unroll
-        for (int g2 = 1; g2 < SEL_G; ++g2) sc[i] = g == g2 ? scg[g2][i] : sc[i];
-        lmax = fmaxf(lmax, sc[i]);
-    }
-    __syncthreads();
-    // ---- softmax over the image columns, rounded to dtype (K4) ----
-    const float rmax = block_reduce_max(lmax, scratch);
-    float lsum = 0.f;
+                for (int half = 0; half < 2; ++half) {
 #pragma unroll
-    for (int i = 0; i < MAX_PER_THREAD; ++i) {
-        const int j = tid + i * 256;
-        if (j < nk_img) {
-            sc[i] = expf(sc[i] - rmax);
-            lsum += sc[i];
-        }
-    }
-    const float rsum = block_reduce_sum(lsum, scratch);
-#pragma unroll
-    for (int i = 0; i < MAX_PER_THREAD; ++i) {
-        const int j = tid + i * 256;
-        if (j < npow2) {
-            uint32_t key = 0u;  // padding sorts last
-            if (j < nk_img) key = ((uint32_t)from_f32<T>(sc[i] / rsum) << 16) | (uint32_t)(0xFFFF - j);
-            keys[j] = key;
-        }
-    }
-    __syncthreads();
-    // ---- bitonic sort, descending on (probability bits, then lower column first) ----
-    if (SEL_X & 2) {
-    } else if (npow2 == 1024) bitonic_sort_desc_regs<4>(keys, npow2, tid);
-    else if (npow2 == 512) bitonic_sort_desc_regs<2>(keys, npow2, tid);
-    else if (npow2 == 256) bitonic_sort_desc_regs<1>(keys, npow2, tid);
-    else if (npow2 == 2048) bitonic_sort_desc_regs<8>(keys, npow2, tid);
-    else
-    for (int k = 2; k <= npow2; k <<= 1) {
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int i = tid; i < npow2; i += 256) {
-                const int l = i ^ j;
-                if (l > i) {
-                    const uint32_t a = keys[i], b = keys[l];
-                    const bool desc = ((i & k) == 0);
-                    if (desc ? (a < b) : (a > b)) {
-                        keys[i] = b;
-                        keys[l] = a;
+                    for (int s_ = 0; s_ < 8; ++s_) {
+                        const int r = s_ * 32 + lr;
+                        tile[r * 8 + (lc ^ ((r >> 1) & 7))] = pre[half][s_];
                     }
+                    __syncthreads();
+                    if (ct * 2 + half + 2 < 2 * ntile) gload(pre[half], ct * 2 + half + 2);
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) {
+                        float f[8];
+                        unpack8<T>(tile[tid * 8 + (c ^ ((tid >> 1) & 7))], f);
+                        float qf[SEL_R][8];
+#pragma unroll
+                        for (int g = 0; g < SEL_R; ++g) unpack8<T>(qr[g][half * 8 + c], qf[g]);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            const sel_f2 ff = (sel_f2){f[e], f[e]};
+#pragma unroll
+                            for (int g2 = 0; g2 < SEL_R / 2; ++g2)
+                                acc[g2] = __builtin_elementwise_fma((sel_f2){qf[2 * g2][e], qf[2 * g2 + 1][e]}, ff, acc[g2]);
+                        }
+                    }
+                    __syncthreads();      // the tile is overwritten by the next pass (or by the scores)
+                }
+#pragma unroll
+                for (int g2 = 0; g2 < SEL_R / 2; ++g2) {
+                    if (SEL_X & 1) {
+                        const int j = ct * 256 + tid;
+                        acc[g2] = (sel_f2){(float)((j * 37 + g2 * 22) % 97) * 0.01f, (float)((j * 37 + g2 * 22 + 11) % 97) * 0.01f};
+                    }
+                    scv[ct][2 * g2] = round_to<T>(round_to<T>(acc[g2].x) * scale);
+                    scv[ct][2 * g2 + 1] = round_to<T>(round_to<T>(acc[g2].y) * scale);
                 }
             }
-            __syncthreads();
+        }
+        float* scw = reinterpret_cast<float*>(rowbuf);
+#pragma unroll
+        for (int ct = 0; ct < MAX_PER_THREAD; ++ct) {
+            const int j = ct * 256 + tid;
+            if (ct * 256 < NP && j < nk_img) {
+#pragma unroll
+                for (int g = 0; g < SEL_R; ++g) scw[g * NP + j] = scv[ct][g];
+            }
         }
     }
+    __syncthreads();
+
+    // ---- phase B: wave g on row m0 + g ----
+    const int lane = tid & 63;
+#pragma unroll 1
+    for (int g = tid >> 6; g < g_n; g += 4) {
+    const int m = m0 + g;
+    const long long row = bh * nq + m;
+    uint32_t* keys = rowbuf + g * NP;
+    uint32_t* bits = bits_all + g * 80;
+    uint32_t* wpre = wpre_all + g * 80;
+    bits[lane] = 0u;
+    if (lane < 16) bits[64 + lane] = 0u;
+
+    // softmax over the image columns, rounded to dtype (K4); lane holds columns lane * E .. lane * E + E - 1
+    float sc[E];
+    float lmax = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < E; ++r) {
+        const int j = lane * E + r;
+        sc[r] = j < nk_img ? __uint_as_float(keys[j]) : -INFINITY;
+        lmax = fmaxf(lmax, sc[r]);
+    }
+    const float rmax = wave_max(lmax);
+    float lsum = 0.f;
+#pragma unroll
+    for (int r = 0; r < E; ++r) {
+        const int j = lane * E + r;
+        if (j < nk_img) {
+            sc[r] = expf(sc[r] - rmax);
+            lsum += sc[r];
+        }
+    }
+    const float rsum = wave_sum(lsum);
+    uint32_t v[E];
+#pragma unroll
+    for (int r = 0; r < E; ++r) {
+        const int j = lane * E + r;
+        v[r] = j < nk_img ? (((uint32_t)from_f32<T>(sc[r] / rsum) << 16) | (uint32_t)(0xFFFF - j)) : 0u;  // padding sorts last
+    }
+    // sort, descending on (probability bits, then lower column first)
+    if (!(SEL_X & 2)) wave_bitonic_sort_desc<E>(v, lane);
+    wave_sync();        // every lane has its scores in registers: the row buffer now takes the sorted keys
+#pragma unroll
+    for (int r = 0; r < E; ++r) keys[lane * E + r] = v[r];
+    wave_sync();
+
     // ---- n = max(#(cumsum <= p) + 1, top_k) ----
+    int count = 0;
     if (SEL_X & 4) {
-        if (tid == 0) *n_sh = top_k;
+        count = top_k - 1;
     } else if (scan_log_nx < 0) {
         // default contract = torch.cumsum of a 16-bit tensor on the CPU (what the reference's goldens were generated
-        // with): sequential fp32 accumulation, each partial rounded to dtype
-        // Round 5.  Wave 0 takes 64 sorted probabilities at a time (one LDS read per lane).
+        // with): sequential fp32 accumulation, each partial rounded to dtype.  The wave takes 64 sorted probabilities at a
+        // time (one LDS read per lane).
         //  * Fast path, bit-identical by construction: the probabilities are 16-bit values and the partial sums stay below
         //    2, so as long as every addend so far is at least 2^-16 (bf16; 2^-13 for fp16) every partial sum -- in ANY order
         //    of addition -- is a multiple of 2^-24 below 2 and therefore exact in fp32: a shuffle scan gives the sequential
@@ -248,37 +298,33 @@ block_select_kernel(const uint16_t* __restrict__ qpool, const uint16_t* __restri
         //    sequential chain itself, every lane redundantly on values broadcast with v_readlane.
         // The partial sums are non-decreasing, so "count while round(acc) <= p, stop at the first miss" equals "count every
         // i with round(acc_i) <= p"; a chunk whose last partial already missed ends the walk.
-        if (tid < 64) {
-            const float exact_min = sizeof(T) && __is_same(T, BF16) ? 1.52587890625e-05f : 1.220703125e-04f;
-            float acc = 0.f;
-            int count = 0;
-            for (int c0 = 0; c0 < nk_img; c0 += 64) {
-                const int col = c0 + tid;
-                const uint32_t mine = col < nk_img ? (keys[col] >> 16) : 0u;
-                const float pv = to_f32<T>((uint16_t)mine);
-                const int last_col = c0 + 63 < nk_img ? 63 : nk_img - 1 - c0;
-                const float smallest = __shfl(pv, last_col);
-                if (smallest >= exact_min) {
-                    float inc = pv;
+        const float exact_min = __is_same(T, BF16) ? 1.52587890625e-05f : 1.220703125e-04f;
+        float acc = 0.f;
+        for (int c0 = 0; c0 < nk_img; c0 += 64) {
+            const int col = c0 + lane;
+            const uint32_t mine = col < nk_img ? (keys[col] >> 16) : 0u;
+            const float pv = to_f32<T>((uint16_t)mine);
+            const int last_col = c0 + 63 < nk_img ? 63 : nk_img - 1 - c0;
+            const float smallest = __shfl(pv, last_col);
+            if (smallest >= exact_min) {
+                float inc = pv;
 #pragma unroll
-                    for (int o = 1; o < 64; o <<= 1) {
-                        const float t_ = __shfl_up(inc, o);
-                        if (tid >= o) inc += t_;
-                    }
-                    const float part = acc + inc;
-                    count += __popcll(__builtin_amdgcn_ballot_w64(col < nk_img && round_to<T>(part) <= p_thr));
-                    acc = __shfl(part, 63);
-                } else {
-#pragma unroll
-                    for (int j = 0; j < 64; ++j) {
-                        const float pj = to_f32<T>((uint16_t)__builtin_amdgcn_readlane((int)mine, j));
-                        acc = acc + pj;
-                        count += (c0 + j < nk_img && round_to<T>(acc) <= p_thr) ? 1 : 0;
-                    }
+                for (int o = 1; o < 64; o <<= 1) {
+                    const float t_ = __shfl_up(inc, o);
+                    if (lane >= o) inc += t_;
                 }
-                if (!(round_to<T>(acc) <= p_thr)) break;      // wave-uniform: every lane holds the same value
+                const float part = acc + inc;
+                count += __popcll(__builtin_amdgcn_ballot_w64(col < nk_img && round_to<T>(part) <= p_thr));
+                acc = __shfl(part, 63);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 64; ++j) {
+                    const float pj = to_f32<T>((uint16_t)__builtin_amdgcn_readlane((int)mine, j));
+                    acc = acc + pj;
+                    count += (c0 + j < nk_img && round_to<T>(acc) <= p_thr) ? 1 : 0;
+                }
             }
-            if (tid == 0) *n_sh = count;
+            if (!(round_to<T>(acc) <= p_thr)) break;      // wave-uniform: every lane holds the same value
         }
     } else {
         // JENGA_SELECT_DEVICE_SCAN: torch.cumsum of a 16-bit tensor on the DEVICE, restated (ATen/native/cuda/
@@ -288,105 +334,96 @@ block_select_kernel(const uint16_t* __restrict__ qpool, const uint16_t* __restri
         // (row_buf is scalar_t); the chunk's last element (also 16-bit) is added to the next chunk's first one.
         // Partials are not monotonic, so ALL columns with cumsum <= p are counted ((cumsum <= p).sum(), :244-245).
         const int nx = 1 << scan_log_nx, W = 2 * nx;
-        if (tid == 0) *n_sh = 0;
-        __syncthreads();
         if (W <= 64) {
-            if (tid < 64) {     // one wave, the chunk in registers, Sklansky steps as wave shuffles
-                float total = 0.f;
-                int count = 0;
-                for (int c0 = 0; c0 < nk_img; c0 += W) {
-                    const int col = c0 + tid;
-                    float v = (tid < W && col < nk_img) ? to_f32<T>((uint16_t)(keys[col] >> 16)) : 0.f;
-                    if (tid == 0) v = round_to<T>(v + total);
-                    for (int m = 0; m <= scan_log_nx; ++m) {
-                        const int sft = 1 << m;
-                        const int src = (tid & ~(2 * sft - 1)) + sft - 1;
-                        const float o = __shfl(v, src & 63);
-                        if (tid & sft) v = round_to<T>(v + o);
-                    }
-                    if (tid < W && col < nk_img && v <= p_thr) ++count;
-                    total = __shfl(v, W - 1);
+            float total = 0.f;      // the chunk in registers, Sklansky steps as wave shuffles
+            for (int c0 = 0; c0 < nk_img; c0 += W) {
+                const int col = c0 + lane;
+                float x = (lane < W && col < nk_img) ? to_f32<T>((uint16_t)(keys[col] >> 16)) : 0.f;
+                if (lane == 0) x = round_to<T>(x + total);
+                for (int s_ = 0; s_ <= scan_log_nx; ++s_) {
+                    const int sft = 1 << s_;
+                    const int src = (lane & ~(2 * sft - 1)) + sft - 1;
+                    const float o = __shfl(x, src & 63);
+                    if (lane & sft) x = round_to<T>(x + o);
                 }
-#pragma unroll
-                for (int o = 32; o > 0; o >>= 1) count += __shfl_xor(count, o);
-                if (tid == 0) *n_sh = count;
+                if (lane < W && col < nk_img && x <= p_thr) ++count;
+                total = __shfl(x, W - 1);
             }
         } else {
+            float* sbuf = sbuf_all + (size_t)g * W;
             float total = 0.f;
-            int count = 0;
             for (int c0 = 0; c0 < nk_img; c0 += W) {
-                for (int e = tid; e < W; e += 256)
+                for (int e = lane; e < W; e += 64)
                     sbuf[e] = (c0 + e < nk_img) ? to_f32<T>((uint16_t)(keys[c0 + e] >> 16)) : 0.f;
-                __syncthreads();
-                if (tid == 0) sbuf[0] = round_to<T>(sbuf[0] + total);
-                __syncthreads();
-                for (int m = 0; m <= scan_log_nx; ++m) {
-                    const int sft = 1 << m;
-                    for (int t = tid; t < nx; t += 256) {
-                        const int a = ((t >> m) << (m + 1)) | sft;
+                wave_sync();
+                if (lane == 0) sbuf[0] = round_to<T>(sbuf[0] + total);
+                wave_sync();
+                for (int s_ = 0; s_ <= scan_log_nx; ++s_) {
+                    const int sft = 1 << s_;
+                    for (int t = lane; t < nx; t += 64) {
+                        const int a = ((t >> s_) << (s_ + 1)) | sft;
                         const int ti = a + (t & (sft - 1)), si = a - 1;
                         sbuf[ti] = round_to<T>(sbuf[ti] + sbuf[si]);
                     }
-                    __syncthreads();
+                    wave_sync();
                 }
-                for (int e = tid; e < W; e += 256)
+                for (int e = lane; e < W; e += 64)
                     if (c0 + e < nk_img && sbuf[e] <= p_thr) ++count;
                 total = sbuf[W - 1];
-                __syncthreads();
+                wave_sync();
             }
-            if (count) atomicAdd(n_sh, count);
         }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) count += __shfl_xor(count, o);
     }
-    __syncthreads();
-    if (tid == 0) {
-        int n = *n_sh + 1;
-        if (n < top_k) n = top_k;
-        if (n > nk_img) n = nk_img;
-        *n_sh = n;
-    }
-    __syncthreads();
-    const int n = *n_sh;
-    for (int i = tid; i < n; i += 256) {
+    int n = count + 1;
+    if (n < top_k) n = top_k;
+    if (n > nk_img) n = nk_img;
+
+    wave_sync();        // bits zeroed above
+    for (int i = lane; i < n; i += 64) {
         const int col = 0xFFFF - (int)(keys[i] & 0xFFFFu);
         atomicOr(&bits[col >> 5], 1u << (col & 31));
     }
     if (neighbors && m < nb_rows) {
         const int lim = nk_img < nb_cols ? nk_img : nb_cols;
         const uint8_t* nr = neighbors + (long long)m * nb_cols;
-        for (int j = tid; j < lim; j += 256)
+        for (int j = lane; j < lim; j += 64)
             if (nr[j]) atomicOr(&bits[j >> 5], 1u << (j & 31));
     }
     if (m < first_frame_blocks) {
         const int lim = first_frame_blocks < nk_all ? first_frame_blocks : nk_all;
-        for (int j = tid; j < lim; j += 256) atomicOr(&bits[j >> 5], 1u << (j & 31));
+        for (int j = lane; j < lim; j += 64) atomicOr(&bits[j >> 5], 1u << (j & 31));
     }
-    for (int j = nk_img + tid; j < nk_all; j += 256) atomicOr(&bits[j >> 5], 1u << (j & 31));
-    __syncthreads();
-    // ---- ascending compaction ----
+    for (int j = nk_img + lane; j < nk_all; j += 64) atomicOr(&bits[j >> 5], 1u << (j & 31));
+    wave_sync();
+    // ---- ascending compaction: exclusive popcount prefix over the (<= 80) words, two shuffle scans ----
     const int nwords = (nk_all + 31) >> 5;     // <= 80 (2048 image + 512 text columns)
-    if (tid < 128) {          // exclusive popcount prefix over the words: two waves, a shuffle scan each, the carry through LDS
-        const int c = tid < nwords ? __popc(bits[tid]) : 0;
-        int inc = c;
+    {
+        const int c0 = lane < nwords ? __popc(bits[lane]) : 0;
+        const int c1 = (lane < 16 && 64 + lane < nwords) ? __popc(bits[64 + lane]) : 0;
+        int i0 = c0, i1 = c1;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) {
-            const int t_ = __shfl_up(inc, o);
-            if ((tid & 63) >= o) inc += t_;
+            const int t0 = __shfl_up(i0, o), t1 = __shfl_up(i1, o);
+            if (lane >= o) {
+                i0 += t0;
+                i1 += t1;
+            }
         }
-        if (tid < 80) wpre[tid] = (uint32_t)(inc - c);
-        if (tid == 63) n_sh[1] = inc;         // popcount of words 0..63
+        const int tot0 = __shfl(i0, 63);
+        wpre[lane] = (uint32_t)(i0 - c0);
+        if (lane < 16) wpre[64 + lane] = (uint32_t)(tot0 + i1 - c1);
+        if (lane == 63 && cnt) cnt[row] = tot0 + i1;
     }
-    __syncthreads();
-    if (tid >= 64 && tid < 80) wpre[tid] += (uint32_t)n_sh[1];
-    __syncthreads();
-    if (tid == nwords - 1 && cnt) cnt[row] = (int)wpre[tid] + __popc(bits[tid]);
-    for (int j = tid; j < nk_all && !(SEL_X & 8); j += 256) {
+    wave_sync();
+    for (int j = lane; j < nk_all && !(SEL_X & 8); j += 64) {
         const uint32_t w = bits[j >> 5];
         const bool on = (w >> (j & 31)) & 1u;
         if (mask) mask[row * nk_all + j] = on ? 1 : 0;
         if (on && idx) idx[row * nk_all + (int)wpre[j >> 5] + __popc(w & ((1u << (j & 31)) - 1u))] = j;
     }
-    __syncthreads();     // keys / bits / wpre / n_sh are reused by the next row
-    }   // rows of the group
+    }   // rows of this wave
 }
 
 
@@ -439,7 +476,7 @@ extern "C" int jenga_block_select(void* stream, const void* qpool, const void* k
     }
     const long long rows = (long long)B * H * nq;
     if (rows == 0) return JENGA_OK;
-    int npow2 = 2;
+    int npow2 = 64;                  // the row, padded to 64 lanes x E keys (E a power of two)
     while (npow2 < nk_img) npow2 <<= 1;
     // device-scan mode: the chunk width torch's launcher would pick for a [rows, nk_img] tensor
     // (get_log_num_threads_x_inner_scan, ATen/native/cuda/ScanUtils.cuh:20-41)
@@ -453,8 +490,8 @@ extern "C" int jenga_block_select(void* stream, const void* qpool, const void* k
         if (l > 9u) l = 9u;
         scan_log_nx = (int)l;
     }
-    const size_t smem = (size_t)npow2 * 4 + SEL_G * 128 * 4 + 80 * 4 * 2 + 8 * 4 + 16 +
-                       (scan_log_nx > 5 ? ((size_t)2 << scan_log_nx) * 4 : 0);
+    const size_t smem = ((size_t)SEL_R * npow2 > 8192 ? (size_t)SEL_R * npow2 : 8192) * 4 + (size_t)SEL_R * 80 * 4 * 2 +
+                        (scan_log_nx > 5 ? (size_t)SEL_R * ((size_t)2 << scan_log_nx) * 4 : 0);
     // the reference compares the dtype cumsum with a Python float: the scalar is rounded to the tensor dtype
     float p_thr;
     if (dtype == JENGA_BF16) {
@@ -466,19 +503,40 @@ extern "C" int jenga_block_select(void* stream, const void* qpool, const void* k
         p_thr = (float)(_Float16)p;
     }
     const long long BH = (long long)B * H;
-    const long long ngrp = (nq + SEL_G - 1) / SEL_G;
+    const long long ngrp = (nq + SEL_R - 1) / SEL_R;
     const int xcd_map = (BH % 8 == 0) ? 1 : 0;
     const long long grid = BH * ngrp;            // (xcd_map: BH % 8 == 0, the same count, another order)
     if (grid > 0x7fffffffLL || BH > 0x7fffffffLL) {
         set_error("jenga_block_select: grid size %lld out of range", grid);
         return JENGA_EINVAL;
     }
-#define LAUNCH_SEL(T)                                                                                                 \
-    hipLaunchKernelGGL(block_select_kernel<T>, dim3((unsigned)grid), dim3(256), smem, (hipStream_t)stream,            \
-                       (const uint16_t*)qpool, (const uint16_t*)kpool, neighbors, (int)nb_rows, (int)nb_cols, mask,   \
-                       idx, cnt, (int)BH, (int)nq, (int)nk_img, (int)text_blocks, (int)top_k, p_thr,                  \
-                       (int)first_frame_blocks, npow2, scan_log_nx, (int)ngrp, xcd_map)
-    if (dtype == JENGA_BF16) LAUNCH_SEL(BF16); else LAUNCH_SEL(FP16);
+    // (only the 1025..2048-column rows need more than the 64 KiB a launch gets without the attribute; the largest
+    //  request, device-scan mode included, is SEL_MAX_SMEM)
+    constexpr int SEL_MAX_SMEM = SEL_R * 2048 * 4 + SEL_R * 80 * 4 * 2 + SEL_R * 1024 * 4;
+#define LAUNCH_SEL(T, E_)                                                                                             \
+    do {                                                                                                              \
+        if (smem > 65536) {                                                                                           \
+            static bool smem_set[64];                                                                                 \
+            lp_set_smem_once(reinterpret_cast<const void*>(block_select_kernel<T, E_>), SEL_MAX_SMEM, smem_set);      \
+        }                                                                                                             \
+        hipLaunchKernelGGL((block_select_kernel<T, E_>), dim3((unsigned)grid), dim3(256), smem, (hipStream_t)stream,  \
+                           (const uint16_t*)qpool, (const uint16_t*)kpool, neighbors, (int)nb_rows, (int)nb_cols,     \
+                           mask, idx, cnt, (int)BH, (int)nq, (int)nk_img, (int)text_blocks, (int)top_k, p_thr,        \
+                           (int)first_frame_blocks, scan_log_nx, (int)ngrp, xcd_map);                                 \
+    } while (0)
+#define LAUNCH_SEL_E(E_)                                                                                              \
+    do {                                                                                                              \
+        if (dtype == JENGA_BF16) LAUNCH_SEL(BF16, E_); else LAUNCH_SEL(FP16, E_);                                     \
+    } while (0)
+    switch (npow2 >> 6) {
+        case 1: LAUNCH_SEL_E(1); break;
+        case 2: LAUNCH_SEL_E(2); break;
+        case 4: LAUNCH_SEL_E(4); break;
+        case 8: LAUNCH_SEL_E(8); break;
+        case 16: LAUNCH_SEL_E(16); break;
+        default: LAUNCH_SEL_E(32); break;
+    }
+#undef LAUNCH_SEL_E
 #undef LAUNCH_SEL
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {

@@ -50,6 +50,17 @@ import json;d=json.loads(open('$O/bench_force_dist.json').read().strip().splitli
     JENGA_ULYSSES_PIPELINE=1 timeout 600 python bench.py $L --sim-exchange-gbps $G > $O/sim8_x${G}_pipe.json 2> $O/sim8_x${G}_pipe.err; python -c "import json;d=json.loads(open('$O/sim8_x${G}_pipe.json').read().strip().splitlines()[-1]);print('sim8 x$G pipelined',d['value'])"
   done
   ;;
+I)  # selection kernel, wave-per-row form: tests, the new reference-kernel goldens, clock + elimination builds
+  timeout 1500 python -m pytest tests/test_gpu_select.py -x -q -m gpu > $O/pytest_select.log 2>&1; tail -4 $O/pytest_select.log
+  timeout 600 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "product_dtype or whole_op or randomized" > $O/pytest_parity.log 2>&1; tail -3 $O/pytest_parity.log
+  for lib in ${LIBS:-base sx1 sx2 sx4 sx8 sx15}; do
+    if [ "$lib" = base ]; then unset JENGA_LIB; else export JENGA_LIB=$PWD/alt_libs/$lib.so; fi
+    for L in "--drop 0.7" "--drop 0.7 --coherent 3 --gain 2"; do
+      timeout 100 python tools/bench_attn.py $L --iters 20 --flags 29 2> $O/$lib.err | python -c "import json,sys;d=json.loads(sys.stdin.read().strip().splitlines()[-1]);print('$lib', '$L', 'select_ms %.4f kept %.1f' % (d['select_ms'], d['kept_mean']))"
+    done
+  done
+  unset JENGA_LIB
+  ;;
 E)  # selection kernel: rows per workgroup and elimination builds (clock only)
   for lib in ${LIBS:-base g1 g2 g8 sx1 sx2 sx4 sx8 sx15}; do
     if [ "$lib" = base ]; then unset JENGA_LIB; else export JENGA_LIB=$PWD/alt_libs/$lib.so; fi
