@@ -240,8 +240,13 @@ int jenga_block_pool(void* stream, const void* x, void* pooled, int64_t B, int64
  *   2 * 2^l columns, l = get_log_num_threads_x_inner_scan(B*H*nq, nk_img) (16 columns x 2 at the production shapes), a
  *   Sklansky network per chunk with EVERY add rounded to the 16-bit dtype, the chunk total carried in the 16-bit dtype;
  *   all columns with cumsum <= p are counted.  tests/test_gpu_select.py checks the kept counts against torch.cumsum on
- *   the device bit for bit.  Default (0): the CPU semantics above. */
+ *   the device bit for bit.  Default (0): the CPU semantics above.
+ *   JENGA_SELECT_HEAD_DIM(d), d in {16, 32, 64}: the scores are scaled by float(d ** -0.5) instead of float(128 ** -0.5)
+ *   (:232 `* head_dim ** -0.5`) -- for heads narrower than 128 channels, whose pooled rows the caller hands over
+ *   zero-padded to 128 (the Triton kernel accepts head dims 16 / 32 / 64 / 128, :155; zero channels add exact zeros to
+ *   every dot product).  Bits 8..15 of flags; 0 = 128. */
 #define JENGA_SELECT_DEVICE_SCAN 1
+#define JENGA_SELECT_HEAD_DIM(d) (((d) & 0xFF) << 8)
 int jenga_block_select(void* stream, const void* qpool, const void* kpool, const uint8_t* neighbors,
                        int64_t nb_rows, int64_t nb_cols, uint8_t* mask, int32_t* idx, int32_t* cnt,
                        int64_t B, int64_t H, int64_t nq, int64_t nk_img, int64_t text_blocks, int64_t top_k,

@@ -633,11 +633,14 @@ def block_pool(x, n_blocks):
 
 
 def block_select(qpool, kpool, neighbors, nk_img, text_blocks, top_k, p, first_frame_blocks=0, want_mask=False,
-                 want_lists=True, flags=None):
+                 want_lists=True, flags=None, head_dim=128):
     """-> (mask uint8 [B,H,nq,nk_all] | None, idx int32 [B,H,nq,nk_all] | None, cnt int32 [B,H,nq] | None).
     flags: SELECT_DEVICE_SCAN = the kept-count rule with torch's DEVICE cumsum semantics (default: CPU semantics, or
-    the JENGA_SELECT_FLAGS environment variable)."""
+    the JENGA_SELECT_FLAGS environment variable).  head_dim in (16, 32, 64): the pooled rows are zero-padded to 128
+    channels and the scores are scaled by head_dim ** -0.5 (JENGA_SELECT_HEAD_DIM)."""
     _need_gpu(qpool, "block_select")
+    if head_dim not in (16, 32, 64, 128):
+        raise ValueError(f"block_select: head_dim must be 16, 32, 64 or 128 (got {head_dim})")
     B, H, nq, _ = qpool.shape
     nk_all = nk_img + text_blocks
     if kpool.shape != (B, H, nk_all, 128):
@@ -656,7 +659,8 @@ def block_select(qpool, kpool, neighbors, nk_img, text_blocks, top_k, p, first_f
         _check(lib().jenga_block_select(_stream(dev), _p(qpool.contiguous()), _p(kpool.contiguous()), _p(neighbors),
                                         nbr, nbc, _p(mask), _p(idx), _p(cnt), B, H, nq, nk_img, text_blocks,
                                         int(top_k), float(p), int(first_frame_blocks), dtype_code(qpool.dtype),
-                                        int(SELECT_DEFAULT_FLAGS if flags is None else flags)),
+                                        int(SELECT_DEFAULT_FLAGS if flags is None else flags) |
+                                        (0 if head_dim == 128 else (head_dim << 8))),
                "jenga_block_select")
     return mask, idx, cnt
 

@@ -123,7 +123,7 @@ __global__ void __launch_bounds__(256)
 block_select_kernel(const uint16_t* __restrict__ qpool, const uint16_t* __restrict__ kpool,
                     const uint8_t* __restrict__ neighbors, int nb_rows, int nb_cols, uint8_t* __restrict__ mask,
                     int32_t* __restrict__ idx, int32_t* __restrict__ cnt, int BH, int nq, int nk_img, int text_blocks,
-                    int top_k, float p_thr, int first_frame_blocks, int scan_log_nx, int ngrp, int xcd_map) {
+                    int top_k, float p_thr, int first_frame_blocks, int scan_log_nx, int ngrp, int xcd_map, float scale) {
     constexpr int NP = 64 * E;                                           // padded row length
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int BUF_WORDS = SEL_R * NP > 8192 ? SEL_R * NP : 8192;     // phase A's K tile (32 KB), then the row buffers
@@ -160,7 +160,6 @@ block_select_kernel(const uint16_t* __restrict__ qpool, const uint16_t* __restri
     // next tile's global loads are in flight while this one is consumed.  The scores stay in registers until the last tile is
     // done; then the tile buffer becomes the row buffer.
     {
-        const float scale = 0.08838834764831845f;  // float(128 ** -0.5)
         uint4* tile = reinterpret_cast<uint4*>(smem);          // [256 rows][8 slots]
         // rows past the end of the head repeat the last one (read, never used)
         const uint4* qr[SEL_R];
@@ -474,6 +473,17 @@ extern "C" int jenga_block_select(void* stream, const void* qpool, const void* k
         set_error("jenga_block_select: dtype must be bf16 or fp16");
         return JENGA_EUNSUPPORTED;
     }
+    // float(head_dim ** -0.5) as torch multiplies a 16-bit tensor by the Python scalar (fp32 opmath)
+    float scale;
+    switch ((flags >> 8) & 0xFF) {
+        case 0: case 128: scale = 0.08838834764831845f; break;
+        case 64: scale = 0.125f; break;
+        case 32: scale = 0.17677669529663687f; break;
+        case 16: scale = 0.25f; break;
+        default:
+            set_error("jenga_block_select: JENGA_SELECT_HEAD_DIM must be 16, 32, 64 or 128 (got %d)", (flags >> 8) & 0xFF);
+            return JENGA_EUNSUPPORTED;
+    }
     const long long rows = (long long)B * H * nq;
     if (rows == 0) return JENGA_OK;
     int npow2 = 64;                  // the row, padded to 64 lanes x E keys (E a power of two)
@@ -522,7 +532,7 @@ extern "C" int jenga_block_select(void* stream, const void* qpool, const void* k
         hipLaunchKernelGGL((block_select_kernel<T, E_>), dim3((unsigned)grid), dim3(256), smem, (hipStream_t)stream,  \
                            (const uint16_t*)qpool, (const uint16_t*)kpool, neighbors, (int)nb_rows, (int)nb_cols,     \
                            mask, idx, cnt, (int)BH, (int)nq, (int)nk_img, (int)text_blocks, (int)top_k, p_thr,        \
-                           (int)first_frame_blocks, scan_log_nx, (int)ngrp, xcd_map);                                 \
+                           (int)first_frame_blocks, scan_log_nx, (int)ngrp, xcd_map, scale);                          \
     } while (0)
 #define LAUNCH_SEL_E(E_)                                                                                              \
     do {                                                                                                              \

@@ -25,10 +25,11 @@ def _seqlens_from_cu(cu_seqlens_q, device):
 
 
 def build_block_index(query, key, top_k, text_blocks, prob_threshold, block_neighbor_list=None,
-                      first_frame_blocks=0, want_mask=False, pooled=None):
+                      first_frame_blocks=0, want_mask=False, pooled=None, head_dim=128):
     """query/key [B,S,H,128] (S multiple of 128).  -> (mask|None, idx, cnt) for the image query blocks.
     Replaces _build_block_index_with_importance_optimized (:198-295).  pooled = (qpool [B,H,nimg,128],
-    kpool [B,H,nb,128]) when the caller's norm+RoPE kernel already produced the block means."""
+    kpool [B,H,nb,128]) when the caller's norm+RoPE kernel already produced the block means.  head_dim < 128: the
+    tensors are zero-padded to 128 channels, the scores scaled by head_dim ** -0.5 (:232)."""
     B, S, H, D = query.shape
     nb = S // BLOCK
     nimg = nb - text_blocks
@@ -38,7 +39,7 @@ def build_block_index(query, key, top_k, text_blocks, prob_threshold, block_neig
         qpool = _capi.block_pool(query, nimg)
         kpool = _capi.block_pool(key, nb)
     return _capi.block_select(qpool, kpool, block_neighbor_list, nimg, text_blocks, top_k, prob_threshold,
-                              first_frame_blocks=first_frame_blocks, want_mask=want_mask)
+                              first_frame_blocks=first_frame_blocks, want_mask=want_mask, head_dim=head_dim)
 
 
 def attencarve_packed(q, k, vt, top_k, seqlens, text_blocks, text_amp, prob_threshold, block_neighbor_list,
@@ -61,8 +62,16 @@ def attencarve_packed(q, k, vt, top_k, seqlens, text_blocks, text_amp, prob_thre
 def _combined(query, key, value, top_k, seqlens, text_blocks, text_amp, prob_threshold, block_neighbor_list,
               shape_xfuse, first_frame_blocks=0, context_size=None, return_mask=False):
     B, S, H, D = query.shape
+    if D not in (16, 32, 64, 128):         # the Triton kernel's own assert (:155)
+        raise ValueError(f"jenga_amd: head_dim must be 16, 32, 64 or 128 (got {D})")
+    head_dim = D
     if D != 128:
-        raise ValueError(f"jenga_amd: head_dim must be 128 (got {D})")
+        # Narrow heads run on the 128-channel kernels with zero channels appended: the extra products are exact zeros in
+        # every dot product (pooled scores, QK^T), the extra output channels are dropped, and the two scales keep the true
+        # head_dim ** -0.5.  No entry script of the reference reaches this (all three models have 128-channel heads), so
+        # it is kept simple rather than fast: 128 / D times the FLOPs.
+        query, key, value = (torch.nn.functional.pad(t, [0, 128 - D]) for t in (query, key, value))
+        D = 128
     if S % BLOCK:
         raise ValueError(f"jenga_amd: sequence length {S} is not a multiple of {BLOCK}")
     nb = S // BLOCK
@@ -72,11 +81,14 @@ def _combined(query, key, value, top_k, seqlens, text_blocks, text_amp, prob_thr
     mask = idx = cnt = None
     if nimg > 0:
         mask, idx, cnt = build_block_index(query, key, top_k, text_blocks, prob_threshold, block_neighbor_list,
-                                           first_frame_blocks, want_mask=return_mask)
+                                           first_frame_blocks, want_mask=return_mask, head_dim=head_dim)
     vt = _capi.pack_v(value, nb)
-    out = _capi.bsattn_fwd(query, key, vt, seqlens, idx, cnt, nimg, D ** -0.5, text_amp, nimg)
+    out = _capi.bsattn_fwd(query, key, vt, seqlens, idx, cnt, nimg, head_dim ** -0.5, text_amp, nimg)
     if context_size is not None and context_size != S:
         out = out[:, :context_size]
+    if head_dim != 128:
+        out = out[..., :head_dim].contiguous()
+        D = head_dim
     if not shape_xfuse:
         out = out.reshape(B, out.shape[1], H * D)
     return (out, mask) if return_mask else out

@@ -60,6 +60,25 @@ def select_inputs(index):
 KERNEL_SPECS = [(2, 4, 2, 70, 0.0, 7), (2, 5, 2, 256, 0.431, 8), (1, 3, 1, 1, 0.25, 9)]
 
 
+NARROW_HEAD_DIMS = (64, 32, 16)        # the other head dims the Triton kernel accepts (:155)
+
+
+def narrow_kernel_inputs(D, dtype=torch.bfloat16):
+    """Kernel case with D-channel heads: -> q [1,2,3*128,D], k, v [1,2,4*128,D], mask, seqlen, text_amp."""
+    H, nb_img, tb = 2, 3, 1
+    gen = torch.Generator().manual_seed(100 + D)
+    S = (nb_img + tb) * 128
+    amp = 1.6 * (128.0 / D) ** 0.5      # same spread of the scaled scores as the 128-channel cases
+    q = (torch.randn(1, H, nb_img * 128, D, generator=gen) * amp).to(dtype)
+    k = (torch.randn(1, H, S, D, generator=gen) * 1.2).to(dtype)
+    v = torch.randn(1, H, S, D, generator=gen).to(dtype)
+    mask = torch.rand(1, H, nb_img, nb_img + tb, generator=gen) < 0.5
+    mask[..., nb_img:] = True
+    for i in range(nb_img):
+        mask[:, :, i, i] = True
+    return q, k, v, mask, nb_img * 128 + 77, 0.3
+
+
 def kernel_inputs(index, dtype=torch.float16):
     """-> q [1,H,nb_img*128,128], k, v [1,H,S,128] fp16 (or the same draws rounded to `dtype`), mask bool
     [1,H,nb_img,nb_all], seqlen, text_amp."""

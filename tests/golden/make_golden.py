@@ -302,6 +302,16 @@ def gen_attn_bf16():
                                        dtype=str(dt).split(".")[1], q_sha256=inputs.tensor_sha(q),
                                        k_sha256=inputs.tensor_sha(k), v_sha256=inputs.tensor_sha(v),
                                        mask_sha256=inputs.sha(mask.numpy()))
+    # --- the other head dims the kernel accepts (:155), bf16
+    for D in inputs.NARROW_HEAD_DIMS:
+        q, k, v, mask, seqlen, amp = inputs.narrow_kernel_inputs(D)
+        nb_img = q.shape[2] // 128
+        o = hy._triton_block_sparse_attention_onehot(q, k, v, torch.tensor([seqlen], dtype=torch.int32), mask, D ** -0.5,
+                                                     128, 128, text_amp=amp, text_block_start=nb_img)
+        assert o.dtype == torch.bfloat16 and o.shape == q.shape
+        out[f"d{D}_o"] = o.contiguous().view(torch.uint16).numpy()
+        meta[f"d{D}"] = dict(head_dim=D, seqlen=seqlen, text_amp=amp, dtype="bfloat16", q_sha256=inputs.tensor_sha(q),
+                             k_sha256=inputs.tensor_sha(k), v_sha256=inputs.tensor_sha(v), mask_sha256=inputs.sha(mask.numpy()))
     meta["harness"] = ("reference kernel source under TRITON_INTERPRET=1 (triton %s); bf16 scalar constant, bf16*bf16, "
                        "tl.dot(bf16) and fp32->bf16 RNE supplied by make_golden._bf16_interpreter_shim" % __import__("triton").__version__)
     np.savez_compressed(os.path.join(OUT, "attn_exact_cases.npz"), **out)

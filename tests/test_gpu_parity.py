@@ -198,7 +198,7 @@ def test_select_vs_oracle_larger(dev):
 
 
 # ----------------------------------------------------------------------------------------------- sparse kernel
-def _run_kernel(q_bhsd, k_bhsd, v_bhsd, mask, seqlen, amp, nb_img, dev, flags=None):
+def _run_kernel(q_bhsd, k_bhsd, v_bhsd, mask, seqlen, amp, nb_img, dev, flags=None, sm_scale=None):
     """inputs in the reference kernel's [B,H,S,D] layout -> o [B,H,Sq_img,D] (image rows only)."""
     from jenga_amd import _capi
     B, H, Sq, D = q_bhsd.shape
@@ -212,7 +212,8 @@ def _run_kernel(q_bhsd, k_bhsd, v_bhsd, mask, seqlen, amp, nb_img, dev, flags=No
     idx, cnt = lists_from_mask(mask, dev)
     vt = _capi.pack_v(v, nb)
     seqlens = torch.tensor([seqlen] * B, dtype=torch.int32, device=dev)
-    o = _capi.bsattn_fwd(q, k, vt, seqlens, idx, cnt, nb_img, D ** -0.5, amp, nb_img, flags=flags)
+    o = _capi.bsattn_fwd(q, k, vt, seqlens, idx, cnt, nb_img, D ** -0.5 if sm_scale is None else sm_scale, amp, nb_img,
+                         flags=flags)
     torch.cuda.synchronize()
     return o.transpose(1, 2)[:, :, :Sq].float().cpu().numpy()
 
@@ -247,6 +248,52 @@ def test_sparse_kernel_vs_reference_kernel_in_the_product_dtype(golden_dir, dev,
     tol = 1.6e-2 if dt == "bfloat16" else 4e-3            # 2 ulp (bf16: 2^-7 at |o| in [1,2)) / 4 ulp (fp16)
     assert err.max() <= tol, err.max()
     assert (err > tol / 4).mean() < 2e-3 and err.mean() < tol / 40
+
+
+@pytest.mark.parametrize("flags", [None, 85], ids=["default", "pair"])
+@pytest.mark.parametrize("D", inputs.NARROW_HEAD_DIMS)
+def test_narrow_heads_kernel_vs_reference_kernel(golden_dir, dev, D, flags):
+    """Head dims 64 / 32 / 16: the 128-channel kernels on zero-padded channels, sm_scale = D ** -0.5, against the reference
+    kernel's own bf16 output at that head dim (attn_exact_cases.npz)."""
+    g = np.load(os.path.join(golden_dir, "attn_exact_cases.npz"))
+    q, k, v, mask, seqlen, amp = inputs.narrow_kernel_inputs(D)
+    pad = lambda t: torch.nn.functional.pad(t, [0, 128 - D])
+    o = _run_kernel(pad(q), pad(k), pad(v), mask, seqlen, amp, q.shape[2] // 128, dev, flags=flags, sm_scale=D ** -0.5)
+    assert np.abs(o[..., D:]).max() == 0.0                 # zero V channels -> exact zeros
+    ref = torch.from_numpy(g[f"d{D}_o"]).view(torch.bfloat16).float().numpy()
+    err = np.abs(o[..., :D] - ref)
+    assert err.max() <= 3.2e-2, err.max()                  # 2 bf16 ulp at |o| in [2,4)
+    assert err.mean() < 1.5e-3                             # (a rounding flip of the bf16 output costs 2e-3 at |o| ~ 0.5)
+
+
+@pytest.mark.parametrize("D", inputs.NARROW_HEAD_DIMS)
+def test_narrow_heads_whole_op_vs_oracle(dev, D):
+    """The op at head dims 64 / 32 / 16 (HY flavour): selection with head_dim ** -0.5 (JENGA_SELECT_HEAD_DIM), attention,
+    text rows -- every row against the oracle run at the true head dim on the HIP pooling kernel's block means."""
+    from jenga_amd import _capi
+    from jenga_amd.modules import attention_block_sparse as op
+    from oracle import attention as oa
+    from oracle import gilbert as og
+    gen = torch.Generator().manual_seed(50 + D)
+    H, tb = 2, 2
+    nbm = og.gilbert_block_neighbor_mapping(2, 8, 64, 128)   # 1024 tokens = 8 blocks
+    S = 10 * 128
+    q, k = inputs.peaky_qk(gen, 1, H, 10, 10, D, 0.8)
+    q = q.transpose(1, 2).to(torch.bfloat16).contiguous()
+    k = k.transpose(1, 2).to(torch.bfloat16).contiguous()
+    v = torch.randn(1, S, H, D, generator=gen).to(torch.bfloat16)
+    cu = torch.tensor([0, 8 * 128 + 60, S], dtype=torch.int32)
+    o = op.block_sparse_attention(q.to(dev), k.to(dev), v.to(dev), 3, cu_seqlens_q=cu.to(dev), cu_seqlens_kv=cu.to(dev),
+                                  text_blocks=tb, text_amp=0.2, block_neighbor_list=torch.from_numpy(nbm),
+                                  p_remain_rates=0.3)
+    assert o.shape == (1, S, H * D)
+    pad = lambda t: torch.nn.functional.pad(t, [0, 128 - D]).to(dev)
+    qp = _capi.block_pool(pad(q), 8).float().cpu().numpy()[..., :D]
+    kp = _capi.block_pool(pad(k), 10).float().cpu().numpy()[..., :D]
+    ref = oa.block_sparse_attention(to_np(q), to_np(k), to_np(v), 3, "bfloat16", cu_seqlens_q=cu.numpy(), text_blocks=tb,
+                                    text_amp=0.2, block_neighbor_list=nbm, p_remain_rates=0.3, pooled=(qp, kp))
+    err = np.abs(o.float().cpu().numpy().reshape(ref.shape) - ref)
+    assert np.median(err) < 2e-3 and int((err.max(-1) > 3e-2).sum()) == 0, err.max()
 
 
 @pytest.mark.parametrize("dt,flags", [("bfloat16", None), ("float16", None), ("bfloat16", 9), ("float16", 8), ("bfloat16", 25),

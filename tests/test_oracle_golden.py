@@ -123,6 +123,18 @@ def test_sparse_kernel_bit_exact_with_the_reference_kernel(golden_dir, index, dt
     assert np.array_equal(o, ref), (np.abs(o - ref).max(), (o != ref).mean())
 
 
+@pytest.mark.parametrize("D", inputs.NARROW_HEAD_DIMS)
+def test_sparse_kernel_bit_exact_with_the_reference_kernel_narrow_heads(golden_dir, D):
+    """Head dims 64 / 32 / 16 (the reference kernel accepts them, :155): same harness, bf16, bit for bit."""
+    meta = json.load(open(os.path.join(golden_dir, "attn_exact_cases.json")))[f"d{D}"]
+    g = np.load(os.path.join(golden_dir, "attn_exact_cases.npz"))
+    q, k, v, mask, seqlen, amp = inputs.narrow_kernel_inputs(D)
+    assert inputs.tensor_sha(q) == meta["q_sha256"] and inputs.tensor_sha(v) == meta["v_sha256"], "RNG drift"
+    o = oa.sparse_rows(to_np(q), to_np(k), to_np(v), [seqlen], mask.numpy(), D ** -0.5, "bfloat16", amp, q.shape[2] // 128)
+    ref = torch.from_numpy(g[f"d{D}_o"]).view(torch.bfloat16).float().numpy()
+    assert np.array_equal(o, ref), (np.abs(o - ref).max(), (o != ref).mean())
+
+
 def test_whole_op_matches_reference(golden_dir):
     s = inputs.OP_SPEC
     meta = json.load(open(os.path.join(golden_dir, "attn_cases.json")))["op"]
