@@ -12,16 +12,26 @@ ARCH = "gfx950"
 # dtype": no fused multiply-adds (-ffp-contract=off) and no v_fma_mix*_f16 -- hipcc otherwise folds `half(float(a) * b)`
 # into one mixed-precision instruction that rounds the exact product ONCE, where torch rounds to fp32 first and to fp16
 # second (found in round 2: 1e-4 of the fp16 RMSNorm outputs differed by an ulp from the reference for that reason).
-EAGER = ["-ffp-contract=off", "-Xclang", "-target-feature", "-Xclang", "-fma-mix-insts"]
+# -fno-slp-vectorize (round 5): the compiler's SLP pass turns adjacent scalar fp32 operations into v_pk_mul_f32 / v_pk_add_f32
+# on register pairs it assembles with v_mov / v_lshlrev right before the packed instruction.  On the MI355X boxes of this pool
+# those kernels (ln_modulate, rmsnorm_rope, qk_norm_rope_pool) returned WRONG VALUES -- the low half of one pair, lanes 48..63
+# of a wave, up to 65 % of the calls -- whenever ANOTHER PROCESS kept the same GPU busy, and never otherwise; torch's own
+# kernels, the kernels without compiler-packed arithmetic and the explicit v_pk_fma_f32 of select.hip stayed clean over
+# 20 000+ calls each (tools/diag_victim.py, profiles/r05_packed_fp32_under_gpu_sharing.json).  Without the pass: 0 mismatches.
+# -packed-fp32-ops on top: no v_pk_*_f32 at all from the sources that do not ask for them explicitly (the vector combiner
+# still produced 32 in rmsnorm_rows_kernel without it).  (hipcc repeats "not a recognized feature" for the HOST pass.)
+NO_SLP = ["-fno-slp-vectorize"]
+NO_PK = NO_SLP + ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]
+EAGER = ["-ffp-contract=off", "-Xclang", "-target-feature", "-Xclang", "-fma-mix-insts"] + NO_SLP
 SOURCES = [
     ("capi.cpp", []),
     ("gemm.cpp", []),          # host code: hipBLASLt GEMMs with epilogues torch's front-end does not expose
-    ("gilbert.hip", []),
-    ("rowops.hip", EAGER),
-    ("select.hip", EAGER),
+    ("gilbert.hip", NO_PK),
+    ("rowops.hip", EAGER + NO_PK[1:]),
+    ("select.hip", EAGER + NO_PK[1:]),
     # no NaNs are produced on the attention path (masked logits are -inf, never inf-inf); without this flag every
     # fmaxf on an MFMA result is preceded by a canonicalising v_max.  Infinities stay honoured.
-    ("bsattn.hip", ["-fno-honor-nans"]),
+    ("bsattn.hip", ["-fno-honor-nans"] + NO_PK),
     # no SLP vectorisation: v_pk_add_f32 beside MFMAs costs more than the two scalar adds it replaces (guide, per-
     # instruction table); the softmax of the LP kernel is placed instruction by instruction into the MFMA gaps
     # -Wno-inline-asm: the LDS-DMA helpers write M0 and say so in their clobber lists (a compiler-generated M0 user

@@ -12,6 +12,10 @@ namespace {
 // pack_v 5.2-5.5 -> 6.0, LayerNorm+modulate 5.5 -> 5.6 (profiles/r04_row_kernels_streaming_ab.json).  Small reused operands
 // (weights, modulation rows, cos / sin tables, indices) keep ordinary loads.
 typedef unsigned int jenga_u32x4 __attribute__((ext_vector_type(4)));
+#ifdef JENGA_NO_NT      // A/B switch (tools/diag_det.py): ordinary accesses instead of the streaming ones
+__device__ __forceinline__ uint4 ld_stream(const void* p) { return *reinterpret_cast<const uint4*>(p); }
+__device__ __forceinline__ void st_stream(void* p, const uint4 v) { *reinterpret_cast<uint4*>(p) = v; }
+#else
 __device__ __forceinline__ uint4 ld_stream(const void* p) {
     const jenga_u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const jenga_u32x4*>(p));
     return make_uint4(v.x, v.y, v.z, v.w);
@@ -20,6 +24,7 @@ __device__ __forceinline__ void st_stream(void* p, const uint4 v) {
     const jenga_u32x4 w = {v.x, v.y, v.z, v.w};
     __builtin_nontemporal_store(w, reinterpret_cast<jenga_u32x4*>(p));
 }
+#endif
 
 // ------------------------------------------------------------------------------------------------ gather
 // dst[b, i, :] = src[b, index[i], :]; one workgroup per output row (grid-stride), 16 B per lane.

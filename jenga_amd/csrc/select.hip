@@ -1,8 +1,8 @@
 // Block selection (K3-5).  One workgroup = 4 consecutive query blocks of one (batch, head).
 //   phase A (the workgroup): the pooled scores of the 4 rows.  The head's pooled K goes through LDS in tiles of 256 columns x
 //     64 channels with coalesced global loads two tiles ahead; a thread owns one column of the tile and runs, per (row,
-//     column), the same 128 sequential fused multiply-adds as ever -- two rows per v_pk_fma_f32 (an IEEE fma per half), the
-//     pooled Q of the 4 rows in SGPR pairs.
+//     column), the same 128 sequential fused multiply-adds as ever, the pooled Q of the 4 rows in SGPRs (the K value is
+//     unpacked once for the 4 rows).
 //   phase B: ONE WAVE OWNS ONE ROW and runs softmax -> sort -> kept-count rule -> bit set -> compaction without another
 //     workgroup barrier: the sort is a bitonic network over 16 keys per lane (registers + wave shuffles), the cumulative sum
 //     an exact shuffle scan, the prefix popcount a shuffle scan.
@@ -12,10 +12,11 @@
 //   round 4   one row per workgroup, one-thread cumulative sum                                    0.69 / 0.58 ms
 //   round 5a  2 rows per workgroup run one after the other by all 4 waves (sort: 6 barriers per row),
 //             exact shuffle scan, (b, h) -> XCD map                                                0.63 / 0.50
-//   round 5b  wave per row, v_pk_fma_f32, K row read by its own thread (64 lines per load
+//   round 5b  wave per row, 4 rows per K value, K row read by its own thread (64 lines per load
 //             instruction: the texture path set the pace, 0.225 of the 0.37)                       0.37 / 0.38
 //   round 5c  K through LDS tiles, coalesced, one tile ahead                                       0.33 / 0.33
 //   round 5d  two tiles ahead (111 VGPRs = the 4 waves per SIMD the 32 KB tile allows anyway)      0.28 / 0.29
+//   round 5e  scalar fmas instead of v_pk_fma_f32 (see build.py), no SLP vectorisation            0.28 / 0.28
 //   (8 rows per workgroup, two per wave: 0.40 -- 132 VGPRs, 3 waves per SIMD.)
 // What is left in 5d (elimination builds): global loads still exposed ~0.10, FMAs + staging ~0.06, sort ~0.04,
 // output ~0.03, launch + softmax + bit set the rest.
@@ -205,10 +206,19 @@ block_select_kernel(const uint16_t* __restrict__ qpool, const uint16_t* __restri
                         for (int g = 0; g < SEL_R; ++g) unpack8<T>(qr[g][half * 8 + c], qf[g]);
 #pragma unroll
                         for (int e = 0; e < 8; ++e) {
+#ifdef SEL_PK           // A/B: two rows per v_pk_fma_f32 (0.316 / 0.324 ms against 0.278 / 0.278 with the scalar chains: the
+                        // phase is latency-bound, and packed fp32 arithmetic is avoided in this library, see build.py)
                             const sel_f2 ff = (sel_f2){f[e], f[e]};
 #pragma unroll
                             for (int g2 = 0; g2 < SEL_R / 2; ++g2)
                                 acc[g2] = __builtin_elementwise_fma((sel_f2){qf[2 * g2][e], qf[2 * g2 + 1][e]}, ff, acc[g2]);
+#else
+#pragma unroll
+                            for (int g2 = 0; g2 < SEL_R / 2; ++g2) {
+                                acc[g2].x = fmaf(qf[2 * g2][e], f[e], acc[g2].x);
+                                acc[g2].y = fmaf(qf[2 * g2 + 1][e], f[e], acc[g2].y);
+                            }
+#endif
                         }
                     }
                     __syncthreads();      // the tile is overwritten by the next pass (or by the scores)

@@ -165,3 +165,67 @@ def hip_pooled(q, k, text_blocks, dev, bf16=False):
     kp = _capi.block_pool(kd.contiguous(), nb)
     torch.cuda.synchronize()
     return qp.float().cpu().numpy(), kp.float().cpu().numpy()
+
+
+# ---- multi-process runs on ONE GPU (tests/test_gpu_rccl.py): the exchange goes through the host on a gloo group -------------
+class _HostDone:
+    def wait(self):
+        return True
+
+
+class HostStagedExchange:
+    """Test infrastructure: the interface of jenga_amd.modules.ulysses.DistExchange (all_to_all / all_gather on [N, ...]
+    buffers) on a gloo process group, every buffer staged through host memory -- so that N real processes that SHARE one GPU
+    (RCCL refuses two ranks on one device) can run the product's sequence-parallel path with its HIP local steps."""
+
+    def __init__(self, group=None):
+        import torch.distributed as dist
+        self.dist, self.group = dist, group
+        self.bytes_out = 0
+        self.calls = 0
+
+    def size(self):
+        return self.dist.get_world_size(self.group)
+
+    def rank(self):
+        return self.dist.get_rank(self.group)
+
+    def all_to_all(self, recvs, sends):
+        self.calls += 1
+        for rc, sd in zip(recvs, sends):
+            torch.cuda.synchronize(sd.device)
+            h_in = sd.contiguous().cpu()
+            h_out = torch.empty_like(h_in)
+            self.dist.all_to_all_single(h_out, h_in, group=self.group)
+            rc.copy_(h_out.to(rc.device))
+        return [_HostDone()]
+
+    def all_gather(self, out, x):
+        self.calls += 1
+        torch.cuda.synchronize(x.device)
+        h = x.contiguous().cpu()
+        parts = [torch.empty_like(h) for _ in range(self.size())]
+        self.dist.all_gather(parts, h, group=self.group)
+        out.copy_(torch.stack(parts, 0).to(out.device).view_as(out))
+        return _HostDone()
+
+
+class HostStagedGroup:
+    """The group object of jenga_amd.modules.ulysses.set_thread_sp_group (.size, .rank, .all_gather(x, dim), .group) on gloo."""
+
+    def __init__(self, group=None):
+        import torch.distributed as dist
+        self.dist, self.group = dist, group if group is not None else dist.group.WORLD
+
+    def size(self):
+        return self.dist.get_world_size(self.group)
+
+    def rank(self):
+        return self.dist.get_rank(self.group)
+
+    def all_gather(self, x, dim=0):
+        torch.cuda.synchronize(x.device)
+        h = x.contiguous().cpu()
+        parts = [torch.empty_like(h) for _ in range(self.size())]
+        self.dist.all_gather(parts, h, group=self.group)
+        return torch.cat(parts, dim=dim).to(x.device)

@@ -62,7 +62,7 @@ def _time_exchange(ex, dev, N, rank, reps=5):
     return out
 
 
-def _worker(rank, world, port, outdir):
+def _worker(rank, world, port, outdir, shared_gpu=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       LOCAL_RANK=str(rank))
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -70,17 +70,27 @@ def _worker(rank, world, port, outdir):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import torch.distributed as dist
-    torch.cuda.set_device(rank)
-    dev = torch.device("cuda", rank)
-    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-    rec = {"world": world, "rank": rank, "modes": {}}
+    # shared_gpu: every rank is its own process ON THE SAME DEVICE; the exchange goes through the host on gloo
+    # (tests/helpers.HostStagedExchange) -- RCCL refuses two ranks on one device
+    dev = torch.device("cuda", 0 if shared_gpu else rank)
+    torch.cuda.set_device(dev)
+    if shared_gpu:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    else:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    rec = {"world": world, "rank": rank, "modes": {}, "shared_gpu": bool(shared_gpu)}
     try:
         from jenga_amd import dit
         from jenga_amd.modules import ulysses
         from test_gpu_sp_dit import _model
         ulysses.init_sequence_parallel()
+        if shared_gpu:
+            from helpers import HostStagedExchange, HostStagedGroup
+            ulysses.set_thread_sp_group(HostStagedGroup())
         N = world
         latent, n_txt = (4, 40, 80), 256            # 3200 image tokens = 25 blocks; S_loc = 400 at N = 8, 1600 at N = 2
+        if os.environ.get("JENGA_TEST_LATENT"):     # (diagnostics: another shape)
+            latent = tuple(int(v) for v in os.environ["JENGA_TEST_LATENT"].split(","))
         S_img = latent[0] * (latent[1] // 2) * (latent[2] // 2)
         assert S_img % N == 0
         base = _model(dev)                          # same seed in every process -> same weights on every rank
@@ -115,9 +125,9 @@ def _worker(rank, world, port, outdir):
         finally:
             dit._select_top_k = orig
         torch.cuda.synchronize(dev)
-        for mode in ("p2p", "a2a"):
+        for mode in (("host-staged",) if shared_gpu else ("p2p", "a2a")):
             m = copy.deepcopy(base)
-            ex = ulysses.DistExchange(ulysses.get_sp_group().group, mode=mode)
+            ex = HostStagedExchange() if shared_gpu else ulysses.DistExchange(ulysses.get_sp_group().group, mode=mode)
             for blk in list(m.double_blocks) + list(m.single_blocks):
                 blk.hybrid_seq_parallel_attn = ulysses.UlyssesAttenCarve(exchange=ex)
             c, s = configure(m)
@@ -134,10 +144,10 @@ def _worker(rank, world, port, outdir):
                 assert exact or (frac <= 5e-3 and err.mean().item() <= 3e-3), (mode, rank, mrec[-1])
             assert m.previous_residual.shape[1] == S_img // N     # the residual cache is the LOCAL shard
             rec["modes"][mode] = {"steps": mrec}
-            if N > 1:
+            if N > 1 and not shared_gpu:
                 rec["modes"][mode]["exchange_720p_shard"] = _time_exchange(ex, dev, N, rank)
         # every rank must hold the same gathered output (assembled from all shards): compare a checksum across ranks
-        chk = torch.stack([gq.float().sum() for gq in got]).to(dev)
+        chk = torch.stack([gq.float().sum() for gq in got]).to("cpu" if shared_gpu else dev)
         allc = [torch.empty_like(chk) for _ in range(world)]
         dist.all_gather(allc, chk)
         assert all(torch.equal(a_, allc[0]) for a_ in allc), "ranks hold different gathered outputs"
@@ -147,16 +157,17 @@ def _worker(rank, world, port, outdir):
         dist.destroy_process_group()
 
 
-def _run_world(world):
+def _run_world(world, shared_gpu=False):
     import torch.multiprocessing as mp
     with tempfile.TemporaryDirectory() as d:
-        mp.spawn(_worker, args=(world, _free_port(), d), nprocs=world, join=True)
+        mp.spawn(_worker, args=(world, _free_port(), d, shared_gpu), nprocs=world, join=True)
         recs = [json.load(open(os.path.join(d, f"rank{r}.json"))) for r in range(world)]
     assert all(r.get("ok") for r in recs), recs
     try:
         out = os.path.join(ROOT, "gpurun_out", "parity_records")
         os.makedirs(out, exist_ok=True)
-        json.dump({"world": world, "ranks": recs}, open(os.path.join(out, f"rccl_world{world}.json"), "w"), indent=1)
+        name = f"shared_gpu_world{world}.json" if shared_gpu else f"rccl_world{world}.json"
+        json.dump({"world": world, "ranks": recs}, open(os.path.join(out, name), "w"), indent=1)
     except OSError:
         pass
     return recs
@@ -167,6 +178,19 @@ def test_sp_dit_forward_over_rccl_world1_harness():
     assert torch.cuda.is_available(), "GPU tests need a GPU"
     recs = _run_world(1)
     assert set(recs[0]["modes"]) == {"p2p", "a2a"}
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_sp_dit_forward_n_processes_sharing_one_gpu(world):
+    """N REAL processes (own library state, own streams, own process-group rank), all on device 0, the product's
+    sequence-parallel forward with its HIP local steps (prologue, pack, selection with top_k = N * int(...), attention on the
+    rank's heads, unpack), the two exchanges and the output all-gather going through the host on a gloo group
+    (tests/helpers.HostStagedExchange -- RCCL refuses two ranks on one device).  Same rule as the RCCL test: over computed ->
+    skipped -> computed steps every rank's output equals the single-rank forward with the multi-GPU top_k.  What this adds to
+    the thread-simulated ranks of tests/test_gpu_sp_dit.py: process isolation; what it cannot show: RCCL itself with N > 1."""
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    recs = _run_world(world, shared_gpu=True)
+    assert all(set(r["modes"]) == {"host-staged"} for r in recs)
 
 
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs at least two GPUs (one rank per GPU over RCCL / xGMI)")

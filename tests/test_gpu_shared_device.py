@@ -1,0 +1,39 @@
+"""GPU (-m gpu): every kernel of the library returns the same bits while ANOTHER PROCESS keeps the same GPU busy.
+
+Round 5 finding: with compiler-packed fp32 arithmetic (v_pk_mul_f32 / v_pk_add_f32, the SLP vectoriser's output) ln_modulate,
+rmsnorm_rope and qk_norm_rope_pool returned wrong values -- the low half of one register pair, lanes 48..63 of a wave, in up to
+65 % of the calls -- under exactly this condition and never otherwise; torch's own kernels and the kernels without packed
+arithmetic did not.  The library is built without packed fp32 since (jenga_amd/build.py; tests/test_isa_cpu.py pins it);
+this test is the behavioural side: a load process (torch GEMMs + elementwise, no library code) and a victim process that
+repeats each kernel on fixed inputs for a few seconds and counts results that differ from the first one.
+Record: profiles/r05_packed_fp32_under_gpu_sharing.json."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_kernels_are_bit_stable_under_load_from_another_process():
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    env = dict(os.environ, DIAG_LOAD="torch", DIAG_SECS="6")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "diag_victim.py")], env=env, stdout=subprocess.PIPE,
+                       stderr=subprocess.STDOUT, timeout=600)
+    lines = [ln for ln in r.stdout.decode().splitlines() if ln.startswith("{")]
+    assert r.returncode == 0 and len(lines) == 2, r.stdout.decode()[-3000:]
+    load, victim = (json.loads(ln) for ln in lines)
+    assert load["load_iterations"] > 100, load                      # the load really ran beside the victim
+    assert victim["runs_per_op"] >= 500, victim
+    bad = {k: v for k, v in victim["mismatches"].items() if v}
+    assert not bad, f"results changed under load: {bad} of {victim['runs_per_op']} runs per kernel"
+    try:
+        out = os.path.join(ROOT, "gpurun_out", "parity_records")
+        os.makedirs(out, exist_ok=True)
+        json.dump({"load": load, "victim": victim}, open(os.path.join(out, "shared_device_bit_stability.json"), "w"), indent=1)
+    except OSError:
+        pass

@@ -114,3 +114,19 @@ def test_pair_kernel_asm_mfmas_have_no_uncovered_hazard(asm_pair):
         assert n >= 400, (name, n)          # the asm form is really there (scores in VGPRs)
         bad = Hz.check(lines)
         assert not bad, (name, bad[:4])
+
+
+@pytest.mark.parametrize("src", ["rowops.hip", "select.hip", "gilbert.hip", "bsattn.hip", "bsattn3.hip", "bsattn5.hip"])
+def test_no_packed_fp32_arithmetic_in_the_device_code(tmp_path, src):
+    """Round 5 finding (jenga_amd/build.py, profiles/r05_packed_fp32_under_gpu_sharing.json): kernels with compiler-packed fp32
+    arithmetic (v_pk_mul_f32 / v_pk_add_f32 from the SLP vectoriser) returned wrong values on MI355X whenever another process
+    kept the same GPU busy.  With the product flags no device source may contain a packed fp32 multiply / add / fma."""
+    from jenga_amd import build
+    flags = dict(build.SOURCES)[src]
+    out = tmp_path / (src + ".s")
+    cmd = [build._hipcc(), f"--offload-arch={build.ARCH}", "-O3", "-std=c++17", "-fPIC", "-x", "hip", "-S", "--cuda-device-only",
+           os.path.join(ROOT, "jenga_amd", "csrc", src), "-o", str(out)] + flags
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    assert r.returncode == 0, r.stdout.decode()[-2000:]
+    hits = re.findall(r"^\s*(v_pk_(?:mul|add|fma)_f32)\b", out.read_text(), re.M)
+    assert not hits, f"{src}: {len(hits)} packed fp32 instructions"
