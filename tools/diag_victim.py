@@ -83,6 +83,33 @@ def worker(rank, world, port, outdir):
             "jenga gather_rows": lambda: _capi.gather_rows(xx, torch.arange(511, -1, -1, device=dev)),
             "jenga linear gelu": lambda: _capi.linear(xx, w, None, act=_capi.ACT_GELU_TANH),
         })
+        # the rest of the C ABI's device kernels
+        oq, ok_ = torch.empty_like(q), torch.empty_like(k)
+        qpo = torch.zeros(1, H_, nb, 128, device=dev, dtype=torch.bfloat16); kpo = torch.zeros_like(qpo)
+        cosf = torch.randn(S_, 128, generator=g, device=dev); sinf = torch.randn(S_, 128, generator=g, device=dev)
+
+        def fused():
+            _capi.qk_norm_rope_pool(q, k, wq, wq, cosf, sinf, oq, ok_, qpool=qpo, kpool=kpo)
+            return torch.cat([oq.flatten(), ok_.flatten(), qpo.flatten(), kpo.flatten()])
+        xf = torch.randn(1, 512, 1536, generator=g, device=dev)
+        wf = torch.randn(1536, generator=g, device=dev); bf = torch.randn(1536, generator=g, device=dev)
+        yb = torch.randn(1, 512, 1536, generator=g, device=dev, dtype=torch.bfloat16)
+        c64 = torch.randn(S_, 64, generator=g, device=dev, dtype=torch.float64); s64 = torch.randn(S_, 64, generator=g, device=dev, dtype=torch.float64)
+        xw = torch.randn(1, S_, 12 * 128, generator=g, device=dev, dtype=torch.bfloat16)
+        ww = torch.randn(12 * 128, generator=g, device=dev)
+        ops.update({
+            "jenga qk_norm_rope_pool": fused,
+            "jenga gelu_tanh": lambda: _capi.gelu_tanh(xx),
+            "jenga wan_ln_modulate": lambda: _capi.wan_ln_modulate(xf, wf, bf, wf, bf),
+            "jenga wan_gate_residual": lambda: _capi.wan_gate_residual(xf, yb, wf),
+            "jenga rmsnorm_rows": lambda: _capi.rmsnorm_rows(xw, ww, 1e-6),
+            "jenga wan_norm_rope": lambda: _capi.wan_norm_rope(xw, ww, c64, s64, S_, 1e-6),
+            "jenga rope_complex": lambda: _capi.rope_complex(q, c64, s64, S_),
+            "jenga cross_attn": lambda: _capi.cross_attn_fwd(q[:, :512], k, v),
+            "jenga ulysses pack": lambda: _capi.ulysses_pack_heads(q, 4),
+            "jenga ulysses unpack": lambda: _capi.ulysses_unpack_heads(_capi.ulysses_pack_heads(q, 4), 4),
+            "jenga linear gate+res": lambda: _capi.linear(xx, w, sh_.float().reshape(-1), gate=sc_.reshape(-1), res=xx),
+        })
         first = {nm: f() for nm, f in ops.items()}
         torch.cuda.synchronize()
         bad = {nm: 0 for nm in ops}; runs = 0
