@@ -12,12 +12,13 @@ ARCH = "gfx950"
 # dtype": no fused multiply-adds (-ffp-contract=off) and no v_fma_mix*_f16 -- hipcc otherwise folds `half(float(a) * b)`
 # into one mixed-precision instruction that rounds the exact product ONCE, where torch rounds to fp32 first and to fp16
 # second (found in round 2: 1e-4 of the fp16 RMSNorm outputs differed by an ulp from the reference for that reason).
-# -fno-slp-vectorize (round 5): the compiler's SLP pass turns adjacent scalar fp32 operations into v_pk_mul_f32 / v_pk_add_f32
-# on register pairs it assembles with v_mov / v_lshlrev right before the packed instruction.  On the MI355X boxes of this pool
-# those kernels (ln_modulate, rmsnorm_rope, qk_norm_rope_pool) returned WRONG VALUES -- the low half of one pair, lanes 48..63
-# of a wave, up to 65 % of the calls -- whenever ANOTHER PROCESS kept the same GPU busy, and never otherwise; torch's own
-# kernels, the kernels without compiler-packed arithmetic and the explicit v_pk_fma_f32 of select.hip stayed clean over
-# 20 000+ calls each (tools/diag_victim.py, profiles/r05_packed_fp32_under_gpu_sharing.json).  Without the pass: 0 mismatches.
+# -fno-slp-vectorize (round 5).  On the MI355X boxes of this pool a packed fp32 VALU instruction whose LOW lane selects the HIGH
+# half of a source pair (v_pk_add_f32 / v_pk_mul_f32 ... op_sel:[0,1]) returns wrong low-lane results (lanes 48..63) while
+# ANOTHER wave on the GPU executes v_mfma_f32_16x16x32_bf16 -- another process or another stream; hipBLASLt's GEMMs are such a
+# load.  The SLP vectoriser emits exactly that form for `x - mean` (the mean broadcast from the high half of a pair): ln_modulate,
+# rmsnorm_rope and qk_norm_rope_pool were wrong in up to 99 % of their calls beside a GEMM and never alone, so no single-stream
+# test saw it.  Stand-alone reproducer: tools/micro/pk_beside_mfma.hip; record: profiles/r05_packed_fp32_under_gpu_sharing.json;
+# pinned by tests/test_isa_cpu.py (no packed fp32 in any device source) and tests/test_gpu_shared_device.py (behaviour).
 # -packed-fp32-ops on top: no v_pk_*_f32 at all from the sources that do not ask for them explicitly (the vector combiner
 # still produced 32 in rmsnorm_rows_kernel without it).  (hipcc repeats "not a recognized feature" for the HOST pass.)
 NO_SLP = ["-fno-slp-vectorize"]

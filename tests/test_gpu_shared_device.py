@@ -1,11 +1,12 @@
-"""GPU (-m gpu): every kernel of the library returns the same bits while ANOTHER PROCESS keeps the same GPU busy.
+"""GPU (-m gpu): every kernel of the library returns the same bits while ANOTHER PROCESS keeps the same GPU busy with GEMMs.
 
-Round 5 finding: with compiler-packed fp32 arithmetic (v_pk_mul_f32 / v_pk_add_f32, the SLP vectoriser's output) ln_modulate,
-rmsnorm_rope and qk_norm_rope_pool returned wrong values -- the low half of one register pair, lanes 48..63 of a wave, in up to
-65 % of the calls -- under exactly this condition and never otherwise; torch's own kernels and the kernels without packed
-arithmetic did not.  The library is built without packed fp32 since (jenga_amd/build.py; tests/test_isa_cpu.py pins it);
-this test is the behavioural side: a load process (torch GEMMs + elementwise, no library code) and a victim process that
-repeats each kernel on fixed inputs for a few seconds and counts results that differ from the first one.
+Round 5 finding: on these MI355X boxes a packed fp32 VALU instruction whose low lane reads the HIGH half of a source pair
+(v_pk_add_f32 / v_pk_mul_f32 op_sel:[0,1] -- the SLP vectoriser's rendering of `x - mean`) returns wrong values while another wave
+on the GPU executes v_mfma_f32_16x16x32_bf16 (hipBLASLt's GEMMs): ln_modulate, rmsnorm_rope and qk_norm_rope_pool were wrong in
+up to 99 % of their calls under exactly this condition and never otherwise (stand-alone reproducer: tools/micro/
+pk_beside_mfma.hip).  The library is built without packed fp32 since (jenga_amd/build.py; tests/test_isa_cpu.py pins it); this
+test is the behavioural side: a load process (torch GEMMs + elementwise, no library code) and a victim process that repeats
+each of the 26 device kernels on fixed inputs for a few seconds and counts results that differ from the first one.
 Record: profiles/r05_packed_fp32_under_gpu_sharing.json."""
 import json
 import os
