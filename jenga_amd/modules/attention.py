@@ -33,18 +33,32 @@ def my_parallel_attention(hybrid_seq_parallel_attn, q, k, v, img_q_len, img_kv_l
 
 def parallel_attention(hybrid_seq_parallel_attn, q, k, v, img_q_len, img_kv_len, cu_seqlens_q, cu_seqlens_kv):
     """attenion.py:198-251: the DENSE sequence-parallel attention (no AttenCarve: yunchang's LongContextAttention over
-    image + valid text, then a separate flash call among the padding tokens, sliced by cu_seqlens on the host).  Callers in
-    the reference: the non-Jenga blocks (hyvideo/modules/models.py:216, 381) and -- in their sequence-parallel branch
-    only -- the Jenga I2V blocks (hyvideo_i2v/modules/models_mul.py:265, 484), i.e. the reference has no Jenga-aware
-    sequence parallelism for I2V.  Not part of the AttenCarve path: the name
-    exists so that the entry scripts' imports resolve (jenga_hyvideo.py:19), and a call says what to use instead.  I2V
-    sequence parallelism WITH AttenCarve is jenga_amd.dit's own path (JengaHYVideoDiT with i2v_condition_type =
-    "token_replace" and UlyssesAttenCarve on the blocks; tests/test_gpu_sp_dit.py)."""
-    raise NotImplementedError(
-        "parallel_attention is the reference's dense (non-Jenga) sequence-parallel attention (attenion.py:198-251) and is "
-        "not implemented: the T2V Jenga blocks call my_parallel_attention; the reference's I2V blocks reach this function "
-        "only with sequence parallelism on, where they run WITHOUT AttenCarve -- use jenga_amd.dit.JengaHYVideoDiT "
-        "(i2v_condition_type='token_replace') with jenga_amd.modules.ulysses.UlyssesAttenCarve for I2V on several GPUs")
+    image + valid text, then a separate flash call among the text-padding tokens).  Callers in the reference: the non-Jenga
+    blocks (hyvideo/modules/models.py:216, 381) and -- in their sequence-parallel branch only -- the Jenga I2V blocks
+    (hyvideo_i2v/modules/models_mul.py:265, 484): the reference has no Jenga-aware sequence parallelism for I2V (SURVEY.md
+    section 2 #22).  Here: the exchange of my_parallel_attention around the DENSE kernel call of `attention` (every block
+    kept for every query block, image AND text rows masked at the valid length), i.e. the rank's heads attend over all
+    image tokens and the valid text tokens -- what LongContextAttention computes.  Requirements of that path: hybrid_seq_parallel_attn is a
+    jenga_amd.modules.ulysses.UlyssesAttenCarve, the image tokens of all ranks together are whole 128-token blocks, the text
+    length is a multiple of 128.  One stated deviation, the dense path's: the text-PADDING rows
+    (beyond cu_seqlens_q[1]) come back as zeros instead of attending among themselves (the reference's second flash call,
+    :222-247); no valid token reads them.  I2V sequence parallelism WITH AttenCarve is jenga_amd.dit's own path
+    (JengaHYVideoDiT, i2v_condition_type = "token_replace"; tests/test_gpu_sp_dit.py)."""
+    from . import ulysses
+    if not isinstance(hybrid_seq_parallel_attn, ulysses.UlyssesAttenCarve):
+        raise TypeError("parallel_attention: hybrid_seq_parallel_attn must be a jenga_amd.modules.ulysses.UlyssesAttenCarve "
+                        f"(got {type(hybrid_seq_parallel_attn).__name__}); yunchang's LongContextAttention is not available here")
+    if img_q_len != img_kv_len:
+        raise ValueError("parallel_attention: img_q_len and img_kv_len must agree (self-attention)")
+    n = hybrid_seq_parallel_attn.exchange().size()
+    if (img_q_len * n) % 128:
+        raise ValueError(f"parallel_attention: {n} ranks x {img_q_len} image tokens are not whole 128-token blocks")
+    attn = hybrid_seq_parallel_attn(
+        None, q[:, :img_q_len], k[:, :img_kv_len], v[:, :img_kv_len], dropout_p=0.0, causal=False,
+        joint_tensor_query=q[:, img_q_len:], joint_tensor_key=k[:, img_kv_len:], joint_tensor_value=v[:, img_kv_len:],
+        joint_strategy="rear", cu_seqlens_q=cu_seqlens_q, cu_seqlens_kv=cu_seqlens_kv, dense=True)
+    b, s, a, d = attn.shape
+    return attn.reshape(b, s, -1)
 
 
 _DENSE_LISTS = {}

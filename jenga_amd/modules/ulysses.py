@@ -151,6 +151,17 @@ def _hip_select(q_all, k_all, top_k, text_blocks, p, neighbors):
     return idx, cnt
 
 
+def _hip_attend_dense(q_all, k_all, v_all, seqlens):
+    """Every kv block kept for EVERY query block, the kv-length mask on for the text rows too: what LongContextAttention
+    computes over image + valid text (parallel_attention, attenion.py:198-221).  Same kernel, same lists as
+    jenga_amd.modules.attention.attention (the single-rank dense front-end)."""
+    from .attention import _dense_lists
+    B, S, Hn, D = q_all.shape
+    nb = S // 128
+    idx, cnt = _dense_lists(q_all.device, B, Hn, nb)
+    return _capi.bsattn_fwd(q_all, k_all, _capi.pack_v(v_all, nb), seqlens, idx, cnt, nb, D ** -0.5, 0.0, nb)
+
+
 def _hip_attend(q_all, k_all, v_all, idx, cnt, seqlens, text_blocks, text_amp):
     nb = q_all.shape[1] // 128
     vt = _capi.pack_v(v_all, nb)
@@ -332,7 +343,8 @@ class UlyssesAttenCarve(torch.nn.Module):
     def forward(self, attn, query, key, value, *, joint_tensor_query=None, joint_tensor_key=None,
                 joint_tensor_value=None, dropout_p=0.0, softmax_scale=None, causal=False, window_size=(-1, -1),
                 alibi_slopes=None, deterministic=False, return_attn_probs=False, joint_strategy="none", top_k=0,
-                text_amp=0.0, block_neighbor_list=None, p_remain_rates=0.0, cu_seqlens_q=None, cu_seqlens_kv=None):
+                text_amp=0.0, block_neighbor_list=None, p_remain_rates=0.0, cu_seqlens_q=None, cu_seqlens_kv=None,
+                dense=False):
         if joint_strategy != "rear" or joint_tensor_query is None or joint_tensor_key is None \
                 or joint_tensor_value is None:
             raise ValueError("jenga_amd Ulysses: only joint_strategy='rear' with text q/k/v (the Jenga call) is supported")
@@ -341,7 +353,7 @@ class UlyssesAttenCarve(torch.nn.Module):
         pend = self.begin(B, S_loc, H, S_txt, query.dtype, query.device, D)
         pend.post_packed(query, key, value, joint_tensor_query, joint_tensor_key, joint_tensor_value)
         return pend.finish(top_k=top_k, text_amp=text_amp, block_neighbor_list=block_neighbor_list,
-                           p_remain_rates=p_remain_rates, cu_seqlens_q=cu_seqlens_q)
+                           p_remain_rates=p_remain_rates, cu_seqlens_q=cu_seqlens_q, dense=dense)
 
     @torch.no_grad()
     def forward_qkv(self, img_qkv, txt_qkv, img_norm_w, txt_norm_w, freqs_cis, *, top_k=0, text_amp=0.0,
@@ -460,7 +472,7 @@ class PendingAttenCarve:
         self.w_v = self._post((2,))
 
     def finish(self, *, top_k=0, text_amp=0.0, block_neighbor_list=None, p_remain_rates=0.0, cu_seqlens_q=None,
-               out=None, while_out=None):
+               out=None, while_out=None, dense=False):
         if self.w_qk is None or self.w_v is None:
             raise RuntimeError("PendingAttenCarve.finish(): Q, K and V have not all been posted")
         sp, ex, N = self.sp, self.ex, self.N
@@ -472,9 +484,13 @@ class PendingAttenCarve:
         for g in range(self.G):
             q_all, k_all, v_all = self.fulls[g]
             _wait_all(self.w_qk[g])
-            idx, cnt = sp.select_fn(q_all, k_all, top_k, S_txt // 128, p_remain_rates, block_neighbor_list)
-            _wait_all(self.w_v[g])                                 # the V transfer overlapped pooling + selection
-            o = sp.attend_fn(q_all, k_all, v_all, idx, cnt, seqlens, S_txt // 128, text_amp)
+            if dense:       # parallel_attention: no selection, every row masked at the valid length
+                _wait_all(self.w_v[g])
+                o = _hip_attend_dense(q_all, k_all, v_all, seqlens)
+            else:
+                idx, cnt = sp.select_fn(q_all, k_all, top_k, S_txt // 128, p_remain_rates, block_neighbor_list)
+                _wait_all(self.w_v[g])                             # the V transfer overlapped pooling + selection
+                o = sp.attend_fn(q_all, k_all, v_all, idx, cnt, seqlens, S_txt // 128, text_amp)
             # ---- exchange out: image rows (already peer-major: chunk p = rank p's tokens) back to sequence shards;
             #      text rows gathered over heads (the reference repeats them N times and all-to-alls, :206-217).
             #      Pipelined: head g's O exchange is in flight while head g + 1 is attended

@@ -114,3 +114,64 @@ def test_simulated_ranks_forward_equals_single_rank_op(dev, N):
         err = np.abs(results[r].float().cpu().numpy() - sim[r])
         # (a borderline block may be selected differently by the numpy restatement of the pooling: allow a few rows)
         assert err.mean() <= 2e-3 and (err.max(-1) > 3e-2).mean() <= 0.02, (r, err.max(), err.mean())
+
+
+@pytest.mark.parametrize("N", [2, 4])
+def test_parallel_attention_is_the_dense_sequence_parallel_attention(dev, N):
+    """attenion.py:198-251 (the reference's dense, non-Jenga sequence-parallel attention; its I2V blocks call it in their
+    sequence-parallel branch): N simulated ranks against (a) the single-rank dense front-end `attention` on the valid rows --
+    the same kernel with every block kept, so the image and valid-text rows must agree to the last bit where the row's
+    block list is the same, and within the attention tolerance everywhere -- and (b) the oracle's dense restatement."""
+    from jenga_amd.modules import ulysses
+    from jenga_amd.modules.attention import attention, parallel_attention
+    from oracle import attention as oa
+    gen = torch.Generator().manual_seed(77 + N)
+    H, nimg, tb = 8, 8, 2
+    S_img, S_txt = nimg * 128, tb * 128
+    S = S_img + S_txt
+    q = torch.randn(1, S, H, 128, generator=gen).to(torch.bfloat16)
+    k = torch.randn(1, S, H, 128, generator=gen).to(torch.bfloat16)
+    v = torch.randn(1, S, H, 128, generator=gen).to(torch.bfloat16)
+    S_loc, n_valid = S_img // N, 70
+    qd, kd, vd = q.to(dev), k.to(dev), v.to(dev)
+    world = SimWorld(N)
+    results, errors = [None] * N, []
+
+    def run(rank):
+        try:
+            torch.cuda.set_device(dev)
+            sl = slice(rank * S_loc, (rank + 1) * S_loc)
+            loc = lambda t: torch.cat([t[:, sl], t[:, S_img:]], dim=1)
+            cu = torch.tensor([0, S_loc + n_valid, S_loc + S_txt], dtype=torch.int32, device=dev)
+            sp = ulysses.UlyssesAttenCarve(exchange=SimExchange(world, rank))
+            out = parallel_attention(sp, loc(qd), loc(kd), loc(vd), img_q_len=S_loc, img_kv_len=S_loc, cu_seqlens_q=cu,
+                                     cu_seqlens_kv=cu)
+            results[rank] = out.reshape(1, S_loc + S_txt, H, 128)
+        except Exception as e:                                 # noqa: BLE001 - surfaced below
+            errors.append((rank, repr(e)))
+            world.barrier.abort()
+
+    threads = [threading.Thread(target=run, args=(r,)) for r in range(N)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=120)
+    assert not errors, errors
+    torch.cuda.synchronize()
+    cu1 = torch.tensor([0, S_img + n_valid, S], dtype=torch.int32, device=dev)
+    single = attention(qd, kd, vd, cu_seqlens_q=cu1, cu_seqlens_kv=cu1).reshape(1, S, H, 128)
+    ref = oa.dense_varlen(to_np(q).transpose(0, 2, 1, 3), to_np(k).transpose(0, 2, 1, 3), to_np(v).transpose(0, 2, 1, 3),
+                          cu1.cpu().numpy(), 128 ** -0.5, "bfloat16").transpose(0, 2, 1, 3)
+    for r in range(N):
+        got_img = results[r][:, :S_loc]
+        got_txt = results[r][:, S_loc:S_loc + n_valid]
+        want_img = single[:, r * S_loc:(r + 1) * S_loc]
+        want_txt = single[:, S_img:S_img + n_valid]
+        for got, want, rf in ((got_img, want_img, ref[:, r * S_loc:(r + 1) * S_loc]), (got_txt, want_txt, ref[:, S_img:S_img + n_valid])):
+            e1 = (got.float() - want.float()).abs().max().item()
+            e2 = np.abs(got.float().cpu().numpy() - rf)
+            e3 = np.abs(want.float().cpu().numpy() - rf)
+            assert e1 <= 1.6e-2, (r, "got-single", e1, "got-oracle", e2.max(), "single-oracle", e3.max())
+            assert e2.max() <= 2e-2 and e2.mean() <= 1e-3, (r, e2.max(), e2.mean())
+    with pytest.raises(TypeError):
+        parallel_attention(object(), qd, kd, vd, S_img, S_img, cu1, cu1)
