@@ -38,3 +38,18 @@ def test_kernels_are_bit_stable_under_load_from_another_process():
         json.dump({"load": load, "victim": victim}, open(os.path.join(out, "shared_device_bit_stability.json"), "w"), indent=1)
     except OSError:
         pass
+
+
+def test_ln_modulate_is_bit_stable_beside_a_gemm_on_another_stream():
+    """The same condition inside ONE process: hipBLASLt GEMMs (16x16x32 MFMAs, the trigger) on a second stream while the
+    LayerNorm + modulate kernel repeats on the first (tools/diag_streams.py; with the SLP build: 41 315 of 59 476 calls wrong)."""
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    env = dict(os.environ, DIAG_LOAD="mfma", DIAG_SECS="4")
+    env.pop("JENGA_LIB", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "diag_streams.py")], env=env, stdout=subprocess.PIPE,
+                       stderr=subprocess.STDOUT, timeout=300)
+    lines = [ln for ln in r.stdout.decode().splitlines() if ln.startswith("{")]
+    assert r.returncode == 0 and len(lines) == 1, r.stdout.decode()[-3000:]
+    rec = json.loads(lines[0])
+    assert rec["runs"] >= 1000 and rec["load_iterations"] >= 100, rec
+    assert rec["ln_modulate_mismatches"] == 0, rec
