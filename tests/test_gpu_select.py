@@ -82,6 +82,7 @@ def _compare_with_oracle_from_pooled(dev, q, k, nimg, tb, top_k, p, nbm, ffb, sa
     nb_np = None if nbm is None else nbm.cpu().numpy()[rows]
     # the oracle works on whole rows of the neighbour matrix / first-frame rule: evaluate row by row
     ham_tot, size_tot, n_diff = 0, 0, 0
+    seq_order_explained = []
     idx_c, cnt_c = idx.cpu().numpy(), cnt.cpu().numpy()
     for i, m in enumerate(rows):
         neigh = None if nb_np is None else nb_np[i:i + 1]
@@ -92,11 +93,34 @@ def _compare_with_oracle_from_pooled(dev, q, k, nimg, tb, top_k, p, nbm, ffb, sa
             got = np.zeros(nb, bool)
             got[idx_c[0, h, m, :cnt_c[0, h, m]]] = True
             d = int((got != ref[0, h, 0]).sum())
+            if d:
+                # the oracle's scores come from an einsum whose summation order is numpy's; the kernel's contract is 128
+                # SEQUENTIAL fused multiply-adds per (row, column).  A score on a bf16 rounding boundary can differ between
+                # the two orders: re-derive this row with the kernel's order (fma emulated in float64: exact product, one
+                # rounding of the sum) and compare again -- only a difference that survives is the kernel's
+                acc = np.zeros(nimg, np.float32)
+                for c in range(128):
+                    acc = (acc.astype(np.float64) + np.float64(qp[0, h, i, c]) * kp[0, h, :nimg, c].astype(np.float64)).astype(np.float32)
+                from oracle.rounding import rounder
+                rnd = rounder("bfloat16")
+                sc = rnd(rnd(acc) * np.float32(128 ** -0.5))[None, None, None]
+                order, n_ = oa.blocks_needed(oa.row_probs(sc, "bfloat16"), top_k, p, "bfloat16")
+                ref2 = ref[0, h, 0].copy()
+                ref2[:nimg] = False
+                ref2[order[0, 0, 0, :int(n_[0, 0, 0])]] = True
+                if neigh is not None:
+                    ref2[:nimg] |= np.asarray(neigh[0, :nimg], bool)
+                if ffb and m < ffb:
+                    ref2[:ffb] = True
+                d2 = int((got != ref2).sum())
+                seq_order_explained.append((tag, m, h, d, d2))
+                d = d2
             ham_tot += d
             n_diff += d > 0
             size_tot += nb
     _record("select_full_size.json", {tag: dict(hamming=ham_tot, of=size_tot, rows_differing=int(n_diff),
-                                                rows=len(rows) * H)})
+                                                rows=len(rows) * H,
+                                                rows_settled_by_the_kernels_dot_order=[list(x) for x in seq_order_explained])})
     # given identical pooled inputs the selection logic must reproduce the oracle's lists: every recorded run
     # (profiles/r02_ / r03_parity_select_full_size.json) has Hamming distance 0 on every shape
     assert ham_tot == 0, (ham_tot, size_tot)
@@ -119,6 +143,23 @@ def test_hunyuan_720p_lists_vs_oracle_from_hip_pooled(dev):
     for top_k, p, tag in ((int(0.3 * nimg), 0.3, "hy720p_r0.7_p0.3"), (int((1 - 0.8) * nimg), 0.3, "hy720p_r0.8_p0.3"),
                           (10, 0.9, "hy720p_topk10_p0.9")):
         _compare_with_oracle_from_pooled(dev, q, k, nimg, tb, top_k, p, nbm, 0, rows, tag)
+
+
+@pytest.mark.parametrize("nimg,tb", [(1500, 2), (2048, 4), (1025, 0)])
+def test_rows_beyond_1024_blocks_vs_oracle_from_hip_pooled(dev, nimg, tb):
+    """More than 1024 image key blocks: 32 keys per lane in the wave-level sort, and (2048) more dynamic LDS than a launch gets
+    without the attribute -- the default (CPU-cumsum) contract against the oracle, no neighbour list."""
+    nb, H = nimg + tb, 2
+    g = torch.Generator(device=dev).manual_seed(9 + nimg)
+    cent = torch.randn(1, nb, 1, H, 128, generator=g, device=dev) * 0.7
+    pick = torch.randint(0, nimg, (nb,), device=dev, generator=g)
+    q = (torch.randn(1, nb, 16, H, 128, generator=g, device=dev) + cent[:, pick]).repeat_interleave(8, dim=2)
+    k = (torch.randn(1, nb, 16, H, 128, generator=g, device=dev) + cent).repeat_interleave(8, dim=2)
+    q = q.to(torch.bfloat16).reshape(1, nb * 128, H, 128)
+    k = k.to(torch.bfloat16).reshape(1, nb * 128, H, 128)
+    rows = list(range(0, nimg, 97)) + [nimg - 1]
+    for top_k, p in ((int(0.2 * nimg), 0.3), (7, 0.9)):
+        _compare_with_oracle_from_pooled(dev, q, k, nimg, tb, top_k, p, None, 0, rows, f"big_{nimg}_{tb}_topk{top_k}_p{p}")
 
 
 def test_wan14b_720p_full_shape_properties(dev):
