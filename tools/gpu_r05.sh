@@ -34,6 +34,10 @@ H)  # the driver's command at HEAD (default flags), then the same command under 
   timeout 1200 bash tools/prof_bench.sh r05_default > $O/prof.log 2>&1; head -12 gpurun_out/prof_r05_default/kernel_stats.csv | cut -c1-150
   timeout 2400 python -m pytest tests -x -q -m gpu > $O/pytest_gpu.log 2>&1; tail -3 $O/pytest_gpu.log
   ;;
+K)  # the command the way the driver runs it (--steps 20 --warmup 5), plain and under rocprofv3 without the extra legs
+  timeout 900 python bench.py --steps 20 --warmup 5 > $O/bench_steps20.json 2> $O/bench_steps20.err; python tools/ab_print.py $O/bench_steps20.json
+  timeout 1200 bash tools/prof_bench.sh r05_steps20 --steps 20 --warmup 5 --no-dense-ref --no-other-kernel-ref --no-wan-extra --no-cpu-baseline > $O/prof.log 2>&1; head -8 gpurun_out/prof_r05_steps20/kernel_stats.csv | cut -c1-150; python tools/ab_print.py gpurun_out/prof_r05_steps20/bench.json | head -2
+  ;;
 G)  # counter passes of the default kernel at both drop rates of the Base preset, one box (roofline.traffic_per_rate)
   for R in 0.7 0.8; do
     timeout 900 bash tools/pmc_attn2.sh r05_lp_flat_$R --drop $R --iters 2 --attn-only --flags 29 > $O/pmc_flat_$R.log 2>&1; grep -E "per_kept_pair|l2_hit|mfma_busy|effective_clock" $O/pmc_flat_$R.log
