@@ -158,8 +158,8 @@ block_select_kernel(const uint16_t* __restrict__ qpool, const uint16_t* __restri
     // with 8 consecutive lanes on one line (a thread reading its own 256-byte row touched 64 lines per load instruction and
     // the texture path, not the FMAs, set the pace: 0.225 of 0.37 ms), the 16-byte chunk c of row r stored at slot
     // c ^ ((r >> 1) & 7) so that both the stores (8 lanes per row) and the loads (one row per lane) are conflict-free.  The
-    // next tile's global loads are in flight while this one is consumed.  The scores stay in registers until the last tile is
-    // done; then the tile buffer becomes the row buffer.
+    // global loads of the next TWO passes are in flight while this one is consumed (one pass ahead left 0.05 ms exposed).  The
+    // scores stay in registers until the last tile is done; then the tile buffer becomes the row buffer.
     {
         uint4* tile = reinterpret_cast<uint4*>(smem);          // [256 rows][8 slots]
         // rows past the end of the head repeat the last one (read, never used)
