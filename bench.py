@@ -626,10 +626,14 @@ def main():
     # warm-up, sequence-parallel modules, choice broadcast, max-over-ranks reductions) -- the smoke test of the N > 1 launch
     # on a one-GPU box; the numbers of such a run are a single-GPU measurement with the sequence-parallel call structure
     dist_on = world > 1 or os.environ.get("JENGA_BENCH_FORCE_DIST", "0") == "1"
+    stdout_guard = None
     if dist_on:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if "MASTER_ADDR" not in os.environ:
             os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+        # RCCL prints a five-line version banner to STDOUT (C stdio) when its communicator comes up: until the communicator
+        # exists and libc's buffers are flushed, file descriptor 1 points at stderr, so that stdout carries the JSON line only
+        stdout_guard = _StdoutToStderr()
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     sim = a.simulate_ranks if not dist_on else 0
     if sim > 1:
@@ -730,6 +734,8 @@ def main():
             w__.wait()
         dist.all_reduce(w_)
         torch.cuda.synchronize()
+    if stdout_guard is not None:
+        stdout_guard.restore()
     sim_ex = _LocalExchange(sim, a.sim_exchange_gbps, a.sim_exchange_latency_us) if sim > 1 else None
     if dist_on or sim > 1:
         ulysses.init_sequence_parallel()
@@ -1275,10 +1281,51 @@ def main():
                       f"({cb['best']} leg A) x {layers} layers x {len(computed_steps)} computed steps, attention + "
                       "selection only (GEMMs, norms and RoPE excluded)",
             "detail": cb["detail"]}
-    if rank == 0:
-        print(json.dumps(res))
+    # The JSON line has to be the LAST thing on stdout.  RCCL writes its five-line version banner ("RCCL version : ...") to
+    # stdout through C stdio when the communicator is created; with stdout a pipe or a file it sits in libc's buffer until the
+    # process exits -- i.e. it used to land AFTER the line below in every run that initialises RCCL (seen in
+    # JENGA_BENCH_FORCE_DIST=1 runs; an N > 1 run would have done the same to the driver's parser).  So: tear the process group
+    # down first, flush libc's buffers, then print.
+    _flush_c_stdio()                # every rank's banner goes out now ...
     if dist_on or sim > 1:
-        dist.destroy_process_group()
+        try:
+            if dist_on:
+                dist.barrier()      # ... and every rank has done so before rank 0 prints
+            dist.destroy_process_group()
+        except Exception as e:      # noqa: BLE001 - the measurement is complete; say so and still print it
+            print(f"bench.py: rank {rank}: destroy_process_group failed ({e!r})", file=sys.stderr)
+    _flush_c_stdio()
+    if rank == 0:
+        sys.stdout.write(json.dumps(res) + "\n")
+        sys.stdout.flush()
+
+
+class _StdoutToStderr:
+    """File descriptor 1 -> stderr until restore(); libc's and Python's buffers are flushed on both edges."""
+
+    def __init__(self):
+        sys.stdout.flush()
+        _flush_c_stdio()
+        self.saved = os.dup(1)
+        os.dup2(2, 1)
+
+    def restore(self):
+        if self.saved is None:
+            return
+        sys.stdout.flush()
+        _flush_c_stdio()
+        os.dup2(self.saved, 1)
+        os.close(self.saved)
+        self.saved = None
+
+
+def _flush_c_stdio():
+    """fflush(NULL): whatever native libraries left in libc's stdio buffers goes out now (see the end of main)."""
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:               # noqa: BLE001
+        pass
 
 
 if __name__ == "__main__":

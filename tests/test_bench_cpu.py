@@ -62,3 +62,31 @@ def test_bench_line_helpers_and_keys():
     # Wan2.1-14B forward: 40 layers x (6 dim^2 + 2 dim*ffn) x 2L flops
     w = bench.wan_gemm_flops_per_forward(75600, 5120, 13824, 40)
     assert 1.7e15 < w < 2.0e15, w
+
+
+def test_stdout_carries_the_json_line_only_when_rccl_is_up():
+    """RCCL writes a version banner to stdout through C stdio when its communicator is created; in a run that initialises it
+    (N > 1, or JENGA_BENCH_FORCE_DIST=1) the banner used to land AFTER the JSON line.  bench.py points fd 1 at stderr while the
+    communicator comes up, tears the process group down and flushes libc's buffers before it prints."""
+    import bench
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    i_guard, i_init = src.index("stdout_guard = _StdoutToStderr()"), src.index('dist.init_process_group("nccl"')
+    i_restore = src.index("stdout_guard.restore()")
+    assert i_guard < i_init < i_restore
+    tail = src[src.index("# The JSON line has to be the LAST thing on stdout."):]
+    assert tail.index("dist.destroy_process_group()") < tail.index("sys.stdout.write(json.dumps(res)")
+    # the guard really moves fd 1 and puts it back
+    r, w = os.pipe()
+    saved1 = os.dup(1)
+    os.dup2(w, 1)
+    try:
+        g = bench._StdoutToStderr()
+        os.write(1, b"to-stderr")           # lands on fd 2, not in the pipe
+        g.restore()
+        os.write(1, b"json")
+    finally:
+        os.dup2(saved1, 1)
+        os.close(saved1)
+        os.close(w)
+    assert os.read(r, 100) == b"json"
+    os.close(r)
