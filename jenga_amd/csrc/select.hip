@@ -17,6 +17,7 @@
 //   round 5c  K through LDS tiles, coalesced, one tile ahead                                       0.33 / 0.33
 //   round 5d  two tiles ahead (111 VGPRs = the 4 waves per SIMD the 32 KB tile allows anyway)      0.28 / 0.29
 //   round 5e  scalar fmas instead of v_pk_fma_f32 (see build.py), no SLP vectorisation            0.28 / 0.28
+//             (passes of loads in flight, same box: 1 -> 0.291 / 0.295, 2 -> 0.281 / 0.282, 3 -> 0.312 / 0.318: 143 VGPRs)
 //   (8 rows per workgroup, two per wave: 0.40 -- 132 VGPRs, 3 waves per SIMD.)
 // What is left in 5d (elimination builds): global loads still exposed ~0.10, FMAs + staging ~0.06, sort ~0.04,
 // output ~0.03, launch + softmax + bit set the rest.
@@ -170,7 +171,10 @@ block_select_kernel(const uint16_t* __restrict__ qpool, const uint16_t* __restri
         const uint4* kbase = reinterpret_cast<const uint4*>(kpool + bh * nk_all * 128);     // 16 chunks per row
         const int ntile = (nk_img + 255) >> 8;
         const int lr = tid >> 3, lc = tid & 7;
-        uint4 pre[2][8];                // pass t lives in pre[t & 1]: two passes of global loads in flight
+#ifndef SEL_AHEAD
+#define SEL_AHEAD 2
+#endif
+        uint4 pre[SEL_AHEAD][8];        // pass t lives in pre[t % SEL_AHEAD]: that many passes of global loads in flight
         auto gload = [&](uint4 (&dst)[8], int t) {       // pass t = (column tile t >> 1, channel half t & 1)
             const int r0 = (t >> 1) * 256 + lr;
 #pragma unroll
@@ -180,8 +184,9 @@ block_select_kernel(const uint16_t* __restrict__ qpool, const uint16_t* __restri
             }
         };
         float scv[MAX_PER_THREAD][SEL_R];
-        gload(pre[0], 0);
-        gload(pre[1], 1);        // (ntile >= 1: both halves of the first tile exist)
+#pragma unroll
+        for (int t = 0; t < SEL_AHEAD; ++t)
+            if (t < 2 * ntile) gload(pre[t], t);
 #pragma unroll
         for (int ct = 0; ct < MAX_PER_THREAD; ++ct) {
             if (ct * 256 < NP && ct < ntile) {
@@ -193,10 +198,10 @@ block_select_kernel(const uint16_t* __restrict__ qpool, const uint16_t* __restri
 #pragma unroll
                     for (int s_ = 0; s_ < 8; ++s_) {
                         const int r = s_ * 32 + lr;
-                        tile[r * 8 + (lc ^ ((r >> 1) & 7))] = pre[half][s_];
+                        tile[r * 8 + (lc ^ ((r >> 1) & 7))] = pre[(ct * 2 + half) % SEL_AHEAD][s_];
                     }
                     __syncthreads();
-                    if (ct * 2 + half + 2 < 2 * ntile) gload(pre[half], ct * 2 + half + 2);
+                    if (ct * 2 + half + SEL_AHEAD < 2 * ntile) gload(pre[(ct * 2 + half) % SEL_AHEAD], ct * 2 + half + SEL_AHEAD);
 #pragma unroll
                     for (int c = 0; c < 8; ++c) {
                         float f[8];
