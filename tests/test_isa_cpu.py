@@ -128,5 +128,11 @@ def test_no_packed_fp32_arithmetic_in_the_device_code(tmp_path, src):
            os.path.join(ROOT, "jenga_amd", "csrc", src), "-o", str(out)] + flags
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
     assert r.returncode == 0, r.stdout.decode()[-2000:]
-    hits = re.findall(r"^\s*(v_pk_(?:mul|add|fma)_f32)\b", out.read_text(), re.M)
+    text = out.read_text()
+    hits = re.findall(r"^\s*(v_pk_(?:mul|add|fma)_f32)\b", text, re.M)
     assert not hits, f"{src}: {len(hits)} packed fp32 instructions"
+    # stricter, and true today: no packed VALU arithmetic of any type and no operand-half selection at all (whether the 16-bit
+    # packed forms share the problem is not known; v_cvt_pk_* conversions are not packed arithmetic)
+    other = re.findall(r"^\s*(v_pk_\w+)", text, re.M)
+    assert not other, f"{src}: packed VALU instructions {sorted(set(other))}"
+    assert "op_sel" not in text, f"{src}: an instruction with op_sel"
