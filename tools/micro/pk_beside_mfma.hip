@@ -93,6 +93,20 @@ __global__ void __launch_bounds__(256) victim(const uint32_t* __restrict__ in, f
                 asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1]" : "=v"(d) : "v"(v), "v"(m));
                 acc = acc + d;
             }
+            // 11: v_pk_fma_f32 with the same selection on its second source;  12 / 13: the 16-bit packed add / mul with it
+            if (FORM == 11) {
+                const f2 m = acc * (f2){0.5f, 0.25f} + (f2){1.f, 1.f};
+                f2 d;
+                asm volatile("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,0]" : "=v"(d) : "v"(v), "v"(m), "v"(acc));
+                acc = acc * (f2){0.5f, 0.5f} + d * (f2){0.25f, 0.25f};
+            }
+            if (FORM == 12 || FORM == 13) {
+                uint32_t d;
+                const uint32_t m = w[(k + 1) & 3];
+                if (FORM == 12) asm volatile("v_pk_add_f16 %0, %1, %2 op_sel:[0,1]" : "=v"(d) : "v"(w[k] & 0x3bff3bffu), "v"(m & 0x3bff3bffu));
+                else asm volatile("v_pk_mul_f16 %0, %1, %2 op_sel:[0,1]" : "=v"(d) : "v"(w[k] & 0x3bff3bffu), "v"(m & 0x3bff3bffu));
+                acc = acc + (f2){(float)(d & 0xffffu), (float)(d >> 16)};
+            }
             // 8: the mirror image: (v.lo - m.lo, v.hi - m.lo)
             if (FORM == 8) {
                 const f2 m = acc * (f2){0.5f, 0.25f};
@@ -117,12 +131,13 @@ int main(int argc, char** argv) {
     hipStream_t sv, sl;
     CHECK(hipStreamCreate(&sv)); CHECK(hipStreamCreate(&sl));
     std::vector<float> first(n), cur(n);
-    const char* names[11] = {"packed mul+add (SLP form)", "scalar", "packed fma", "packed mul", "packed add",
+    const char* names[14] = {"packed mul+add (SLP form)", "scalar", "packed fma", "packed mul", "packed add",
                             "packed sub of a broadcast HIGH half (op_sel:[0,1])", "packed sub of a broadcast LOW half (op_sel_hi:[1,0])",
                             "asm v_pk_add_f32 op_sel:[0,1] neg (x - mean, the LayerNorm instruction)", "asm v_pk_add_f32 op_sel_hi:[1,0] neg",
-                            "asm v_pk_add_f32 op_sel:[0,1] (no neg)", "asm v_pk_mul_f32 op_sel:[0,1]"};
+                            "asm v_pk_add_f32 op_sel:[0,1] (no neg)", "asm v_pk_mul_f32 op_sel:[0,1]",
+                            "asm v_pk_fma_f32 op_sel:[0,1,0]", "asm v_pk_add_f16 op_sel:[0,1]", "asm v_pk_mul_f16 op_sel:[0,1]"};
     for (int with_load = 2; with_load >= 0; --with_load) {      // 2: 16x16x32 MFMAs beside it, 1: 32x32x16, 0: nothing
-        for (int form = 0; form < 11; ++form) {
+        for (int form = 0; form < 14; ++form) {
             int bad = 0;
             for (int l = 0; l < launches; ++l) {
                 if (with_load == 2 && (l % 4) == 0) hipLaunchKernelGGL(mfma_load<1>, dim3(2048), dim3(256), 0, sl, dsink, 4000);
@@ -138,7 +153,10 @@ int main(int argc, char** argv) {
                     case 7: hipLaunchKernelGGL(victim<7>, dim3(n / 256), dim3(256), 0, sv, din, dout, n); break;
                     case 8: hipLaunchKernelGGL(victim<8>, dim3(n / 256), dim3(256), 0, sv, din, dout, n); break;
                     case 9: hipLaunchKernelGGL(victim<9>, dim3(n / 256), dim3(256), 0, sv, din, dout, n); break;
-                    default: hipLaunchKernelGGL(victim<10>, dim3(n / 256), dim3(256), 0, sv, din, dout, n); break;
+                    case 10: hipLaunchKernelGGL(victim<10>, dim3(n / 256), dim3(256), 0, sv, din, dout, n); break;
+                    case 11: hipLaunchKernelGGL(victim<11>, dim3(n / 256), dim3(256), 0, sv, din, dout, n); break;
+                    case 12: hipLaunchKernelGGL(victim<12>, dim3(n / 256), dim3(256), 0, sv, din, dout, n); break;
+                    default: hipLaunchKernelGGL(victim<13>, dim3(n / 256), dim3(256), 0, sv, din, dout, n); break;
                 }
                 if (l == 0 || (l % 16) == 15) {          // check every 16th launch (and the first)
                     CHECK(hipMemcpyAsync(cur.data(), dout, n * 4, hipMemcpyDeviceToHost, sv));
