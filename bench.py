@@ -307,7 +307,7 @@ def secondary_roofline(dev, S_img=115200, S_txt=256, H=24, C=3072, mlp=12288, to
     hbm("pack_v", ms, 2 * q.numel() * 2, "read + write V [1,S,24,128] bf16")
     ms = _timed(lambda: _capi.block_select(qp, kp, nbm, nimg, nb - nimg, top_k, p_remain))
     lists = H * nimg * nb * 4 + H * nimg * 4
-    out["block_select"] = {"bound": "latency (one workgroup per 4 query blocks of a head: 4 x 900 sequential-fma dot products from "
+    out["block_select"] = {"bound": "VALU issue (>= 84 % busy, profiles/r05_pmc_select.json; one workgroup per 4 query blocks of a head: 4 x 900 sequential-fma dot products from "
                                     "LDS-staged pooled K, then one wave per row: softmax, bitonic sort in registers, exact "
                                     "shuffle-scan cumulative sum, compaction; DESIGN.md 3.5)", "ms": round(ms, 4),
                            "bytes": int(lists + (qp.numel() + kp.numel()) * 2),

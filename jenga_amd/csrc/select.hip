@@ -19,8 +19,8 @@
 //   round 5e  scalar fmas instead of v_pk_fma_f32 (see build.py), no SLP vectorisation            0.28 / 0.28
 //             (passes of loads in flight, same box: 1 -> 0.291 / 0.295, 2 -> 0.281 / 0.282, 3 -> 0.312 / 0.318: 143 VGPRs)
 //   (8 rows per workgroup, two per wave: 0.40 -- 132 VGPRs, 3 waves per SIMD.)
-// What is left in 5d (elimination builds): global loads still exposed ~0.10, FMAs + staging ~0.06, sort ~0.04,
-// output ~0.03, launch + softmax + bit set the rest.
+// What is left (counter passes, profiles/r05_pmc_select.json): 6.2 k VALU instructions per row-wave -- ~2.6 k dot products,
+// ~1.9 k sort, ~0.5 k softmax -- keep the VALU >= 84 % busy: the kernel is instruction-bound now.
 // The per-row work:
 //   scores -> softmax (dtype) -> sort -> cumulative-probability / top-k rule -> bit set
 //   -> OR static neighbours / first-frame / text columns -> ascending index list (+ optional one-hot mask).
