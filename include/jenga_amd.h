@@ -12,8 +12,11 @@
  *   - strides are in ELEMENTS; the innermost (head_dim) stride is always 1.
  *   - dtype: JENGA_BF16 or JENGA_FP16 (the reference kernel accepts both, ...diffres.py:167-170).
  *   - return value: JENGA_OK or an error code; jenga_last_error() gives the message for this thread.
- *   - head_dim must be 128, block size 128 (the only configuration the reference runs: HunyuanVideo,
- *     HunyuanVideo-I2V, Wan2.1 all use D=128 and BLOCK_M=BLOCK_N=128).
+ *   - the kernels work on 128-channel rows and 128-token blocks (the only configuration the reference runs: HunyuanVideo,
+ *     HunyuanVideo-I2V, Wan2.1 all use D=128 and BLOCK_M=BLOCK_N=128).  The Triton kernel's other accepted head dims
+ *     (16 / 32 / 64, ...diffres.py:155) are served by the host side on the same entry points: rows zero-padded to 128
+ *     channels, the true head_dim ** -0.5 passed as sm_scale (jenga_bsattn_fwd) and as JENGA_SELECT_HEAD_DIM(d)
+ *     (jenga_block_select) -- exact zeros in every dot product (jenga_amd/modules/attention_block_sparse.py).
  *   - state the library keeps (everything else is a pure function of its arguments):
  *       a thread-local error string (jenga_last_error);
  *       per device, for launches with JENGA_ATTN_BALANCE: 64 sets of 8 ticket counters in device memory, an event per

@@ -715,6 +715,10 @@ def bsattn_fwd(q, k, vt, seqlens, idx, cnt, nq_img, sm_scale, text_amp, text_blo
     if not xcd_remap:
         fl &= ~ATTN_XCD_REMAP
     pair = bool(fl & ATTN_PAIR)
+    if pair and order is not None:
+        # `order` ranks query BLOCKS; the pair kernel launches block PAIRS in an order of its own (ATTN_SORTED) -- dropping a
+        # caller's hint silently would misreport what ran
+        raise ValueError("bsattn_fwd: a launch-order hint (order=) cannot be combined with the pair kernel (ATTN_PAIR)")
     prof = ATTN_PROFILE
     with _on(q.device):
         pidx = pcnt = order_t = None

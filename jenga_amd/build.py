@@ -54,10 +54,17 @@ def _deps():
         os.path.join(HERE, "..", "include", "jenga_amd.h"), os.path.abspath(__file__)]   # (the flags live here)
 
 
+def _extra_flags():
+    return os.environ.get("JENGA_HIPCC_FLAGS", "").split()
+
+
 def source_digest():
-    """sha256 over every file the library is built from (csrc/, the header, this file: the flags live here)."""
+    """sha256 over everything the library is built from: csrc/, the header, this file (the flags live here) AND the
+    effective JENGA_HIPCC_FLAGS -- an elimination build (-DLQ_X_NODMA=1 ...: wrong results by design) must never pass for
+    the product library on a later run."""
     import hashlib
     h = hashlib.sha256()
+    h.update(("flags:" + " ".join(_extra_flags())).encode())
     for d in _deps():
         h.update(os.path.relpath(d, HERE).encode())
         with open(d, "rb") as f:
@@ -65,15 +72,21 @@ def source_digest():
     return h.hexdigest()
 
 
-STAMP = LIB + ".src.sha256"       # written next to the library (git-ignored like it, ships to the GPU box with it)
+def stamp_path(lib=LIB):
+    """written next to the library it describes (git-ignored like it, ships to the GPU box with it)"""
+    return lib + ".src.sha256"
+
+
+STAMP = stamp_path()
 
 
 def needs_build(lib=LIB):
-    """True unless `lib` exists and was built from exactly the sources in the tree (content hash, not mtimes: a snapshot
-    copied to another machine keeps its prebuilt library only if it really matches)."""
-    if not os.path.exists(lib) or not os.path.exists(STAMP):
+    """True unless `lib` exists and was built from exactly the sources in the tree with exactly the current extra flags
+    (content hash, not mtimes: a snapshot copied to another machine keeps its prebuilt library only if it really matches)."""
+    stamp = stamp_path(lib)
+    if not os.path.exists(lib) or not os.path.exists(stamp):
         return True
-    with open(STAMP) as f:
+    with open(stamp) as f:
         return f.read().strip() != source_digest()
 
 
@@ -89,7 +102,7 @@ def build(force=False, verbose=False):
     for src, extra in SOURCES:
         obj = os.path.join(objdir, os.path.basename(src).rsplit(".", 1)[0] + ".o")
         cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-x", "hip", "-c",
-               os.path.join(CSRC, src), "-o", obj] + extra + os.environ.get("JENGA_HIPCC_FLAGS", "").split()
+               os.path.join(CSRC, src), "-o", obj] + extra + _extra_flags()
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
@@ -102,7 +115,7 @@ def build(force=False, verbose=False):
             print(out.decode(), file=sys.stderr)
     cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", lib] + objs + ["-lhipblaslt"]
     subprocess.check_call(cmd)
-    with open(STAMP, "w") as f:
+    with open(stamp_path(lib), "w") as f:
         f.write(source_digest() + "\n")
     return lib
 

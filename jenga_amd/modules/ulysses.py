@@ -329,7 +329,7 @@ class UlyssesAttenCarve(torch.nn.Module):
         if (S_loc * N) % 128 or S_txt % 128:
             raise ValueError("gathered image length and text length must be multiples of 128")
 
-    def begin(self, B, S_loc, H, S_txt, dtype, device, D=128):
+    def begin(self, B, S_loc, H, S_txt, dtype, device, D=128, pipeline=None):
         """Start one attention call of the sequence-parallel blocks: allocates the peer-major send buffers and the
         gathered attention inputs and returns the pending call (`PendingAttenCarve`).  The caller posts Q, K (and V)
         as soon as their GEMM is done, keeps issuing independent work (the V GEMM, the text stream, the MLP half of
@@ -337,7 +337,8 @@ class UlyssesAttenCarve(torch.nn.Module):
         ex = self.exchange()
         N, r = ex.size(), ex.rank()
         self._check(B, S_loc, H, S_txt, N)
-        return PendingAttenCarve(self, ex, N, r, B, S_loc, H, S_txt, D, dtype, device)
+        return PendingAttenCarve(self, ex, N, r, B, S_loc, H, S_txt, D, dtype, device,
+                                 pipeline=self.pipeline if pipeline is None else bool(pipeline))
 
     @torch.no_grad()
     def forward(self, attn, query, key, value, *, joint_tensor_query=None, joint_tensor_key=None,
@@ -350,7 +351,8 @@ class UlyssesAttenCarve(torch.nn.Module):
             raise ValueError("jenga_amd Ulysses: only joint_strategy='rear' with text q/k/v (the Jenga call) is supported")
         B, S_loc, H, D = query.shape
         S_txt = joint_tensor_query.shape[1]
-        pend = self.begin(B, S_loc, H, S_txt, query.dtype, query.device, D)
+        # (the reference-signature call has no head-group pipeline: one group whatever JENGA_ULYSSES_PIPELINE says -- ADVICE r5)
+        pend = self.begin(B, S_loc, H, S_txt, query.dtype, query.device, D, pipeline=False)
         pend.post_packed(query, key, value, joint_tensor_query, joint_tensor_key, joint_tensor_value)
         return pend.finish(top_k=top_k, text_amp=text_amp, block_neighbor_list=block_neighbor_list,
                            p_remain_rates=p_remain_rates, cu_seqlens_q=cu_seqlens_q, dense=dense)
@@ -384,15 +386,16 @@ class PendingAttenCarve:
 
     Everything between a post_* and finish() that the caller enqueues on the compute stream overlaps the transfer."""
 
-    def __init__(self, sp, ex, N, r, B, S_loc, H, S_txt, D, dtype, device):
+    def __init__(self, sp, ex, N, r, B, S_loc, H, S_txt, D, dtype, device, pipeline=None):
         self.sp, self.ex, self.N, self.r = sp, ex, N, r
+        pipeline = sp.pipeline if pipeline is None else pipeline
         self.B, self.S_loc, self.H, self.S_txt, self.D = B, S_loc, H, S_txt, D
         self.Hn, self.S_img = H // N, S_loc * N
         self.dtype, self.device = dtype, device
         # head groups: 1 (all H/N heads of the rank in one exchange / one attention launch) or, pipelined, H/N groups of one
         # head.  Everything is allocated group-major -- [G, B, S, hg, D] attention inputs, [G, N, B, S_loc, hg, D] send
         # buffers -- so that a group's chunks are contiguous messages; with G == 1 that IS the round-4 layout.
-        self.G = self.Hn if (sp.pipeline and self.Hn > 1) else 1
+        self.G = self.Hn if (pipeline and self.Hn > 1) else 1
         self.hg = self.Hn // self.G
         mk = lambda shape: torch.empty(shape, dtype=dtype, device=device)
         self.alloc = [mk((self.G, B, self.S_img + S_txt, self.hg, D)) for _ in range(3)]

@@ -65,9 +65,17 @@ def test_golden_cases_hamming_is_reported(golden_dir, dev, index):
     assert ok, f"{name}: mask is not legal under the tie freedom (hamming {ham}/{ref.size})"
 
 
+# rows whose only difference from the oracle is the summation order of one pooled score (see below): at most 1 in 1000 sampled
+# (row, head) pairs may be settled that way -- every recorded run so far has 0..2 of 3600+ -- so that a systematic error in
+# the kernel's dot products cannot pass as "summation order" 
+MAX_SETTLED_PER_1000 = 1
+
+
 def _compare_with_oracle_from_pooled(dev, q, k, nimg, tb, top_k, p, nbm, ffb, sample_rows, tag):
     """q,k [1,S,H,128] on the device (already padded to blocks).  HIP lists vs oracle selection from the HIP pooled
     tensors, on `sample_rows` query blocks of every head."""
+    dtype_name = {torch.bfloat16: "bfloat16", torch.float16: "float16"}[q.dtype]
+    scale = np.float32(q.shape[-1] ** -0.5)      # the selection's sm_scale: head_dim ** -0.5 of the call
     from jenga_amd import _capi
     from oracle import attention as oa
     nb = nimg + tb
@@ -86,7 +94,7 @@ def _compare_with_oracle_from_pooled(dev, q, k, nimg, tb, top_k, p, nbm, ffb, sa
     idx_c, cnt_c = idx.cpu().numpy(), cnt.cpu().numpy()
     for i, m in enumerate(rows):
         neigh = None if nb_np is None else nb_np[i:i + 1]
-        ref, n_ref = oa.build_block_mask_from_pooled(qp[:, :, i:i + 1], kp, top_k, nimg, nb, p, tb, neigh, "bfloat16")
+        ref, n_ref = oa.build_block_mask_from_pooled(qp[:, :, i:i + 1], kp, top_k, nimg, nb, p, tb, neigh, dtype_name)
         if ffb and m < ffb:
             ref[..., :ffb] = True
         for h in range(H):
@@ -99,12 +107,12 @@ def _compare_with_oracle_from_pooled(dev, q, k, nimg, tb, top_k, p, nbm, ffb, sa
                 # the two orders: re-derive this row with the kernel's order (fma emulated in float64: exact product, one
                 # rounding of the sum) and compare again -- only a difference that survives is the kernel's
                 acc = np.zeros(nimg, np.float32)
-                for c in range(128):
+                for c in range(q.shape[-1]):
                     acc = (acc.astype(np.float64) + np.float64(qp[0, h, i, c]) * kp[0, h, :nimg, c].astype(np.float64)).astype(np.float32)
                 from oracle.rounding import rounder
-                rnd = rounder("bfloat16")
-                sc = rnd(rnd(acc) * np.float32(128 ** -0.5))[None, None, None]
-                order, n_ = oa.blocks_needed(oa.row_probs(sc, "bfloat16"), top_k, p, "bfloat16")
+                rnd = rounder(dtype_name)
+                sc = rnd(rnd(acc) * scale)[None, None, None]
+                order, n_ = oa.blocks_needed(oa.row_probs(sc, dtype_name), top_k, p, dtype_name)
                 ref2 = ref[0, h, 0].copy()
                 ref2[:nimg] = False
                 ref2[order[0, 0, 0, :int(n_[0, 0, 0])]] = True
@@ -118,9 +126,12 @@ def _compare_with_oracle_from_pooled(dev, q, k, nimg, tb, top_k, p, nbm, ffb, sa
             ham_tot += d
             n_diff += d > 0
             size_tot += nb
+    n_settled = sum(1 for x in seq_order_explained if x[4] == 0)
+    cap = max(1, (len(rows) * H * MAX_SETTLED_PER_1000 + 999) // 1000)
     _record("select_full_size.json", {tag: dict(hamming=ham_tot, of=size_tot, rows_differing=int(n_diff),
-                                                rows=len(rows) * H,
+                                                rows=len(rows) * H, rows_settled=n_settled, rows_settled_cap=cap,
                                                 rows_settled_by_the_kernels_dot_order=[list(x) for x in seq_order_explained])})
+    assert n_settled <= cap, f"{tag}: {n_settled} of {len(rows) * H} rows needed the kernel's own dot order (cap {cap})"
     # given identical pooled inputs the selection logic must reproduce the oracle's lists: every recorded run
     # (profiles/r02_ / r03_parity_select_full_size.json) has Hamming distance 0 on every shape
     assert ham_tot == 0, (ham_tot, size_tot)
@@ -147,8 +158,9 @@ def test_hunyuan_720p_lists_vs_oracle_from_hip_pooled(dev):
 
 @pytest.mark.parametrize("nimg,tb", [(1500, 2), (2048, 4), (1025, 0)])
 def test_rows_beyond_1024_blocks_vs_oracle_from_hip_pooled(dev, nimg, tb):
-    """More than 1024 image key blocks: 32 keys per lane in the wave-level sort, and (2048) more dynamic LDS than a launch gets
-    without the attribute -- the default (CPU-cumsum) contract against the oracle, no neighbour list."""
+    """More than 1024 image key blocks: 32 keys per lane in the wave-level sort and the largest dynamic-LDS request of the
+    kernel (2048 columns: 51 712 bytes, still under the 64 KiB a launch gets without an attribute; select.hip static_asserts
+    it) -- the default (CPU-cumsum) contract against the oracle, no neighbour list."""
     nb, H = nimg + tb, 2
     g = torch.Generator(device=dev).manual_seed(9 + nimg)
     cent = torch.randn(1, nb, 1, H, 128, generator=g, device=dev) * 0.7

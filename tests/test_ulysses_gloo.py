@@ -80,6 +80,15 @@ def _worker(rank, world, port, ret, mode):
                                     cu_seqlens_kv=cu, top_k=world * top_k_local, text_amp=0.25,
                                     block_neighbor_list=torch.from_numpy(nbm), p_remain_rates=0.3)
         ret[rank] = out.float().numpy()
+        # JENGA_ULYSSES_PIPELINE=1 / pipeline=True must not break the reference-signature call (it has no head-group pipeline
+        # and runs as one group): same collectives, same bits
+        sp_p = ulysses.UlyssesAttenCarve(select_fn=_oracle_select, attend_fn=_oracle_attend, pack_fn=ou.pack_heads,
+                                         unpack_fn=ou.unpack_heads, pipeline=True,
+                                         exchange=ulysses.DistExchange(ulysses.get_sp_group().group, mode=mode))
+        out_p = my_parallel_attention(sp_p, loc(q), loc(k), loc(v), img_q_len=S_loc, img_kv_len=S_loc, cu_seqlens_q=cu,
+                                      cu_seqlens_kv=cu, top_k=world * top_k_local, text_amp=0.25,
+                                      block_neighbor_list=torch.from_numpy(nbm), p_remain_rates=0.3)
+        assert torch.equal(out_p, out), "forward() with pipeline=True differs from the unpipelined call"
         # the fused entry point the DiT blocks use (forward_qkv: RAW q / k / v, norm + RoPE + pack in one local step):
         # must equal forward() on the separately normalised / rotated tensors, bit for bit
         from oracle import norm_rope as onr
