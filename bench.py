@@ -73,6 +73,105 @@ def traffic_bytes_per_pair(pmc, rate, shared_frac):
                        "coh": [round(f1, 3), round(coh["traffic_bytes_per_kept_pair"])], "at_shared_frac": round(x, 3)}}
 
 
+def pmc_read_in_this_run(argv, timeout_s=360):
+    """-> ({tag: {"fetch_bytes", "write_bytes", "pairs", "launches"}}, "ok") or (None, why).  Two child processes of this
+    script (`--pmc-child`: the same model, seeds, lists; one computed step per stage) under rocprofv3 --pmc, one counter set
+    each (FETCH_SIZE needs 3 of the 4 TCC counters, WRITE_SIZE 2: MI355X_MICROARCH.md), counters only.  Bytes with the guide's
+    gfx950 corrections: FETCH_SIZE counts 64 B per 128-B request -> x 2; both are in KiB."""
+    import glob
+    import shutil
+    import sqlite3
+    import subprocess
+    import tempfile
+    rp = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(rp):
+        return None, "rocprofv3 not found"
+    work = tempfile.mkdtemp(prefix="jenga_bench_pmc_", dir="/tmp")
+    child = [sys.executable, os.path.join(ROOT, "bench.py"), "--pmc-child"] + argv
+    env = dict(os.environ, TMPDIR="/tmp")
+    per_ctr, order = {}, None
+    try:
+        for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(work, ctr)
+            with open(os.path.join(work, ctr + ".out"), "w") as fo, open(os.path.join(work, ctr + ".err"), "w") as fe:
+                r = subprocess.run([rp, "--pmc", ctr, "-d", d, "-o", "p", "--"] + child, cwd="/tmp", env=env, stdout=fo,
+                                   stderr=fe, timeout=timeout_s)
+            if r.returncode != 0:
+                return None, f"the {ctr} pass exited with {r.returncode}: " + open(os.path.join(work, ctr + ".err")).read()[-300:]
+            lines = [ln for ln in open(os.path.join(work, ctr + ".out")) if ln.startswith('{"pmc_child"')]
+            if not lines:
+                return None, f"the {ctr} pass printed no launch list"
+            launches = json.loads(lines[-1])["pmc_child"]
+            if order is None:
+                order = launches
+            elif [x[1] for x in order] != [x[1] for x in launches]:
+                return None, "the two passes saw different kept lists"
+            dbs = glob.glob(os.path.join(d, "**", "*.db"), recursive=True)
+            if not dbs:
+                return None, f"the {ctr} pass left no database"
+            con = sqlite3.connect(dbs[0])
+            tabs = [r_[0] for r_ in con.execute("select name from sqlite_master where type='table'")]
+            g_ = lambda k: [t for t in tabs if k in t][0]
+            q = f"""select d.id, sum(e.value) from {g_('pmc_event')} e
+                    join {g_('info_pmc')} p on e.pmc_id = p.id join {g_('kernel_dispatch')} d on e.event_id = d.event_id
+                    join {g_('info_kernel_symbol')} s on d.kernel_id = s.id
+                    where s.kernel_name like '%bsattn_l%' and p.name = '{ctr}' group by d.id order by d.start"""
+            vals = [v for _, v in con.execute(q)]
+            con.close()
+            if len(vals) != len(launches):
+                return None, f"{ctr}: {len(vals)} attention dispatches in the database, {len(launches)} launches in the child"
+            per_ctr[ctr] = vals
+        out = {}
+        for (tag, pairs), f_, w_ in zip(order, per_ctr["FETCH_SIZE"], per_ctr["WRITE_SIZE"]):
+            t = out.setdefault(tag, dict(fetch_bytes=0.0, write_bytes=0.0, pairs=0, launches=0))
+            t["fetch_bytes"] += 2.0 * f_ * 1024.0
+            t["write_bytes"] += w_ * 1024.0
+            t["pairs"] += int(pairs)
+            t["launches"] += 1
+        return out, "ok"
+    except subprocess.TimeoutExpired:
+        return None, f"a counter pass exceeded {timeout_s} s"
+    except Exception as e:      # noqa: BLE001 - a measurement convenience must not end the run
+        return None, repr(e)[:300]
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
+
+
+def _apply_pmc(read, ps, traffic_per_rate, t_pmc):
+    """Counter-pass results per drop rate -> (traffic, traffic_TBps, traffic_per_rate, provenance) of the timed launches, or None
+    when a drop rate of the timed launches has no counter-pass launch."""
+    tot_bytes, per_rate_new = 0.0, {}
+    for tag, bt in ps.get("by_tag", {}).items():
+        r_ = read.get(tag)
+        if r_ is None or r_["pairs"] == 0:
+            continue
+        bpp = (r_["fetch_bytes"] + r_["write_bytes"]) / r_["pairs"]
+        per_launch = bpp * bt["pairs"] / max(bt["launches"], 1)
+        tot_bytes += bpp * bt["pairs"]
+        per_rate_new[str(tag)] = {
+            "launches": bt["launches"], "avg_launch_ms": round(bt["total_ms"] / max(bt["launches"], 1), 3),
+            "kept_block_pairs_per_launch": bt["pairs"] // max(bt["launches"], 1),
+            "counter_pass_launches": r_["launches"],
+            "counter_pass_kept_block_pairs_per_launch": r_["pairs"] // max(r_["launches"], 1),
+            "fetch_bytes_per_launch_counter_pass": int(r_["fetch_bytes"] / r_["launches"]),
+            "write_bytes_per_launch_counter_pass": int(r_["write_bytes"] / r_["launches"]),
+            "bytes_per_kept_pair": round(bpp),
+            "bytes_per_kept_pair_from_committed_constants": traffic_per_rate.get(str(tag), {}).get("bytes_per_kept_pair"),
+            "traffic_per_launch": int(per_launch),
+            "traffic_TBps": round(per_launch / max(bt["total_ms"] / max(bt["launches"], 1) * 1e-3, 1e-12) / 1e12, 3),
+            "ratio_to_algorithmic_bytes": round(per_launch / ATTN_ALGORITHMIC_BYTES, 1)}
+    if tot_bytes <= 0 or len(per_rate_new) != len(ps.get("by_tag", {})):
+        return None
+    traffic = int(tot_bytes / ps["launches"])
+    tbps = round(traffic / (ps["total_ms"] / ps["launches"] * 1e-3) / 1e12, 3) if ps["total_ms"] > 0 else None
+    prov = ("read in this run: two child passes of this command on this box (`rocprofv3 --pmc FETCH_SIZE` and `--pmc "
+            "WRITE_SIZE`, counters only) ran one computed step per stage with the same seeds -- the same kept lists, see "
+            "counter_pass_kept_block_pairs_per_launch -- and read both counters for every attention launch; bytes = 2 x FETCH_SIZE "
+            "KiB + WRITE_SIZE KiB (gfx950 tallies a 128-B request as 64 B: MI355X_MICROARCH.md), per kept pair and drop rate, x the "
+            f"timed launches' pairs ({time.perf_counter() - t_pmc:.0f} s for both passes)")
+    return traffic, tbps, per_rate_new, prov
+
+
 def attn_kernel_name():
     """Name of the attention kernel the current default flags launch (as rocprofv3 prints it)."""
     from jenga_amd import _capi
@@ -123,6 +222,13 @@ def parse():
     ap.add_argument("--no-other-kernel-ref", action="store_true",
                     help="skip the computed steps re-run after the timed region with the OTHER attention kernel (LP <-> pair)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--pmc", choices=["auto", "on", "off"], default="auto",
+                    help="roofline.traffic READ IN THIS RUN: after the timed region, two child passes of this script under "
+                         "`rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (counters only, no tracing domain) run one computed "
+                         "step per stage with the same seeds and read the memory-side bytes of every attention launch.  auto = on "
+                         "for a single-GPU hy720p run when rocprofv3 is on the box; a failed pass falls back to the committed "
+                         "per-pair constants and says so")
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--no-dense-ref", action="store_true",
                     help="skip the ONE dense (sa-drop 0) computed step that is run after the timed region to report "
                          "speedup_vs_dense (the reference's own headline: 1625 s -> 310 s, README.md:80-82)")
@@ -835,6 +941,17 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if a.pmc_child:
+        # (under rocprofv3 --pmc, started by pmc_read_in_this_run of the parent run): one computed step per stage, nothing else;
+        # the attention launches in dispatch order with their drop rate and kept pairs go to stdout
+        _capi.ATTN_PROFILE = prof_c = _capi.AttnProfile()
+        for k in range(len(stages)):
+            run_step(next(i for i in computed_steps if stage_of(i, split) == k and i not in forced))
+        torch.cuda.synchronize()
+        print(json.dumps({"pmc_child": [[tag, int(pr.item()) if torch.is_tensor(pr) else int(pr)] for tag, pr in prof_c.per_launch]}),
+              flush=True)
+        return
+
     if dist_on or sim > 1:
         # per-rank GEMM shapes (M = S_img / N): hipBLASLt's first pick is not its fastest there (profiles/
         # r03_gemm_tunableop.json, r03_gemm_epilogue_ab.json) -- let jenga_linear time its first 32 candidates once per
@@ -1091,6 +1208,29 @@ def main():
             traffic = int(tot_bytes / ps["launches"])
             if ps["total_ms"] > 0:
                 traffic_tbps = round(traffic / (ps["total_ms"] / ps["launches"] * 1e-3) / 1e12, 3)
+    # ---- ... and READ in this run (review r5 item 6): child passes under rocprofv3 --pmc, same seeds and lists, this box
+    traffic_provenance = ("derived, not read in this run: committed per-kept-pair constants (one per drop "
+                          "rate) x this run's pairs, launch by launch")
+    pmc_note = None
+    want_pmc = a.pmc == "on" or (a.pmc == "auto" and not dist_on and sim <= 1 and a.preset != "dense" and rank == 0)
+    if want_pmc and ps["launches"] > 0:
+        child_argv = ["--preset", a.preset, "--rates"] + [str(r_) for r_ in a.rates] + [
+            "--p-remain", str(a.p_remain), "--latent"] + [str(v_) for v_ in a.latent] + [
+            "--valid-text", str(a.valid_text), "--peaky", str(a.peaky), "--coherent", str(a.coherent), "--gemm-tuning", a.gemm_tuning,
+            "--pmc", "off"] + (["--i2v"] if a.i2v else []) + (["--depth", str(a.depth[0]), str(a.depth[1])] if a.depth else [])
+        t_pmc = time.perf_counter()
+        read, pmc_note = pmc_read_in_this_run(child_argv)
+        try:
+            pmc_applied = _apply_pmc(read, ps, traffic_per_rate, t_pmc) if read is not None else None
+        except Exception as e:      # noqa: BLE001 - never lose the line over the optional leg
+            pmc_applied, pmc_note = None, "applying the counters failed: " + repr(e)[:200]
+        if pmc_applied is not None:
+            traffic, traffic_tbps, traffic_per_rate, traffic_provenance = pmc_applied
+        elif read is not None and pmc_note == "ok":
+            pmc_note = "the counter passes did not cover every drop rate of the timed launches"
+        if pmc_note != "ok":
+            traffic_provenance += f" (the in-run counter passes were tried and failed: {pmc_note})"
+            print(f"bench.py: in-run counter passes failed: {pmc_note}", file=sys.stderr)
     flops = ps["pairs"] * FLOPS_PER_PAIR
     ach = flops / (ps["total_ms"] * 1e-3) / 1e12 if ps["total_ms"] > 0 else 0.0
     # ---- whole-loop arithmetic: attention FLOPs of the realised lists (this rank's launches) + the dense linear algebra
@@ -1150,9 +1290,8 @@ def main():
         "roofline": {"kernel": attn_kernel_name(), "bound": "mfma", "achieved": round(ach, 1),
                      "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_PEAK_TFLOPS, 4),
                      "traffic": traffic, "traffic_TBps": traffic_tbps,
-                     "traffic_provenance": "derived, not read in this run: committed per-kept-pair constants (one per drop "
-                                           "rate) x this run's pairs, launch by launch",
-                     "traffic_source": f"{pmc_rel}: memory-side bytes per kept block pair from separate rocprofv3 --pmc "
+                     "traffic_provenance": traffic_provenance,
+                     "traffic_source_of_the_committed_constants": f"{pmc_rel}: memory-side bytes per kept block pair from separate rocprofv3 --pmc "
                                        "passes of this kernel at sa-drop 0.7 and 0.8 on one box (FETCH_SIZE / WRITE_SIZE with the "
                                        "guide's gfx950 corrections; lists with little and with much overlap between adjacent "
                                        "query blocks, interpolated at this run's adjacent_shared_frac); traffic = mean over the "

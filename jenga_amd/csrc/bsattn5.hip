@@ -45,6 +45,9 @@
 #ifndef LQ_DMA_SLOT0
 #define LQ_DMA_SLOT0 3    // the four LDS-DMA pieces of a block go out in slots LQ_DMA_SLOT0 + 8 i
 #endif
+#ifndef LQ_WAIT_PAIR
+#define LQ_WAIT_PAIR 0    // round 6: one counted lgkmcnt wait per FOUR MFMAs (two fragments) instead of one per two
+#endif
 #ifndef LQ_X_NOSM
 #define LQ_X_NOSM 0       // no softmax arithmetic in lq_bb (P = const, no exact-path ballot)
 #endif
@@ -124,10 +127,15 @@ __device__ __forceinline__ void lq_bb(LpState& sa, LpState& sb, const unsigned c
 #define LQ_SM_X(E_) ((E_) < 4 ? ((E_) >> 1) : (E_) - 2)
 #define LQ_SM_ADD(E_)                                                                                                 \
     do {                                                                                                              \
-        if (((E_) & 15) < 4) acc[((E_) >> 4) * 4 + ((E_) & 3)] = xx[E_];                                              \
-        else acc[((E_) >> 4) * 4 + ((E_) & 3)] += xx[E_];                                                             \
+        if (!LP_ROWSUM_DOT2) {                                                                                        \
+            if (((E_) & 15) < 4) acc[((E_) >> 4) * 4 + ((E_) & 3)] = xx[E_];                                          \
+            else acc[((E_) >> 4) * 4 + ((E_) & 3)] += xx[E_];                                                         \
+        }                                                                                                             \
         if ((E_) & 1) {                                                                                               \
             ww[(E_) >> 1] = pack2<T>(xx[(E_) - 1], xx[E_]);                                                           \
+            /* LP_ROWSUM_DOT2: one chain per sub-block, c + lo + hi of the packed pair (lp_core.h); in front of the pin */ \
+            if (LP_ROWSUM_DOT2)                                                                                       \
+                acc[((E_) >> 4) * 4] = lp_pair_sum<T>(ww[(E_) >> 1], ((E_) & 15) == 1 ? 0.f : acc[((E_) >> 4) * 4]);  \
             asm volatile("" : "+v"(ww[(E_) >> 1]));   /* stay in this slot */                                         \
         }                                                                                                             \
     } while (0)
@@ -139,16 +147,16 @@ __device__ __forceinline__ void lq_bb(LpState& sa, LpState& sb, const unsigned c
                 if ((M_) >= 1 && (M_) < 33) xx[((M_) - 1) & 31] = __builtin_amdgcn_exp2f(tt[((M_) - 1) & 31]);        \
                 if ((M_) < 32) tt[(M_) & 31] = LQ_SP((M_) & 31) * qk_scale + ((((M_) & 31) >> 4) ? sb.neg_m : sa.neg_m); \
                 if ((M_) == 33) {                                                                                     \
-                    halfA = (acc[0] + acc[1]) + (acc[2] + acc[3]);                                                    \
-                    halfB = (acc[4] + acc[5]) + (acc[6] + acc[7]);                                                    \
+                    halfA = LP_ROWSUM_DOT2 ? acc[0] : (acc[0] + acc[1]) + (acc[2] + acc[3]);                          \
+                    halfB = LP_ROWSUM_DOT2 ? acc[4] : (acc[4] + acc[5]) + (acc[6] + acc[7]);                          \
                 }                                                                                                     \
             } else {                                                                                                  \
                 _Pragma("unroll") for (int e_ = 0; e_ < 32; ++e_)                                                     \
                     if (LQ_SM_X(e_) + 1 == (M_)) LQ_SM_ADD(e_);                                                       \
                 _Pragma("unroll") for (int e_ = 0; e_ < 32; ++e_)                                                     \
                     if (LQ_SM_X(e_) == (M_)) xx[e_] = __builtin_amdgcn_exp2f(LQ_SP(e_));                              \
-                if ((M_) == 15) halfA = (acc[0] + acc[1]) + (acc[2] + acc[3]);                                        \
-                if ((M_) == 31) halfB = (acc[4] + acc[5]) + (acc[6] + acc[7]);                                        \
+                if ((M_) == 15) halfA = LP_ROWSUM_DOT2 ? acc[0] : (acc[0] + acc[1]) + (acc[2] + acc[3]);              \
+                if ((M_) == 31) halfB = LP_ROWSUM_DOT2 ? acc[4] : (acc[4] + acc[5]) + (acc[6] + acc[7]);              \
             }                                                                                                         \
         }                                                                                                             \
     } while (0)
@@ -168,8 +176,16 @@ __device__ __forceinline__ void lq_bb(LpState& sa, LpState& sb, const unsigned c
 #define LQ_SLOT(M_)                                                                                                   \
     do {                                                                                                              \
         if (!LQ_X_NOREAD && !((M_) & 1) && (((M_) < 16 && DO_QK) || ((M_) >= 16 && DO_PV))) {                         \
-            LQ_LGKM(LAST - ((M_) >> 1) < LQ_AHEAD - 1 ? LAST - ((M_) >> 1) : LQ_AHEAD - 1);                                                 \
-            __builtin_amdgcn_sched_barrier(0);   /* or hipcc moves the MFMA above the wait and adds its own */        \
+            if (!LQ_WAIT_PAIR) {                                                                                      \
+                LQ_LGKM(LAST - ((M_) >> 1) < LQ_AHEAD - 1 ? LAST - ((M_) >> 1) : LQ_AHEAD - 1);                       \
+                __builtin_amdgcn_sched_barrier(0);   /* or hipcc moves the MFMA above the wait and adds its own */    \
+            } else if (((M_) & 3) == 0) {                                                                             \
+                /* one wait per FOUR MFMAs: fragments f = m >> 1 and f + 1 must both be there; requested behind */    \
+                /* them: f + 2 .. min(f + LQ_AHEAD - 1, LAST) */                                                      \
+                LQ_LGKM(LAST - ((M_) >> 1) - 1 < LQ_AHEAD - 2 ? (LAST - ((M_) >> 1) - 1 < 0 ? 0 : LAST - ((M_) >> 1) - 1) \
+                                                              : LQ_AHEAD - 2);                                        \
+                __builtin_amdgcn_sched_barrier(0);                                                                    \
+            }                                                                                                         \
         }                                                                                                             \
         if ((M_) < 16) {                                                                                              \
             if (DO_QK) {                                                                                              \

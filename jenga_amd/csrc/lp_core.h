@@ -18,6 +18,34 @@ template <typename T> __device__ __forceinline__ constexpr float lp_tiny();
 template <> __device__ __forceinline__ constexpr float lp_tiny<BF16>() { return 8.673617379884035e-19f; }   // 2^-60
 template <> __device__ __forceinline__ constexpr float lp_tiny<FP16>() { return 0.0625f; }                   // 2^-4
 
+// ---- round 6: the "issue-slot diet" switches (review item 1; both kernels can be built with either, A/B in profiles/r06_*) ----
+// LP_ROWSUM_DOT2: the row sums l come from the PACKED 16-bit P with one v_dot2_f32_{bf16,f16} per register pair (P . (1, 1) + acc)
+//   instead of one fp32 add per score: 8 instead of 16 + 3 VALU instructions per 32-key item and sub-block.  Deviation from the
+//   reference, which sums the UNROUNDED fp32 p (attention_block_triton_diffres.py:131 `l_i = l_i * alpha + tl.sum(p, 1)`): here
+//   l = sum of dtype-rounded p, i.e. numerator and denominator of o = acc / l see the same P.  |dl / l| <= 2^-9 / sqrt(n) for
+//   bf16; the goldens' <= 2 ulp bound is re-checked with it (tests/test_gpu_parity.py).
+#ifndef LP_ROWSUM_DOT2
+#define LP_ROWSUM_DOT2 0
+#endif
+// LP_DMA_M0_ONCE: one M0 write per four-piece LDS-DMA stage in the unrolled loops (lp_stage1<0> writes it, <1..3> rely on it):
+//   3 x (s_mov + s_nop) fewer per stage.  M0 is per-wave state; nothing else in these kernels writes it between the pieces of a
+//   stage -- tools/isa_hazards.py checks that in the generated code (no M0 write between an lp_stage1<0> and the third
+//   global_load_lds behind it, all four in one basic block).
+#ifndef LP_DMA_M0_ONCE
+#define LP_DMA_M0_ONCE 0
+#endif
+
+typedef __bf16 lp_bf2 __attribute__((ext_vector_type(2)));
+typedef _Float16 lp_h2 __attribute__((ext_vector_type(2)));
+// c + lo(w) + hi(w) for a packed pair of T
+template <typename T>
+__device__ __forceinline__ float lp_pair_sum(uint32_t w, float c) {
+    if constexpr (__is_same(T, BF16))
+        return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(lp_bf2, w), __builtin_bit_cast(lp_bf2, 0x3f803f80u), c, false);
+    else
+        return __builtin_amdgcn_fdot2(__builtin_bit_cast(lp_h2, w), __builtin_bit_cast(lp_h2, 0x3c003c00u), c, false);
+}
+
 // four 1-KiB LDS-DMA pieces of one tile (the instruction's immediate offset adds to BOTH addresses: piece i's lane offsets
 // are biased by -1024 i, so one M0 value serves the four pieces)
 __device__ __forceinline__ void lp_stage4(const void* base, unsigned lds, unsigned o0, unsigned o1, unsigned o2,
@@ -43,12 +71,21 @@ template <int I>
 __device__ __forceinline__ void lp_stage1(const LpDma& d) {
     if (I == 0)
         asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %1" : : "s"(d.lds), "s"(d.base), "v"(d.o[0]) : "memory", "m0");
+#if LP_DMA_M0_ONCE
+    else if (I == 1)
+        asm volatile("global_load_lds_dwordx4 %1, %0 offset:1024" : : "s"(d.base), "v"(d.o[1]) : "memory");
+    else if (I == 2)
+        asm volatile("global_load_lds_dwordx4 %1, %0 offset:2048" : : "s"(d.base), "v"(d.o[2]) : "memory");
+    else
+        asm volatile("global_load_lds_dwordx4 %1, %0 offset:3072" : : "s"(d.base), "v"(d.o[3]) : "memory");
+#else
     else if (I == 1)
         asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %1 offset:1024" : : "s"(d.lds), "s"(d.base), "v"(d.o[1]) : "memory", "m0");
     else if (I == 2)
         asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %1 offset:2048" : : "s"(d.lds), "s"(d.base), "v"(d.o[2]) : "memory", "m0");
     else
         asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %1 offset:3072" : : "s"(d.lds), "s"(d.base), "v"(d.o[3]) : "memory", "m0");
+#endif
 }
 #define LP_WAIT_ALL() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
 #define LP_WAIT_KEEP4() asm volatile("s_waitcnt vmcnt(4)" ::: "memory")
@@ -192,9 +229,13 @@ __device__ __forceinline__ void lp_exact(LpState& st, const f32x16& s, uint4 (&p
     for (int r = 0; r < 16; r += 2) {
         const float e0 = __builtin_amdgcn_exp2f((TEXT ? s[r] * qk_scale + old_neg_m : s[r]) - delta);
         const float e1 = __builtin_amdgcn_exp2f((TEXT ? s[r + 1] * qk_scale + old_neg_m : s[r + 1]) - delta);
+        w[r >> 1] = pack2<T>(e0, e1);
+#if LP_ROWSUM_DOT2
+        psum = lp_pair_sum<T>(w[r >> 1], psum);
+#else
         psum += e0;
         psum += e1;
-        w[r >> 1] = pack2<T>(e0, e1);
+#endif
     }
     psum += __shfl_xor(psum, 32);
     pf[0] = make_uint4(w[0], w[1], w[2], w[3]);
@@ -232,11 +273,19 @@ __device__ __forceinline__ void lp_exact(LpState& st, const f32x16& s, uint4 (&p
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         e[r] = __builtin_amdgcn_exp2f(v[r] - delta);
+#if !LP_ROWSUM_DOT2
         psum += e[r];
+#endif
     }
-    psum += __shfl_xor(psum, 32);
     pf[0] = make_uint4(pack2<T>(e[0], e[1]), pack2<T>(e[2], e[3]), pack2<T>(e[4], e[5]), pack2<T>(e[6], e[7]));
     pf[1] = make_uint4(pack2<T>(e[8], e[9]), pack2<T>(e[10], e[11]), pack2<T>(e[12], e[13]), pack2<T>(e[14], e[15]));
+#if LP_ROWSUM_DOT2
+    psum = lp_pair_sum<T>(pf[0].x, psum); psum = lp_pair_sum<T>(pf[0].y, psum);
+    psum = lp_pair_sum<T>(pf[0].z, psum); psum = lp_pair_sum<T>(pf[0].w, psum);
+    psum = lp_pair_sum<T>(pf[1].x, psum); psum = lp_pair_sum<T>(pf[1].y, psum);
+    psum = lp_pair_sum<T>(pf[1].z, psum); psum = lp_pair_sum<T>(pf[1].w, psum);
+#endif
+    psum += __shfl_xor(psum, 32);
 #endif
 }
 
@@ -288,27 +337,33 @@ __device__ __forceinline__ void lp_bb(LpState& st, const unsigned char* kt, cons
                 if ((M_) < 16) tt[(M_) & 15] = sp[(M_) & 15] * qk_scale + st.neg_m;                                   \
                 if ((M_) >= 1 && (M_) < 17) xx[((M_) - 1) & 15] = __builtin_amdgcn_exp2f(tt[((M_) - 1) & 15]);        \
                 if ((M_) >= 2 && (M_) < 18) {                                                                         \
-                    if ((M_) < 6) acc[((M_) - 2) & 3] = xx[((M_) - 2) & 15];                                          \
-                    else acc[((M_) - 2) & 3] += xx[((M_) - 2) & 15];                                                  \
+                    if (!LP_ROWSUM_DOT2) {                                                                            \
+                        if ((M_) < 6) acc[((M_) - 2) & 3] = xx[((M_) - 2) & 15];                                      \
+                        else acc[((M_) - 2) & 3] += xx[((M_) - 2) & 15];                                              \
+                    }                                                                                                 \
                     if (((M_) - 2) & 1) {                                                                             \
                         ww[(((M_) - 2) & 15) >> 1] = pack2<T>(xx[((M_) - 3) & 15], xx[((M_) - 2) & 15]);              \
+                        /* (the dot2 in front of the pin: hipcc's hazard recogniser assumes a dst_sel forwarding hazard */ \
+                        /* behind every inline asm that defines a VGPR and puts an s_nop in front of an adjacent reader) */ \
+                        if (LP_ROWSUM_DOT2) acc[0] = lp_pair_sum<T>(ww[(((M_) - 2) & 15) >> 1], (M_) == 3 ? 0.f : acc[0]); \
                         asm volatile("" : "+v"(ww[(((M_) - 2) & 15) >> 1]));   /* stay in this slot */                \
                     }                                                                                                 \
                 }                                                                                                     \
-                if ((M_) == 17) half_ = (acc[0] + acc[1]) + (acc[2] + acc[3]);                                        \
+                if ((M_) == 17) half_ = LP_ROWSUM_DOT2 ? acc[0] : (acc[0] + acc[1]) + (acc[2] + acc[3]);              \
             } else {                                                                                                  \
                 _Pragma("unroll") for (int e_ = 0; e_ < 16; ++e_) {                                                   \
                     if (LP_SM_X(e_) + 1 == (M_)) {                                                                    \
-                        if (e_ < 4) acc[e_ & 3] = xx[e_]; else acc[e_ & 3] += xx[e_];                                 \
+                        if (!LP_ROWSUM_DOT2) { if (e_ < 4) acc[e_ & 3] = xx[e_]; else acc[e_ & 3] += xx[e_]; }        \
                         if (e_ & 1) {                                                                                 \
                             ww[e_ >> 1] = pack2<T>(xx[e_ - 1], xx[e_]);                                               \
+                            if (LP_ROWSUM_DOT2) acc[0] = lp_pair_sum<T>(ww[e_ >> 1], e_ == 1 ? 0.f : acc[0]);         \
                             asm volatile("" : "+v"(ww[e_ >> 1]));   /* stay in this slot */                           \
                         }                                                                                             \
                     }                                                                                                 \
                 }                                                                                                     \
                 _Pragma("unroll") for (int e_ = 0; e_ < 16; ++e_)                                                     \
                     if (LP_SM_X(e_) == (M_)) xx[e_] = __builtin_amdgcn_exp2f(sp[e_]);                                 \
-                if ((M_) == 15) half_ = (acc[0] + acc[1]) + (acc[2] + acc[3]);                                        \
+                if ((M_) == 15) half_ = LP_ROWSUM_DOT2 ? acc[0] : (acc[0] + acc[1]) + (acc[2] + acc[3]);              \
             }                                                                                                         \
         }                                                                                                             \
     } while (0)

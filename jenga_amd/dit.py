@@ -95,6 +95,39 @@ SP_OVERLAP = os.environ.get("JENGA_SP_OVERLAP", "1") != "0"
 SP_MLP_TAIL = float(os.environ.get("JENGA_SP_MLP_TAIL", "0.375"))
 
 
+# Round 6 (review item 2): the HBM-bound row kernels between the QKV GEMM and the attention launch -- fused RMSNorm + RoPE +
+# pooling, V re-tiling, block selection (~1.15 ms per layer at the 720p shape, all serial behind MFMA-bound kernels until now) --
+# run on a second stream beside the block's independent GEMM: in the single-stream blocks the MLP half of linear1 (+ GELU),
+# which needs only the modulated input (models_mul_block_gc_ha_multigpu.py:392-500: `linear1` feeds qkv AND mlp); in the
+# double-stream blocks the text stream's modulate + QKV GEMM + norm (:161-316).  Same kernels on the same inputs: results are
+# bit-identical to the one-stream order (tests/test_gpu_dit.py).  Concurrent streams are safe since round 5's packed-fp32 fix
+# (DESIGN.md section 4).  JENGA_ROWOPS_OVERLAP=0 restores the one-stream order.
+ROWOPS_OVERLAP = os.environ.get("JENGA_ROWOPS_OVERLAP", "1") != "0"
+_SIDE_STREAMS = {}
+
+
+class _Fork:
+    """fn() on the device's side stream, ordered behind everything enqueued on the current stream so far; .join() orders the
+    current stream behind it and returns fn's result.  Tensors fn allocates belong to the side stream's pool and are consumed
+    on the main stream after join(): the next fork starts behind a LATER point of the main stream, so a reused block is never
+    written while the main stream still reads it; tensors of the main stream that fn reads are released by the caller after
+    join()."""
+
+    def __init__(self, device, fn):
+        self.main = torch.cuda.current_stream(device)
+        key = (device.index, self.main.cuda_stream)
+        if key not in _SIDE_STREAMS:
+            _SIDE_STREAMS[key] = torch.cuda.Stream(device=device)
+        self.side = _SIDE_STREAMS[key]
+        self.side.wait_stream(self.main)
+        with torch.cuda.stream(self.side):
+            self.result = fn()
+
+    def join(self):
+        self.main.wait_stream(self.side)
+        return self.result
+
+
 def linear_gate_residual(lin, x, gate, res, gate2=None, mask=None):
     """res + apply_gate(lin(x), gate) (models_mul...:297-315, 500).  Without a token mask the gate multiply and the
     residual add ride in the GEMM's epilogue (jenga_linear: per-channel gate = alpha vector, residual = C matrix; the
@@ -241,6 +274,12 @@ class MMDoubleStreamBlock(nn.Module):
                 pend = sp.begin(B, S_img, H, S_txt, img_qkv.dtype, img_qkv.device)
                 pend.post_qkv(img_qkv[:, :, 0], img_qkv[:, :, 1], img_qkv[:, :, 2],
                               (self.img_attn_q_norm.weight, self.img_attn_k_norm.weight), (cos, sin))
+        if (pend is None and ROWOPS_OVERLAP and not sp and img.is_cuda and sa_drop_rate != 0.0 and S_img % 128 == 0
+                and S_txt % 128 == 0 and S_txt // 128 == txt_block_num):
+            attn = self._attention_overlapped(img_qkv, txt, txt_mod1_shift, txt_mod1_scale, cos, sin, top_k, txt_amp,
+                                              txt_block_num, p_remain_rates, block_neighbor_list, cu_seqlens_q)
+            return self._after_attention(img, txt, attn, S_img, img_mod1_gate, img_mod2_shift, img_mod2_scale, img_mod2_gate,
+                                         txt_mod1_gate, txt_mod2_shift, txt_mod2_scale, txt_mod2_gate, tr, fm)
         txt_qkv = self.txt_attn_qkv(_capi.ln_modulate(txt, txt_mod1_shift, txt_mod1_scale)).view(B, S_txt, 3, H, 128)
         if pend is not None:
             # this rank's head slice of the (replicated) text rows goes straight behind the gathered image rows; pooling
@@ -253,6 +292,43 @@ class MMDoubleStreamBlock(nn.Module):
         else:
             attn = self._attention_unfused(img_qkv, txt_qkv, cos, sin, sa_drop_rate, top_k, txt_amp, txt_block_num,
                                            p_remain_rates, block_neighbor_list, cu_seqlens_q, cu_seqlens_kv)
+        return self._after_attention(img, txt, attn, S_img, img_mod1_gate, img_mod2_shift, img_mod2_scale, img_mod2_gate,
+                                     txt_mod1_gate, txt_mod2_shift, txt_mod2_scale, txt_mod2_gate, tr, fm)
+
+    def _attention_overlapped(self, img_qkv, txt, txt_shift, txt_scale, cos, sin, top_k, txt_amp, txt_block_num,
+                              p_remain_rates, block_neighbor_list, cu_seqlens_q):
+        """The single-GPU sparse branch of _attention_unfused with the image stream's row kernels (norm + RoPE + pooling of
+        115 200 rows, V re-tiling) on the side stream while the text stream's LayerNorm + modulate, QKV GEMM, norm and V
+        re-tiling run on the main one -- they write disjoint parts of the same (image | text) buffers.  Same kernels, same
+        inputs: bit-identical to the one-stream order."""
+        H = self.heads_num
+        B, S_img = img_qkv.shape[:2]
+        S_txt = txt.shape[1]
+        dt, dev = img_qkv.dtype, img_qkv.device
+        nimg, nb = S_img // 128, (S_img + S_txt) // 128
+        q = torch.empty((B, S_img + S_txt, H, 128), dtype=dt, device=dev)
+        k = torch.empty_like(q)
+        qp = torch.empty((B, H, nimg, 128), dtype=dt, device=dev)
+        kp = torch.empty((B, H, nb, 128), dtype=dt, device=dev)
+        vt = torch.empty((B, H, 2 * nb, 128, 64), dtype=dt, device=dev)
+
+        def image_rows():
+            _capi.qk_norm_rope_pool(img_qkv[:, :, 0], img_qkv[:, :, 1], self.img_attn_q_norm.weight,
+                                    self.img_attn_k_norm.weight, cos, sin, q[:, :S_img], k[:, :S_img], qpool=qp, kpool=kp)
+            _capi.pack_v(img_qkv[:, :, 2], nimg, out=vt, dst_block0=0, dst_blocks_total=nb)
+
+        side = _Fork(dev, image_rows)
+        txt_qkv = self.txt_attn_qkv(_capi.ln_modulate(txt, txt_shift, txt_scale)).view(B, S_txt, 3, H, 128)
+        _capi.qk_norm_rope_pool(txt_qkv[:, :, 0], txt_qkv[:, :, 1], self.txt_attn_q_norm.weight,
+                                self.txt_attn_k_norm.weight, None, None, q[:, S_img:], k[:, S_img:], qpool=None,
+                                kpool=kp, pool_block0=nimg)
+        _capi.pack_v(txt_qkv[:, :, 2], S_txt // 128, out=vt, dst_block0=nimg, dst_blocks_total=nb)
+        side.join()
+        return op.attencarve_packed(q, k, vt, top_k, cu_seqlens_q[1:2], txt_block_num, txt_amp, p_remain_rates,
+                                    block_neighbor_list, pooled=(qp, kp)).view(B, S_img + S_txt, H * 128)
+
+    def _after_attention(self, img, txt, attn, S_img, img_mod1_gate, img_mod2_shift, img_mod2_scale, img_mod2_gate,
+                         txt_mod1_gate, txt_mod2_shift, txt_mod2_scale, txt_mod2_gate, tr, fm):
         img_attn, txt_attn = attn[:, :S_img], attn[:, S_img:]
         # gate * proj(attn) + residual in the proj GEMM's epilogue; the MLP input is LayerNorm + modulate in one pass, its
         # fc1 carries the GELU, its fc2 the gate and the residual
@@ -315,6 +391,22 @@ class MMSingleStreamBlock(nn.Module):
             op.attencarve_packed(q, k, vt, top_k, cu_seqlens_q[1:2], txt_block_num, txt_amp, p_remain_rates,
                                  block_neighbor_list, out=attn_out, pooled=pooled)
 
+    def _attention_prepare(self, qkv, S_img, cos, sin, top_k, txt_block_num, p_remain_rates, block_neighbor_list):
+        """Everything of the single-GPU AttenCarve call in front of the attention launch (the sparse branch of
+        _attention_unfused, same kernels in the same order): fused Q / K RMSNorm + RoPE + block means, V re-tiling, block
+        selection.  -> (q, k, vt, idx, cnt)"""
+        H = self.heads_num
+        B, S = qkv.shape[:2]
+        q = torch.empty((B, S, H, 128), dtype=qkv.dtype, device=qkv.device)
+        k = torch.empty_like(q)
+        pooled = (torch.empty((B, H, S_img // 128, 128), dtype=qkv.dtype, device=qkv.device),
+                  torch.empty((B, H, S // 128, 128), dtype=qkv.dtype, device=qkv.device))
+        _capi.qk_norm_rope_pool(qkv[:, :, 0], qkv[:, :, 1], self.q_norm.weight, self.k_norm.weight, cos, sin, q, k,
+                                s_rope=S_img, qpool=pooled[0], kpool=pooled[1])
+        vt = _capi.pack_v(qkv[:, :, 2], S // 128)
+        _, idx, cnt = op.build_block_index(q, k, top_k, txt_block_num, p_remain_rates, block_neighbor_list, pooled=pooled)
+        return q, k, vt, idx, cnt
+
     @torch.no_grad()
     def forward(self, x, vec, txt_len, cu_seqlens_q=None, cu_seqlens_kv=None, max_seqlen_q=None, max_seqlen_kv=None,
                 freqs_cis: Tuple[torch.Tensor, torch.Tensor] = None, sa_drop_rate: float = 0.0, txt_amp: float = 1.0,
@@ -374,6 +466,16 @@ class MMSingleStreamBlock(nn.Module):
         # and linear2's concat buffer as its (strided) destination -- no separate 5.7 GB activation pass, no copy
         if SPLIT_LINEAR1:
             qkv = F.linear(xm, w1[: 3 * C], None if b1 is None else b1[: 3 * C]).unflatten(-1, (3, H, 128))
+            if (ROWOPS_OVERLAP and not sp and x.is_cuda and sa_drop_rate != 0.0 and S % 128 == 0 and S_img % 128 == 0
+                    and S // 128 > txt_block_num):
+                # the row kernels on the side stream, the MLP half beside them, then the attention launch
+                prep = _Fork(x.device, lambda: self._attention_prepare(qkv, S_img, cos, sin, top_k, txt_block_num,
+                                                                       p_remain_rates, block_neighbor_list))
+                mlp_half(0, self.mlp_hidden_dim)
+                q, k, vt, idx, cnt = prep.join()
+                nimg = S // 128 - txt_block_num
+                _capi.bsattn_fwd(q, k, vt, cu_seqlens_q[1:2], idx, cnt, nimg, 128 ** -0.5, txt_amp, nimg, out=attn_out)
+                return linear_gate_residual(self.linear2, cat, mod_gate, x, gate2=tr[2], mask=fm)
             mlp_half(0, self.mlp_hidden_dim)
         else:       # one GEMM, then the activation as a pass of its own (strided source and destination)
             lin1 = self.linear1(xm)

@@ -90,3 +90,65 @@ def test_stdout_carries_the_json_line_only_when_rccl_is_up():
         os.close(w)
     assert os.read(r, 100) == b"json"
     os.close(r)
+
+
+def test_in_run_counter_passes_are_parsed_and_applied(tmp_path, monkeypatch):
+    """bench.py --pmc (round 6): roofline.traffic read in the run that reports it.  A stand-in `rocprofv3` (this test runs without
+    a GPU) writes what the real one writes -- a rocpd sqlite database with per-dispatch counter values -- and prints the child's
+    launch list; the parsing, the gfx950 corrections (2 x FETCH_SIZE KiB + WRITE_SIZE KiB), the per-rate aggregation and the
+    failure paths (no tool, mismatching dispatch count) are checked here, the real passes on the GPU box."""
+    import sqlite3
+    import stat
+
+    import bench
+    fake = tmp_path / "rocprofv3"
+    fake.write_text(f"""#!{sys.executable}
+import json, os, sqlite3, sys
+a = sys.argv[1:]
+ctr, d = a[a.index("--pmc") + 1], a[a.index("-d") + 1]
+os.makedirs(os.path.join(d, "host"), exist_ok=True)
+con = sqlite3.connect(os.path.join(d, "host", "1_results.db"))
+con.execute("create table rocpd_info_pmc_x (id integer, name text)")
+con.execute("create table rocpd_pmc_event_x (event_id integer, pmc_id integer, value real)")
+con.execute("create table rocpd_kernel_dispatch_x (id integer, event_id integer, kernel_id integer, start integer)")
+con.execute("create table rocpd_info_kernel_symbol_x (id integer, kernel_name text)")
+con.execute("insert into rocpd_info_pmc_x values (1, ?)", (ctr,))
+con.execute("insert into rocpd_info_kernel_symbol_x values (1, 'void jenga::bsattn_lp_kernel<jenga::BF16, 4>(LpParams)')")
+con.execute("insert into rocpd_info_kernel_symbol_x values (2, 'Cijk_gemm')")
+n = int(os.environ.get("FAKE_LAUNCHES", "4"))
+for i in range(n):                      # two XCC instances per dispatch: the query has to SUM them
+    for inst in range(2):
+        con.execute("insert into rocpd_pmc_event_x values (?, 1, ?)", (i, (1000.0 if ctr == "FETCH_SIZE" else 10.0) * (1 + i // 2)))
+    con.execute("insert into rocpd_kernel_dispatch_x values (?, ?, 1, ?)", (i, i, 100 - i if os.environ.get("FAKE_REVERSED") else i))
+con.execute("insert into rocpd_pmc_event_x values (99, 1, 5e9)")
+con.execute("insert into rocpd_kernel_dispatch_x values (99, 99, 2, 50)")
+con.commit()
+print(json.dumps({{"pmc_child": [[0.7, 100], [0.7, 100], [0.8, 50], [0.8, 50]]}}))
+""")
+    fake.chmod(fake.stat().st_mode | stat.S_IEXEC)
+    monkeypatch.setenv("PATH", str(tmp_path) + os.pathsep + os.environ["PATH"])
+    read, note = bench.pmc_read_in_this_run(["--preset", "base"], timeout_s=60)
+    assert note == "ok", note
+    # rate 0.7: two launches x two instances x 1000 KiB fetch -> 2 x 2 x 2000 KiB; write 2 x 2 x 10 KiB
+    assert read[0.7] == dict(fetch_bytes=2.0 * 4000 * 1024, write_bytes=40.0 * 1024, pairs=200, launches=2)
+    assert read[0.8]["fetch_bytes"] == 2.0 * 8000 * 1024 and read[0.8]["pairs"] == 100
+    ps = {"launches": 6, "total_ms": 60.0, "by_tag": {0.7: dict(launches=4, total_ms=44.0, pairs=400),
+                                                      0.8: dict(launches=2, total_ms=16.0, pairs=100)}}
+    import time
+    traffic, tbps, per_rate, prov = bench._apply_pmc(read, ps, {"0.7": {"bytes_per_kept_pair": 1}}, time.perf_counter())
+    bpp7 = (2.0 * 4000 * 1024 + 40 * 1024) / 200
+    bpp8 = (2.0 * 8000 * 1024 + 80 * 1024) / 100
+    assert per_rate["0.7"]["bytes_per_kept_pair"] == round(bpp7) and per_rate["0.8"]["bytes_per_kept_pair"] == round(bpp8)
+    assert traffic == int((bpp7 * 400 + bpp8 * 100) / 6) and prov.startswith("read in this run")
+    assert per_rate["0.7"]["bytes_per_kept_pair_from_committed_constants"] == 1
+    # a drop rate of the timed launches without a counter-pass launch: not applied
+    assert bench._apply_pmc({0.7: read[0.7]}, ps, {}, time.perf_counter()) is None
+    # dispatch count and launch list disagree -> refused, with the reason
+    monkeypatch.setenv("FAKE_LAUNCHES", "3")
+    read2, note2 = bench.pmc_read_in_this_run([], timeout_s=60)
+    assert read2 is None and "attention dispatches" in note2
+    # no tool on the box
+    monkeypatch.setenv("PATH", "/nonexistent")
+    monkeypatch.setattr(bench.os.path, "exists", lambda p: False if "rocprofv3" in p else os.path.lexists(p))
+    read3, note3 = bench.pmc_read_in_this_run([], timeout_s=5)
+    assert read3 is None and "not found" in note3

@@ -155,6 +155,37 @@ def test_forward_gather_scatter_and_skip_cache(dev):
     assert (y1.float() - y0.float()).abs().max().item() < 0.05             # same input, same residual (bf16 re-rounding)
 
 
+def test_row_kernels_on_the_side_stream_are_bit_identical_to_the_one_stream_order(dev):
+    """Round 6: the HBM-bound row kernels in front of the attention launch run on a second stream beside the block's
+    independent GEMM (jenga_amd.dit.ROWOPS_OVERLAP).  Same kernels, same inputs, same order of dependent work: the DiT forward
+    (2 double-stream + 2 single-stream blocks, computed steps at two drop rates) must give the same bits as with the switch
+    off -- repeated, so that a missing stream dependency (a race) has several chances to show."""
+    from jenga_amd import dit
+    m = _tiny_model(dev, depth=(2, 2), seed=3)
+    x, text, text2, mask = _inputs(dev, latent=(4, 16, 64))               # 2048 image tokens = 16 blocks
+    cos, sin = m.set_stage((4, 16, 64), dev)
+    t = torch.tensor([900.0], device=dev)
+    gd = torch.tensor([6000.0], device=dev)
+    old = dit.ROWOPS_OVERLAP
+    outs = {}
+    try:
+        for mode in (False, True, True, True):
+            dit.ROWOPS_OVERLAP = mode
+            for rate in (0.5, 0.75):
+                m.sa_drop_rate, m.text_amp, m.p_remain_rates = rate, 0.2, 0.3
+                m.cnt = 0
+                y = m(x, t, text, mask, text2, cos, sin, gd, return_dict=False)
+                torch.cuda.synchronize()
+                if (rate,) not in outs:
+                    assert mode is False
+                    outs[(rate,)] = y.clone()
+                else:
+                    assert torch.equal(y, outs[(rate,)]), f"overlap={mode} rate={rate}: differs from the one-stream order"
+    finally:
+        dit.ROWOPS_OVERLAP = old
+    assert torch.isfinite(outs[(0.5,)].float()).all() and not torch.equal(outs[(0.5,)], outs[(0.75,)])
+
+
 def test_sequence_parallel_path_world1_rccl(dev):
     """World size 1 over RCCL: exercises the HIP head pack/unpack kernels, all_to_all_single / all_gather plumbing
     and the SP branches of blocks and driver; must reproduce the single-GPU path bit for bit."""

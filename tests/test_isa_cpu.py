@@ -116,6 +116,28 @@ def test_pair_kernel_asm_mfmas_have_no_uncovered_hazard(asm_pair):
         assert not bad, (name, bad[:4])
 
 
+def test_lds_dma_always_follows_an_m0_write_of_its_own_stretch(asm, asm_pair):
+    """LDS-DMA takes its LDS base from M0, which the helpers of lp_core.h write in their own asm statements.  The lint
+    (tools/isa_hazards.py::check_m0) walks the generated code of both attention kernels: every global_load_lds follows an
+    `s_mov_b32 m0` of the same straight-line stretch, nothing else writes M0 in between, and a wait state separates the two.
+    (It is what makes the LP_DMA_M0_ONCE form -- one M0 write per four-piece stage, round 6, profiles/r06_attn_pair_diet.json --
+    checkable at all; the product build writes M0 per piece and must pass as well.)  A hand-made violation is caught."""
+    import isa_hazards as Hz
+    import isa_loop_spills as T
+    for text, pat in ((asm, "bsattn_lp_kernel"), (asm_pair, "bsattn_lq_kernel")):
+        ks = T.kernels(text, pat)
+        assert ks
+        for name, lines in ks.items():
+            assert sum(1 for l in lines if l.startswith("global_load_lds")) >= 16, name
+            assert Hz.check_m0(lines) == [], (name, Hz.check_m0(lines)[:3])
+    good = ["s_mov_b32 m0, s4", "s_nop 0", "global_load_lds_dwordx4 v1, s[2:3]", "v_add_f32 v0, v0, v1",
+            "global_load_lds_dwordx4 v2, s[2:3] offset:1024"]
+    assert Hz.check_m0(good) == []
+    assert Hz.check_m0(good[:3] + [".LBB0_1:"] + good[4:])                       # a join point in between: M0 unknown
+    assert Hz.check_m0(good[:3] + ["s_add_u32 m0, m0, 4"] + good[4:])            # somebody else writes M0
+    assert Hz.check_m0(["s_mov_b32 m0, s4", "global_load_lds_dwordx4 v1, s[2:3]"])  # no wait state behind the write
+
+
 @pytest.mark.parametrize("src", ["rowops.hip", "select.hip", "gilbert.hip", "bsattn.hip", "bsattn3.hip", "bsattn5.hip"])
 def test_no_packed_fp32_arithmetic_in_the_device_code(tmp_path, src):
     """Round 5 finding (jenga_amd/build.py, profiles/r05_packed_fp32_under_gpu_sharing.json): kernels with compiler-packed fp32

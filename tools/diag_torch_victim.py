@@ -4,8 +4,10 @@ The round-5 diagnosis: `v_pk_{add,mul,fma}_f32 ... op_sel:[0,1]` returns wrong l
 executes `v_mfma_f32_16x16x32_bf16`.  All the evidence so far came from this library's own kernels and one stand-alone
 reproducer.  This tool asks the question of code nobody here wrote or compiled: torch's own gfx950 kernels.
 
-  * `tools/torch_pk_census.sh` (CPU, no GPU needed) disassembles every gfx950 code object of libtorch_hip.so and lists the
-    kernels that contain the instruction form (profiles/r06_torch_pk_opsel_kernels.txt: 768 kernels).
+  * `tools/torch_pk_census.sh` (CPU, no GPU needed) disassembles every gfx950 code object of libtorch_hip.so and classifies the
+    operand selection of every v_pk_{add,mul,fma}_f32: 1895 kernels use a non-default selection, 106 of them the BROADCAST-HIGH
+    one (profiles/r06_torch_pk_bcast_hi_kernels.txt; the stand-alone reproducer's failing selection), the others SWAP /
+    broadcast-low only (profiles/r06_torch_pk_opsel_kernels.txt lists the 768 with `op_sel:[0,1...`).
   * This script repeats torch ops on fixed inputs on one stream -- ops whose kernels are on that list ("suspect") and ops
     whose kernels are not ("control") -- while a load runs on a second stream of the same process: nothing, 32x32x16 MFMAs,
     16x16x32 MFMAs (tools/micro/mfma_spin.hip: registers only, no memory traffic) or torch's bf16 GEMM (hipBLASLt, MI16x16).
@@ -32,11 +34,30 @@ N = 1 << 20
 a32 = torch.rand(1024, 2048, generator=g, device=dev) + 0.5
 b32 = torch.rand(1024, 2048, generator=g, device=dev) + 0.5
 a16 = a32.to(torch.bfloat16)
+b16_ = b32.to(torch.bfloat16)
 ah = a32.half()
 gemm_a = torch.randn(4096, 4096, generator=g, device=dev, dtype=torch.bfloat16)
 
-# (name, suspect?, fn).  "suspect": the census lists a kernel of this op's family (the trace intersect confirms per run)
+c64a = torch.complex(a32[:, :1024].contiguous(), b32[:, :1024].contiguous())
+c64b = torch.complex(b32[:, 1024:].contiguous(), a32[:, 1024:].contiguous())
+va, vb = c64a[0].contiguous(), c64b[1].contiguous()
+
+# (name, class, fn).  class "bcast": torch kernels that contain the BROADCAST-HIGH selection (op_sel:[0,1] / [1,0] with op_sel_hi
+# left at 1: both result lanes read the high half of a source pair -- the selection of the stand-alone reproducer's failing forms;
+# 106 kernels, almost all complex<float> arithmetic); True: kernels with the SWAP selection only (op_sel:[0,1] op_sel_hi:[1,0]);
+# False: controls.  The trace intersect confirms per run which kernels were really launched.
 OPS = [
+    ("mul complex64 (MulFunctor<complex<float>>)", "bcast", lambda: c64a * c64b),
+    ("mul complex64 strided", "bcast", lambda: c64a[:, ::2] * c64b[:, ::2]),
+    ("add complex64 alpha=(0.5+0.25j) (CUDAFunctor_add<complex<float>>)", "bcast", lambda: torch.add(c64a, c64b, alpha=0.5 + 0.25j)),
+    ("pow(complex64, complex64)", "bcast", lambda: torch.pow(c64a, c64b)),
+    ("pow(complex64, 2.5)", "bcast", lambda: torch.pow(c64a, 2.5)),
+    ("addr complex64", "bcast", lambda: torch.addr(c64a[:1024, :1024], va, vb)),
+    ("prod complex64 dim=-1 (ReductionMulOp)", "bcast", lambda: torch.prod(c64a * 0.7, dim=-1)),
+    ("cumprod complex64 (lookback_scan multiplies<complex>)", "bcast", lambda: torch.cumprod(c64a * 0.7, dim=-1)),
+    ("_foreach_log complex64", "bcast", lambda: torch._foreach_log([c64a, c64b])[1]),
+    ("polar", "bcast", lambda: torch.polar(a32, b32)),
+    ("addcmul(fp32, value=tensor-like scalar) mixed dtypes", "bcast", lambda: torch.addcmul(a32, torch.tensor(1.5, device=dev), b16_)),
     ("mul fp32, strided operands (elementwise_kernel_manual_unroll MulFunctor<float>)", True,
      lambda: a32[:, ::2] * b32[:, ::2]),
     ("vector_norm fp32 dim=-1 (reduce_kernel NormOps<float>)", True, lambda: torch.linalg.vector_norm(a32, dim=-1)),
@@ -91,7 +112,15 @@ def load(mode):
 def main():
     global stop
     modes = os.environ.get("DIAG_LOADS", "none,spin32,spin16,gemm").split(",")
-    first = {nm: f().clone() for nm, _, f in OPS}
+    global OPS
+    first, kept = {}, []
+    for nm, cls_, f in OPS:          # an op this torch build rejects (dtype mix ...) is skipped, not fatal
+        try:
+            first[nm] = f().clone()
+            kept.append((nm, cls_, f))
+        except Exception as e:       # noqa: BLE001
+            print(json.dumps({"skipped": nm, "why": repr(e)[:200]}), flush=True)
+    OPS = kept
     torch.cuda.synchronize()
     for mode in modes:
         stop = False
@@ -112,8 +141,9 @@ def main():
         if t:
             t.join()
         print(json.dumps({"load": mode, "load_iterations": n_load[0], "runs_per_op": runs,
-                          "mismatches_suspect": {nm: bad[nm] for nm, s_, _ in OPS if s_},
-                          "mismatches_control": {nm: bad[nm] for nm, s_, _ in OPS if not s_}}), flush=True)
+                          "mismatches_broadcast_high_kernels": {nm: bad[nm] for nm, s_, _ in OPS if s_ == "bcast"},
+                          "mismatches_swap_only_kernels": {nm: bad[nm] for nm, s_, _ in OPS if s_ is True},
+                          "mismatches_control": {nm: bad[nm] for nm, s_, _ in OPS if s_ is False}}), flush=True)
 
 
 if __name__ == "__main__":

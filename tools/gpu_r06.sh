@@ -1,0 +1,67 @@
+#!/bin/bash
+# GPU sessions of round 6 (run through gpurun): bash tools/gpu_r06.sh <stage>
+cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd /root/repo
+export TMPDIR=/tmp
+O=gpurun_out/r06_$1; mkdir -p $O
+ab() { python tools/ab_print.py "$1"; }
+case "$1" in
+A)  # new parity tests, the torch-native victim test (+ kernel names under rocprofv3), the stand-alone reproducer, LP vs pair on this box
+  rocm-smi --showproductname 2>/dev/null | head -8 > $O/box.txt; hostname >> $O/box.txt
+  timeout 1500 python -m pytest tests/test_gpu_pool.py tests/test_gpu_ulysses.py tests/test_gpu_select.py tests/test_gpu_order.py -x -q -m gpu > $O/pytest_new.log 2>&1; tail -5 $O/pytest_new.log
+  python __graft_entry__.py --smoke > $O/smoke.log 2>&1; tail -2 $O/smoke.log
+  DIAG_SECS=8 timeout 300 python tools/diag_torch_victim.py > $O/torch_victim.jsonl 2> $O/torch_victim.err; cat $O/torch_victim.jsonl | cut -c1-1500
+  (cd /tmp && DIAG_SECS=1 DIAG_LOADS=none timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof_r06_torch_victim -o tv -- python $GRAFT_REPO_ROOT/tools/diag_torch_victim.py > $GRAFT_REPO_ROOT/$O/tv_prof.log 2>&1)
+  find gpurun_out/prof_r06_torch_victim -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $O/torch_victim_kernel_stats.csv
+  bash tools/torch_pk_census.sh --intersect profiles/r06_torch_pk_opsel_kernels.txt $O/torch_victim_kernel_stats.csv > $O/torch_victim_intersect.txt 2>&1; tail -25 $O/torch_victim_intersect.txt | cut -c1-220
+  timeout 300 tools/micro/bin/pk_beside_mfma 4000 > $O/pk_beside_mfma.jsonl 2>&1; grep -v '"differing": 0' $O/pk_beside_mfma.jsonl | cut -c1-200
+  timeout 300 python tools/bench_attn.py --drop 0.7 --iters 40 --attn-only --coherent 3 --gain 2 --flags 29 --also-flags 85 > $O/ab_coh.json 2> $O/ab_coh.err; ab $O/ab_coh.json
+  timeout 300 python tools/bench_attn.py --drop 0.7 --iters 40 --attn-only --flags 29 --also-flags 85 > $O/ab_flat.json 2> $O/ab_flat.err; ab $O/ab_flat.json
+  ;;
+B)  # issue-slot diet (review item 1): alt libs of both kernels on ONE box, two interleaved passes; parity of the candidates
+  C="--drop 0.7 --iters 40 --attn-only --coherent 3 --gain 2"
+  for pass in 1 2; do
+    for L in base p_dot2 p_m0 p_both p_w4 p_w6; do
+      [ $L = base ] && unset JENGA_LIB || export JENGA_LIB=$PWD/alt_libs/$L.so
+      timeout 200 python tools/bench_attn.py $C --flags 85 > $O/pair_${L}_$pass.json 2> $O/pair_${L}_$pass.err; echo "pair $L pass $pass: $(ab $O/pair_${L}_$pass.json | sed -n 2p)"
+    done
+    for L in base l_dot2 l_m0 l_both; do
+      [ $L = base ] && unset JENGA_LIB || export JENGA_LIB=$PWD/alt_libs/$L.so
+      timeout 200 python tools/bench_attn.py $C --flags 29 > $O/lp_${L}_$pass.json 2> $O/lp_${L}_$pass.err; echo "LP   $L pass $pass: $(ab $O/lp_${L}_$pass.json | sed -n 2p)"
+    done
+  done
+  for L in p_w4 p_w6 l_both; do
+    JENGA_LIB=$PWD/alt_libs/$L.so timeout 900 python -m pytest tests/test_gpu_pair.py tests/test_gpu_order.py "tests/test_gpu_parity.py" -x -q -m gpu -k "pair or order or full_size or sparse_kernel or narrow or whole_op or running_max" > $O/pytest_$L.log 2>&1; echo "parity $L: $(tail -1 $O/pytest_$L.log)"
+  done
+  unset JENGA_LIB
+  ;;
+C)  # diet without dot2 (clean A/B + counters), torch victims with the broadcast-high selection, row-kernel overlap A/B in the loop
+  C="--drop 0.7 --iters 40 --attn-only --coherent 3 --gain 2"
+  for pass in 1 2; do
+    for L in base p_m0 p_m0w4 p_m0w6; do
+      [ $L = base ] && unset JENGA_LIB || export JENGA_LIB=$PWD/alt_libs/$L.so
+      timeout 200 python tools/bench_attn.py $C --flags 85 > $O/pair_${L}_$pass.json 2> $O/pair_${L}_$pass.err; echo "pair $L pass $pass: $(ab $O/pair_${L}_$pass.json | sed -n 2p)"
+    done
+  done
+  unset JENGA_LIB
+  timeout 600 bash tools/pmc_attn2.sh r06_pair_base --drop 0.7 --iters 2 --attn-only --coherent 3 --gain 2 --flags 85 > $O/pmc_pair_base.log 2>&1; grep -E "valu_per_mfma|salu_per_mfma|lds_per_mfma|mfma_busy|effective_clock|issuing|issue_stalled|parked" $O/pmc_pair_base.log
+  JENGA_LIB=$PWD/alt_libs/p_m0w4.so timeout 600 bash tools/pmc_attn2.sh r06_pair_m0w4 --drop 0.7 --iters 2 --attn-only --coherent 3 --gain 2 --flags 85 > $O/pmc_pair_m0w4.log 2>&1; grep -E "valu_per_mfma|salu_per_mfma|lds_per_mfma|mfma_busy|effective_clock|issuing|issue_stalled|parked" $O/pmc_pair_m0w4.log
+  DIAG_SECS=8 timeout 400 python tools/diag_torch_victim.py > $O/torch_victim.jsonl 2> $O/torch_victim.err; python - <<PY
+import json
+for l in open("$O/torch_victim.jsonl"):
+    d = json.loads(l)
+    if "skipped" in d: print("skipped", d); continue
+    print(d["load"], "runs", d["runs_per_op"], "load_it", d["load_iterations"], "bcast:", {k[:28]: v for k, v in d["mismatches_broadcast_high_kernels"].items()}, "swap-only bad:", sum(d["mismatches_swap_only_kernels"].values()), "control bad:", sum(d["mismatches_control"].values()))
+PY
+  (cd /tmp && DIAG_SECS=1 DIAG_LOADS=none timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof_r06_torch_victim2 -o tv -- python $GRAFT_REPO_ROOT/tools/diag_torch_victim.py > $GRAFT_REPO_ROOT/$O/tv_prof.log 2>&1)
+  find gpurun_out/prof_r06_torch_victim2 -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $O/torch_victim_kernel_stats.csv
+  bash tools/torch_pk_census.sh --intersect profiles/r06_torch_pk_bcast_hi_kernels.txt $O/torch_victim_kernel_stats.csv > $O/torch_victim_intersect_bcast.txt 2>&1; tail -20 $O/torch_victim_intersect_bcast.txt | cut -c1-200
+  timeout 400 tools/micro/bin/pk_beside_mfma 4000 > $O/pk_beside_mfma.jsonl 2>&1; grep -v '"differing": 0' $O/pk_beside_mfma.jsonl | cut -c1-220; grep -c '"differing": 0' $O/pk_beside_mfma.jsonl
+  timeout 900 python -m pytest tests/test_gpu_dit.py tests/test_gpu_sp_dit.py -x -q -m gpu > $O/pytest_dit.log 2>&1; tail -3 $O/pytest_dit.log
+  LB="--steps 6 --warmup 2 --no-cpu-baseline --no-dense-ref --no-wan-extra --no-secondary --no-other-kernel-ref"
+  for pass in 1 2; do
+    for V in 0 1; do
+      JENGA_ROWOPS_OVERLAP=$V timeout 600 python bench.py $LB > $O/bench_overlap${V}_$pass.json 2> $O/bench_overlap${V}_$pass.err; echo "overlap=$V pass $pass: $(ab $O/bench_overlap${V}_$pass.json | head -1)"
+    done
+  done
+  ;;
+esac

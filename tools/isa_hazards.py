@@ -78,6 +78,33 @@ def check(lines, need=2, far=20):
     return bad
 
 
+def check_m0(lines):
+    """LDS-DMA (global_load_lds_*) takes its LDS base from M0.  With LP_DMA_M0_ONCE (lp_core.h) only the first piece of a
+    four-piece stage writes M0; the other three rely on it.  Per straight-line stretch (labels are join points: M0 unknown
+    behind them): every global_load_lds must follow an `s_mov_b32 m0, ...` of the same stretch with no other write to M0 in
+    between, and at least one wait state behind that s_mov.  -> list of (index, line, reason)"""
+    bad, valid, since = [], False, 0
+    for i, l in enumerate(lines):
+        if l.endswith(":"):
+            valid = False
+            continue
+        op, ops = split(l)
+        if op.startswith("global_load_lds") or op.startswith("buffer_load") and "lds" in l:
+            if not valid:
+                bad.append((i, l, "no M0 write in this straight-line stretch"))
+            elif since < 1:
+                bad.append((i, l, "no wait state between the M0 write and the LDS-DMA"))
+            since += 1
+            continue
+        if ops and ops[0] == "m0":
+            valid, since = op == "s_mov_b32", 0
+            continue
+        if op.startswith(("s_setpc", "s_swappc", "s_call")):
+            valid = False
+        since += wait_states(l)
+    return bad
+
+
 def main():
     path, pat = sys.argv[1], sys.argv[2] if len(sys.argv) > 2 else ""
     for name, lines in T.kernels(open(path).read(), pat).items():
@@ -86,6 +113,10 @@ def main():
         print(name[-60:], "asm-form MFMAs", n, "violations", len(bad))
         for i, kind, l, o in bad[:12]:
             print("   ", kind, "@", i, "|", l, "<-" if kind == "producer" else "->", o)
+        bm = check_m0(lines)
+        print("   LDS-DMA pieces", sum(1 for l in lines if l.startswith("global_load_lds")), "M0 violations", len(bm))
+        for i, l, why in bm[:8]:
+            print("    m0 @", i, "|", l, "|", why)
 
 
 if __name__ == "__main__":

@@ -107,6 +107,27 @@ __global__ void __launch_bounds__(256) victim(const uint32_t* __restrict__ in, f
                 else asm volatile("v_pk_mul_f16 %0, %1, %2 op_sel:[0,1]" : "=v"(d) : "v"(w[k] & 0x3bff3bffu), "v"(m & 0x3bff3bffu));
                 acc = acc + (f2){(float)(d & 0xffffu), (float)(d >> 16)};
             }
+            // round 6: 14 = the SWAP selection on the second source (low result reads the high half, high result the low half:
+            //   op_sel:[0,1] op_sel_hi:[1,0] -- thousands of instances in torch's own kernels, profiles/r06_torch_pk_*);
+            //   15 = the high half of the FIRST source broadcast (op_sel:[1,0]); 16 = v_pk_mul_f32 with the swap selection
+            if (FORM == 14) {
+                const f2 m = acc * (f2){0.5f, 0.25f};
+                f2 d;
+                asm volatile("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0]" : "=v"(d) : "v"(v), "v"(m));
+                acc = acc + d;
+            }
+            if (FORM == 15) {
+                const f2 m = acc * (f2){0.5f, 0.25f};
+                f2 d;
+                asm volatile("v_pk_add_f32 %0, %1, %2 op_sel:[1,0]" : "=v"(d) : "v"(m), "v"(v));
+                acc = acc + d;
+            }
+            if (FORM == 16) {
+                const f2 m = acc * (f2){0.5f, 0.25f} + (f2){1.f, 1.f};
+                f2 d;
+                asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0]" : "=v"(d) : "v"(v), "v"(m));
+                acc = acc + d;
+            }
             // 8: the mirror image: (v.lo - m.lo, v.hi - m.lo)
             if (FORM == 8) {
                 const f2 m = acc * (f2){0.5f, 0.25f};
@@ -131,13 +152,15 @@ int main(int argc, char** argv) {
     hipStream_t sv, sl;
     CHECK(hipStreamCreate(&sv)); CHECK(hipStreamCreate(&sl));
     std::vector<float> first(n), cur(n);
-    const char* names[14] = {"packed mul+add (SLP form)", "scalar", "packed fma", "packed mul", "packed add",
+    const char* names[17] = {"packed mul+add (SLP form)", "scalar", "packed fma", "packed mul", "packed add",
                             "packed sub of a broadcast HIGH half (op_sel:[0,1])", "packed sub of a broadcast LOW half (op_sel_hi:[1,0])",
                             "asm v_pk_add_f32 op_sel:[0,1] neg (x - mean, the LayerNorm instruction)", "asm v_pk_add_f32 op_sel_hi:[1,0] neg",
                             "asm v_pk_add_f32 op_sel:[0,1] (no neg)", "asm v_pk_mul_f32 op_sel:[0,1]",
-                            "asm v_pk_fma_f32 op_sel:[0,1,0]", "asm v_pk_add_f16 op_sel:[0,1]", "asm v_pk_mul_f16 op_sel:[0,1]"};
+                            "asm v_pk_fma_f32 op_sel:[0,1,0]", "asm v_pk_add_f16 op_sel:[0,1]", "asm v_pk_mul_f16 op_sel:[0,1]",
+                            "asm v_pk_add_f32 op_sel:[0,1] op_sel_hi:[1,0] (SWAP on src1)", "asm v_pk_add_f32 op_sel:[1,0] (HIGH half of src0 broadcast)",
+                            "asm v_pk_mul_f32 op_sel:[0,1] op_sel_hi:[1,0] (SWAP on src1)"};
     for (int with_load = 2; with_load >= 0; --with_load) {      // 2: 16x16x32 MFMAs beside it, 1: 32x32x16, 0: nothing
-        for (int form = 0; form < 14; ++form) {
+        for (int form = 0; form < 17; ++form) {
             int bad = 0;
             for (int l = 0; l < launches; ++l) {
                 if (with_load == 2 && (l % 4) == 0) hipLaunchKernelGGL(mfma_load<1>, dim3(2048), dim3(256), 0, sl, dsink, 4000);
@@ -156,7 +179,10 @@ int main(int argc, char** argv) {
                     case 10: hipLaunchKernelGGL(victim<10>, dim3(n / 256), dim3(256), 0, sv, din, dout, n); break;
                     case 11: hipLaunchKernelGGL(victim<11>, dim3(n / 256), dim3(256), 0, sv, din, dout, n); break;
                     case 12: hipLaunchKernelGGL(victim<12>, dim3(n / 256), dim3(256), 0, sv, din, dout, n); break;
-                    default: hipLaunchKernelGGL(victim<13>, dim3(n / 256), dim3(256), 0, sv, din, dout, n); break;
+                    case 13: hipLaunchKernelGGL(victim<13>, dim3(n / 256), dim3(256), 0, sv, din, dout, n); break;
+                    case 14: hipLaunchKernelGGL(victim<14>, dim3(n / 256), dim3(256), 0, sv, din, dout, n); break;
+                    case 15: hipLaunchKernelGGL(victim<15>, dim3(n / 256), dim3(256), 0, sv, din, dout, n); break;
+                    default: hipLaunchKernelGGL(victim<16>, dim3(n / 256), dim3(256), 0, sv, din, dout, n); break;
                 }
                 if (l == 0 || (l % 16) == 15) {          // check every 16th launch (and the first)
                     CHECK(hipMemcpyAsync(cur.data(), dout, n * 4, hipMemcpyDeviceToHost, sv));
