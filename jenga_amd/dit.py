@@ -101,8 +101,10 @@ SP_MLP_TAIL = float(os.environ.get("JENGA_SP_MLP_TAIL", "0.375"))
 # which needs only the modulated input (models_mul_block_gc_ha_multigpu.py:392-500: `linear1` feeds qkv AND mlp); in the
 # double-stream blocks the text stream's modulate + QKV GEMM + norm (:161-316).  Same kernels on the same inputs: results are
 # bit-identical to the one-stream order (tests/test_gpu_dit.py).  Concurrent streams are safe since round 5's packed-fp32 fix
-# (DESIGN.md section 4).  JENGA_ROWOPS_OVERLAP=0 restores the one-stream order.
-ROWOPS_OVERLAP = os.environ.get("JENGA_ROWOPS_OVERLAP", "1") != "0"
+# (DESIGN.md section 4).  MEASURED: it loses -- 78.68 / 78.71 against 78.50 / 78.56 s/video on one box, two interleaved passes
+# (profiles/r06_rowops_overlap_ab.json): on the power-capped board the GEMM beside the row kernels slows down by what they
+# hide.  So the one-stream order stays the default; JENGA_ROWOPS_OVERLAP=1 is the opt-in.
+ROWOPS_OVERLAP = os.environ.get("JENGA_ROWOPS_OVERLAP", "0") == "1"
 _SIDE_STREAMS = {}
 
 

@@ -130,7 +130,7 @@ print(json.dumps({{"pmc_child": [[0.7, 100], [0.7, 100], [0.8, 50], [0.8, 50]]}}
     read, note = bench.pmc_read_in_this_run(["--preset", "base"], timeout_s=60)
     assert note == "ok", note
     # rate 0.7: two launches x two instances x 1000 KiB fetch -> 2 x 2 x 2000 KiB; write 2 x 2 x 10 KiB
-    assert read[0.7] == dict(fetch_bytes=2.0 * 4000 * 1024, write_bytes=40.0 * 1024, pairs=200, launches=2)
+    assert read[0.7] == dict(fetch_bytes=2.0 * 4000 * 1024, write_bytes=40.0 * 1024, pairs=200, pairs_write_pass=200, launches=2)
     assert read[0.8]["fetch_bytes"] == 2.0 * 8000 * 1024 and read[0.8]["pairs"] == 100
     ps = {"launches": 6, "total_ms": 60.0, "by_tag": {0.7: dict(launches=4, total_ms=44.0, pairs=400),
                                                       0.8: dict(launches=2, total_ms=16.0, pairs=100)}}
@@ -152,3 +152,13 @@ print(json.dumps({{"pmc_child": [[0.7, 100], [0.7, 100], [0.8, 50], [0.8, 50]]}}
     monkeypatch.setattr(bench.os.path, "exists", lambda p: False if "rocprofv3" in p else os.path.lexists(p))
     read3, note3 = bench.pmc_read_in_this_run([], timeout_s=5)
     assert read3 is None and "not found" in note3
+
+
+def test_bench_and_its_helper_modules_reference_no_undefined_global():
+    """bench.py was split into benchlib/ in round 6; almost none of it runs without a GPU, so a name lost in the move would
+    only show on the GPU box.  tools/check_names.py: every name a function resolves as a module global exists."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import check_names
+    for m in ("bench", "benchlib.consts", "benchlib.pmc", "benchlib.launch", "benchlib.power", "benchlib.secondary",
+              "benchlib.cpu_ref", "benchlib.wan"):
+        assert check_names.undefined_globals(m) == [], m

@@ -6,8 +6,8 @@ reproducer.  This tool asks the question of code nobody here wrote or compiled: 
 
   * `tools/torch_pk_census.sh` (CPU, no GPU needed) disassembles every gfx950 code object of libtorch_hip.so and classifies the
     operand selection of every v_pk_{add,mul,fma}_f32: 1895 kernels use a non-default selection, 106 of them the BROADCAST-HIGH
-    one (profiles/r06_torch_pk_bcast_hi_kernels.txt; the stand-alone reproducer's failing selection), the others SWAP /
-    broadcast-low only (profiles/r06_torch_pk_opsel_kernels.txt lists the 768 with `op_sel:[0,1...`).
+    one (profiles/r06_torch_pk_selections.json.gz; the stand-alone reproducer's failing selection), the others SWAP /
+    broadcast-low only (the census is profiles/r06_torch_pk_selections.json.gz).
   * This script repeats torch ops on fixed inputs on one stream -- ops whose kernels are on that list ("suspect") and ops
     whose kernels are not ("control") -- while a load runs on a second stream of the same process: nothing, 32x32x16 MFMAs,
     16x16x32 MFMAs (tools/micro/mfma_spin.hip: registers only, no memory traffic) or torch's bf16 GEMM (hipBLASLt, MI16x16).

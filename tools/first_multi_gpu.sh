@@ -28,7 +28,7 @@ PY
 if [ -n "$DRY" ]; then
   export JENGA_BENCH_FORCE_DIST=1
   NS="1"
-  STEPS=${STEPS:-"--steps 3 --warmup 1"}
+  STEPS=${STEPS:-"--steps 6 --warmup 1"}   # (6 steps: every (stage, computed / skipped) class of a three-stage preset is sampled)
 else
   NS="1"
   for n in 2 4 8; do [ "$n" -le "$NDEV" ] && NS="$NS $n"; done

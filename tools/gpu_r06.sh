@@ -12,7 +12,7 @@ A)  # new parity tests, the torch-native victim test (+ kernel names under rocpr
   DIAG_SECS=8 timeout 300 python tools/diag_torch_victim.py > $O/torch_victim.jsonl 2> $O/torch_victim.err; cat $O/torch_victim.jsonl | cut -c1-1500
   (cd /tmp && DIAG_SECS=1 DIAG_LOADS=none timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof_r06_torch_victim -o tv -- python $GRAFT_REPO_ROOT/tools/diag_torch_victim.py > $GRAFT_REPO_ROOT/$O/tv_prof.log 2>&1)
   find gpurun_out/prof_r06_torch_victim -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $O/torch_victim_kernel_stats.csv
-  bash tools/torch_pk_census.sh --intersect profiles/r06_torch_pk_opsel_kernels.txt $O/torch_victim_kernel_stats.csv > $O/torch_victim_intersect.txt 2>&1; tail -25 $O/torch_victim_intersect.txt | cut -c1-220
+  bash tools/torch_pk_census.sh --intersect profiles/r06_torch_pk_selections.json.gz $O/torch_victim_kernel_stats.csv > $O/torch_victim_intersect.txt 2>&1; tail -25 $O/torch_victim_intersect.txt | cut -c1-220
   timeout 300 tools/micro/bin/pk_beside_mfma 4000 > $O/pk_beside_mfma.jsonl 2>&1; grep -v '"differing": 0' $O/pk_beside_mfma.jsonl | cut -c1-200
   timeout 300 python tools/bench_attn.py --drop 0.7 --iters 40 --attn-only --coherent 3 --gain 2 --flags 29 --also-flags 85 > $O/ab_coh.json 2> $O/ab_coh.err; ab $O/ab_coh.json
   timeout 300 python tools/bench_attn.py --drop 0.7 --iters 40 --attn-only --flags 29 --also-flags 85 > $O/ab_flat.json 2> $O/ab_flat.err; ab $O/ab_flat.json
@@ -54,7 +54,7 @@ for l in open("$O/torch_victim.jsonl"):
 PY
   (cd /tmp && DIAG_SECS=1 DIAG_LOADS=none timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof_r06_torch_victim2 -o tv -- python $GRAFT_REPO_ROOT/tools/diag_torch_victim.py > $GRAFT_REPO_ROOT/$O/tv_prof.log 2>&1)
   find gpurun_out/prof_r06_torch_victim2 -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $O/torch_victim_kernel_stats.csv
-  bash tools/torch_pk_census.sh --intersect profiles/r06_torch_pk_bcast_hi_kernels.txt $O/torch_victim_kernel_stats.csv > $O/torch_victim_intersect_bcast.txt 2>&1; tail -20 $O/torch_victim_intersect_bcast.txt | cut -c1-200
+  bash tools/torch_pk_census.sh --intersect profiles/r06_torch_pk_selections.json.gz $O/torch_victim_kernel_stats.csv > $O/torch_victim_intersect_bcast.txt 2>&1; tail -20 $O/torch_victim_intersect_bcast.txt | cut -c1-200
   timeout 400 tools/micro/bin/pk_beside_mfma 4000 > $O/pk_beside_mfma.jsonl 2>&1; grep -v '"differing": 0' $O/pk_beside_mfma.jsonl | cut -c1-220; grep -c '"differing": 0' $O/pk_beside_mfma.jsonl
   timeout 900 python -m pytest tests/test_gpu_dit.py tests/test_gpu_sp_dit.py -x -q -m gpu > $O/pytest_dit.log 2>&1; tail -3 $O/pytest_dit.log
   LB="--steps 6 --warmup 2 --no-cpu-baseline --no-dense-ref --no-wan-extra --no-secondary --no-other-kernel-ref"
@@ -63,5 +63,26 @@ PY
       JENGA_ROWOPS_OVERLAP=$V timeout 600 python bench.py $LB > $O/bench_overlap${V}_$pass.json 2> $O/bench_overlap${V}_$pass.err; echo "overlap=$V pass $pass: $(ab $O/bench_overlap${V}_$pass.json | head -1)"
     done
   done
+  ;;
+D)  # the in-run counter passes in a bench line, the dry run of tools/first_multi_gpu.sh, the whole GPU suite
+  timeout 1200 python bench.py --steps 6 --warmup 2 --no-dense-ref --no-wan-extra --no-cpu-baseline --no-other-kernel-ref > $O/bench_pmc.json 2> $O/bench_pmc.err; ab $O/bench_pmc.json
+  python - <<PY
+import json
+d = json.loads(open("$O/bench_pmc.json").read().strip().splitlines()[-1])["roofline"]
+print(d["traffic_provenance"][:400]); print("traffic", d["traffic"], d["traffic_TBps"], d["traffic_ratio_to_algorithmic_bytes"])
+for k, v in d["traffic_per_rate"].items(): print(k, {kk: v[kk] for kk in v if kk not in ("pmc_points",)})
+PY
+  DRY=1 timeout 2400 bash tools/first_multi_gpu.sh $O/first_multi_gpu_dry > $O/first_multi_gpu_dry.log 2>&1; tail -12 $O/first_multi_gpu_dry.log
+  timeout 2400 python -m pytest tests -x -q -m gpu > $O/pytest_gpu.log 2>&1; grep -E "passed|failed|error" $O/pytest_gpu.log | tail -3
+  ;;
+E)  # the records at HEAD (review item 5): the driver's command, the full 50-step loop, Wan2.1-14B, the shipped rates -- each plain and under rocprofv3 --stats
+  timeout 1500 python bench.py --steps 20 --warmup 5 > $O/bench_steps20.json 2> $O/bench_steps20.err; ab $O/bench_steps20.json
+  timeout 1200 bash tools/prof_bench.sh r06_steps20 --steps 20 --warmup 5 --no-dense-ref --no-other-kernel-ref --no-wan-extra --no-cpu-baseline --no-secondary --pmc off > $O/prof_steps20.log 2>&1; head -6 gpurun_out/prof_r06_steps20/kernel_stats.csv | cut -c1-160; ab gpurun_out/prof_r06_steps20/bench.json | head -1
+  timeout 1500 python bench.py --steps 50 --warmup 2 --no-wan-extra --no-cpu-baseline > $O/bench_full50.json 2> $O/bench_full50.err; ab $O/bench_full50.json
+  timeout 1200 bash tools/prof_bench.sh r06_full50 --steps 50 --warmup 2 --no-dense-ref --no-other-kernel-ref --no-wan-extra --no-cpu-baseline --no-secondary --pmc off > $O/prof_full50.log 2>&1; head -6 gpurun_out/prof_r06_full50/kernel_stats.csv | cut -c1-160; ab gpurun_out/prof_r06_full50/bench.json | head -1
+  timeout 1500 python bench.py --preset base-mgpu --steps 50 --warmup 2 --no-wan-extra --no-cpu-baseline > $O/bench_base_mgpu_full50.json 2> $O/bench_base_mgpu_full50.err; ab $O/bench_base_mgpu_full50.json
+  timeout 2400 python bench.py --workload wan14b --steps 50 --warmup 1 > $O/bench_wan14b.json 2> $O/bench_wan14b.err; python -c "
+import json;d=json.loads(open('$O/bench_wan14b.json').read().strip().splitlines()[-1]);print('wan14b', d['value'], d['unit'], d['roofline']['frac'], d['config'].get('schedule','')[:80])"
+  timeout 2400 bash tools/prof_bench.sh r06_wan14b --workload wan14b --steps 50 --warmup 1 --no-cpu-baseline > $O/prof_wan14b.log 2>&1; head -6 gpurun_out/prof_r06_wan14b/kernel_stats.csv | cut -c1-160
   ;;
 esac
