@@ -488,6 +488,8 @@ class PendingAttenCarve:
             q_all, k_all, v_all = self.fulls[g]
             _wait_all(self.w_qk[g])
             if dense:       # parallel_attention: no selection, every row masked at the valid length
+                # (HIP only: the dense call goes straight to the library -- an injected select_fn / attend_fn, which exist for
+                # the CPU tests of the AttenCarve path, is NOT consulted here; on CPU tensors this raises JengaError)
                 _wait_all(self.w_v[g])
                 o = _hip_attend_dense(q_all, k_all, v_all, seqlens)
             else:

@@ -75,6 +75,23 @@ PY
   DRY=1 timeout 2400 bash tools/first_multi_gpu.sh $O/first_multi_gpu_dry > $O/first_multi_gpu_dry.log 2>&1; tail -12 $O/first_multi_gpu_dry.log
   timeout 2400 python -m pytest tests -x -q -m gpu > $O/pytest_gpu.log 2>&1; grep -E "passed|failed|error" $O/pytest_gpu.log | tail -3
   ;;
+E0)  # the split bench.py end to end with every leg, short: a lost name would otherwise cost the long session
+  timeout 900 python bench.py --steps 2 --warmup 1 > $O/bench_short.json 2> $O/bench_short.err
+  timeout 900 python bench.py --workload wan14b --steps 2 --warmup 1 > $O/wan_short.json 2> $O/wan_short.err
+  python - <<PY || exit 1
+import json, sys
+ok = True
+for f in ("$O/bench_short.json", "$O/wan_short.json"):
+    try:
+        d = json.loads(open(f).read().strip().splitlines()[-1])
+        print(f, d["value"], "extras_failed:", d.get("extras_failed"), "keys:", sorted(k for k in d if k not in ("config",)))
+        ok &= not d.get("extras_failed")
+    except Exception as e:
+        print(f, "NO LINE", repr(e)); ok = False
+        print(open(f.replace(".json", ".err")).read()[-1500:])
+sys.exit(0 if ok else 1)
+PY
+  ;;
 E)  # the records at HEAD (review item 5): the driver's command, the full 50-step loop, Wan2.1-14B, the shipped rates -- each plain and under rocprofv3 --stats
   timeout 1500 python bench.py --steps 20 --warmup 5 > $O/bench_steps20.json 2> $O/bench_steps20.err; ab $O/bench_steps20.json
   timeout 1200 bash tools/prof_bench.sh r06_steps20 --steps 20 --warmup 5 --no-dense-ref --no-other-kernel-ref --no-wan-extra --no-cpu-baseline --no-secondary --pmc off > $O/prof_steps20.log 2>&1; head -6 gpurun_out/prof_r06_steps20/kernel_stats.csv | cut -c1-160; ab gpurun_out/prof_r06_steps20/bench.json | head -1
