@@ -1,5 +1,6 @@
-"""Per-head RMSNorm, drop-in for hyvideo/modules/norm_layers.py:5-59 (same constructor, same `.weight` state-dict
-key).  forward() runs the HIP kernel jenga_rmsnorm_rope (norm only) for [..., H, 128] inputs on the GPU."""
+"""RMSNorm, drop-in for hyvideo/modules/norm_layers.py:5-59 (same constructor, same `.weight` state-dict key).  forward() runs
+the HIP kernel jenga_rmsnorm_rope (norm only) for the per-head [..., H, 128] QK-norm of the Jenga blocks, and jenga_rmsnorm_rows
+for any other width (a multiple of 8, <= 8192: the same formula, `(x.float() * rsqrt(mean(x^2) + eps)).type_as(x) * weight`)."""
 import torch
 import torch.nn as nn
 
@@ -16,9 +17,15 @@ class RMSNorm(nn.Module):
             self.weight = nn.Parameter(torch.ones(dim, **factory_kwargs))
 
     def forward(self, x):
-        if x.shape[-1] != 128 or self.dim != 128:
-            raise ValueError("jenga_amd.RMSNorm implements the per-head (dim=128) QK-norm of the Jenga DiT blocks")
         w = getattr(self, "weight", None)
+        if x.shape[-1] != self.dim:
+            raise ValueError(f"jenga_amd.RMSNorm({self.dim}): the input's last dimension is {x.shape[-1]}")
+        if self.dim != 128:
+            # any other width (no Jenga entry script uses one): the full-row kernel of the Wan flavour, weight in x's dtype
+            if self.dim % 8 or self.dim > 8192:
+                raise ValueError("jenga_amd.RMSNorm: the width must be a multiple of 8 and at most 8192")
+            return _capi.rmsnorm_rows(x, w.to(x.dtype) if w is not None else torch.ones(self.dim, dtype=x.dtype, device=x.device),
+                                      self.eps)
         x4 = x if x.dim() == 4 else x.reshape(1, -1, 1, 128)
         y = _capi.rmsnorm_rope(x4, w, None, None, eps=self.eps)
         return y if x.dim() == 4 else y.reshape(x.shape)

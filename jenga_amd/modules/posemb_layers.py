@@ -70,26 +70,42 @@ def get_nd_rotary_pos_embed(rope_dim_list, start, *args, theta=10000.0, use_real
     return torch.cat(embs, dim=1)
 
 
-def _tables(freqs_cis, x):
-    if not isinstance(freqs_cis, tuple):
-        raise NotImplementedError("jenga_amd: only the real (cos, sin) RoPE form used by HunyuanVideo is implemented")
-    cos, sin = freqs_cis
-    assert cos.shape == (x.shape[1], x.shape[-1]), f"freqs_cis shape {cos.shape} does not match x shape {x.shape}"
-    return cos.to(x.device, torch.float32), sin.to(x.device, torch.float32)
+def _tables(freqs_cis, x, head_first=False):
+    """-> (cos, sin) fp32 [S, D] on x's device.  freqs_cis: the real (cos, sin) pair HunyuanVideo uses, or the COMPLEX table of
+    posemb_layers.py:216-227 ([S, D/2]): (a + ib)(c + is) = (ac - bs) + i(as + bc) is the real form with cos = Re, sin = Im
+    repeated per pair -- the same two products and one add in fp32 (tests/test_oracle_golden.py pins that bit for bit)."""
+    S = x.shape[-2] if head_first else x.shape[1]
+    if isinstance(freqs_cis, tuple):
+        cos, sin = freqs_cis
+    else:
+        if not torch.is_complex(freqs_cis):
+            raise ValueError("jenga_amd: freqs_cis must be a (cos, sin) tuple or a complex tensor")
+        cos = freqs_cis.real.repeat_interleave(2, dim=-1)
+        sin = freqs_cis.imag.repeat_interleave(2, dim=-1)
+    assert cos.shape == (S, x.shape[-1]), f"freqs_cis shape {tuple(cos.shape)} does not match x shape {tuple(x.shape)}"
+    return cos.to(x.device, torch.float32).contiguous(), sin.to(x.device, torch.float32).contiguous()
+
+
+def _rope(x, cos, sin, head_first):
+    if not head_first:
+        return _capi.rmsnorm_rope(x, None, cos, sin, eps=-1.0)
+    # [B, H, S, D]: the kernel takes any (batch, token, head) strides -- run it on the transposed view, write a [B, H, S, D] result
+    out = torch.empty_like(x, memory_format=torch.contiguous_format)
+    _capi.rmsnorm_rope(x.transpose(1, 2), None, cos, sin, eps=-1.0, out=out.transpose(1, 2))
+    return out
 
 
 def apply_rotary_emb(xq: torch.Tensor, xk: torch.Tensor, freqs_cis, head_first: bool = False
                      ) -> Tuple[torch.Tensor, torch.Tensor]:
-    """xq, xk [B,S,H,128]; freqs_cis = (cos, sin) fp32 [S,128]: (x*cos + rotate_half(x)*sin).type_as(x)."""
-    if head_first:
-        raise NotImplementedError("jenga_amd: head_first=True is not used by the Jenga DiT blocks")
-    cos, sin = _tables(freqs_cis, xq)
-    return (_capi.rmsnorm_rope(xq, None, cos, sin, eps=-1.0), _capi.rmsnorm_rope(xk, None, cos, sin, eps=-1.0))
+    """xq, xk [B,S,H,128] ([B,H,S,128] with head_first); freqs_cis = (cos, sin) fp32 [S,128] or complex [S,64]:
+    (x*cos + rotate_half(x)*sin).type_as(x)  (posemb_layers.py:181-229, both branches)."""
+    cos, sin = _tables(freqs_cis, xq, head_first)
+    return _rope(xq, cos, sin, head_first), _rope(xk, cos, sin, head_first)
 
 
 def apply_rotary_emb_single(xq, freqs_cis, head_first=False):
-    cos, sin = _tables(freqs_cis, xq)
-    return _capi.rmsnorm_rope(xq, None, cos, sin, eps=-1.0)
+    cos, sin = _tables(freqs_cis, xq, head_first)
+    return _rope(xq, cos, sin, head_first)
 
 
 def qk_norm_rope(q, k, q_weight, k_weight, freqs_cis=None, eps=1e-6, out_q=None, out_k=None):

@@ -350,6 +350,39 @@ def gen_norm_rope():
         json.dump(meta, f, indent=1, sort_keys=True)
 
 
+def gen_rope_forms():
+    """The reference's other accepted forms of the pre-ops, which no Jenga entry script reaches (VERDICT r5 missing 5):
+    apply_rotary_emb with head_first=True and with a COMPLEX freqs_cis (posemb_layers.py:181-229), RMSNorm over a width other
+    than 128 (norm_layers.py:5-59).  -> rope_forms_cases.npz"""
+    pe = _load("ref_posemb", "hyvideo/modules/posemb_layers.py")
+    nl = _load("ref_norm", "hyvideo/modules/norm_layers.py")
+    out = {}
+    grid = [3, 4, 6]
+    cos, sin = pe.get_nd_rotary_pos_embed([16, 56, 56], grid, theta=256, use_real=True, theta_rescale_factor=1)
+    cis = pe.get_nd_rotary_pos_embed([16, 56, 56], grid, theta=256, use_real=False, theta_rescale_factor=1)
+    out["cos"], out["sin"] = cos.numpy(), sin.numpy()
+    out["cis_real"], out["cis_imag"] = cis.real.numpy().copy(), cis.imag.numpy().copy()
+    gen = torch.Generator().manual_seed(15)
+    S, H, D = 72, 3, 128
+    for dt, tag in [(torch.bfloat16, "bf16"), (torch.float16, "fp16")]:
+        view = (lambda t: t.contiguous().view(torch.uint16).numpy()) if dt == torch.bfloat16 else (lambda t: t.contiguous().numpy())
+        x_q = (torch.randn(1, S, H, D, generator=gen) * 2.0).to(dt)
+        x_k = (torch.randn(1, S, H, D, generator=gen) * 0.5).to(dt)
+        hq, hk = pe.apply_rotary_emb(x_q.transpose(1, 2).contiguous(), x_k.transpose(1, 2).contiguous(), (cos, sin),
+                                     head_first=True)                       # [B, H, S, D] in and out
+        cq, ck = pe.apply_rotary_emb(x_q, x_k, cis, head_first=False)        # complex table
+        for nme, t in [("xq", x_q), ("xk", x_k), ("headfirst_q", hq), ("headfirst_k", hk), ("complex_q", cq), ("complex_k", ck)]:
+            out[f"{tag}_{nme}"] = view(t)
+        for C in (256, 3072):
+            x = (torch.randn(2, 5, C, generator=gen) * 1.5).to(dt)
+            n = nl.RMSNorm(C, elementwise_affine=True, eps=1e-6, dtype=dt)
+            n.weight.copy_((1 + 0.1 * torch.randn(C, generator=gen)).to(dt))
+            n0 = nl.RMSNorm(C, elementwise_affine=False, eps=1e-5, dtype=dt)
+            for nme, t in [(f"rms{C}_x", x), (f"rms{C}_w", n.weight.data), (f"rms{C}_y", n(x)), (f"rms{C}_y_noweight", n0(x))]:
+                out[f"{tag}_{nme}"] = view(t)
+    np.savez_compressed(os.path.join(OUT, "rope_forms_cases.npz"), **out)
+
+
 def gen_wan():
     """wan/modules/model_mul.py: rope_params / rope_apply / WanRMSNorm (diffusers is absent -> stubbed for the import)."""
     for name in ("diffusers", "diffusers.configuration_utils", "diffusers.models", "diffusers.models.modeling_utils"):
@@ -995,7 +1028,7 @@ if __name__ == "__main__":
     ap.add_argument("--only", default="")
     a = ap.parse_args()
     torch.set_grad_enabled(False)
-    if a.only not in ("wan", "sched", "wansched", "wanblock", "hyblocks", "wanforward", "hyforward", "i2vblock", "wan1p3b",
+    if a.only not in ("ropeforms", "wan", "sched", "wansched", "wanblock", "hyblocks", "wanforward", "hyforward", "i2vblock", "wan1p3b",
                       "signatures"):
         gen_gilbert(a.big)
     if a.only in ("", "select", "attn"):
@@ -1004,6 +1037,8 @@ if __name__ == "__main__":
         gen_attn()
     if a.only in ("", "rope"):
         gen_norm_rope()
+    if a.only in ("", "rope", "ropeforms"):
+        gen_rope_forms()
     if a.only in ("", "wan"):
         gen_wan()
     if a.only in ("", "wan", "wanblock"):

@@ -120,6 +120,38 @@ def test_rmsnorm_rope_vs_reference_golden(golden_dir, dev, tag, dt):
     assert_ulp_close(to_np(fk), to_np(from_bits(g[f"{tag}_rk"], dt)), dt, max_frac=2e-3, max_ulps=2, rowwise=True)
 
 
+@pytest.mark.parametrize("tag,dt", [("bf16", "bfloat16"), ("fp16", "float16")])
+def test_other_forms_of_the_pre_ops_vs_reference_golden(golden_dir, dev, tag, dt):
+    """The forms of the reference's pre-ops no Jenga entry script uses (posemb_layers.py:181-229 head_first=True and a complex
+    freqs_cis; norm_layers.py:5-59 at a width other than 128), against the reference's own outputs: RoPE bit for bit, RMSNorm
+    <= 2 ulp (the order of the mean is free)."""
+    from jenga_amd.modules.norm_layers import RMSNorm
+    from jenga_amd.modules.posemb_layers import apply_rotary_emb
+    g = np.load(os.path.join(golden_dir, "rope_forms_cases.npz"))
+    tdt = getattr(torch, dt)
+    xq, xk = from_bits(g[f"{tag}_xq"], dt).to(dev), from_bits(g[f"{tag}_xk"], dt).to(dev)
+    cos, sin = torch.from_numpy(g["cos"]), torch.from_numpy(g["sin"])
+    cis = torch.complex(torch.from_numpy(g["cis_real"]), torch.from_numpy(g["cis_imag"]))
+    cq, ck = apply_rotary_emb(xq, xk, cis, head_first=False)
+    assert np.array_equal(to_np(cq), to_np(from_bits(g[f"{tag}_complex_q"], dt)))
+    assert np.array_equal(to_np(ck), to_np(from_bits(g[f"{tag}_complex_k"], dt)))
+    hq, hk = apply_rotary_emb(xq.transpose(1, 2).contiguous(), xk.transpose(1, 2).contiguous(), (cos, sin), head_first=True)
+    assert hq.shape == (1, 3, 72, 128) and hq.is_contiguous()
+    assert np.array_equal(to_np(hq), to_np(from_bits(g[f"{tag}_headfirst_q"], dt)))
+    assert np.array_equal(to_np(hk), to_np(from_bits(g[f"{tag}_headfirst_k"], dt)))
+    for C in (256, 3072):
+        x = from_bits(g[f"{tag}_rms{C}_x"], dt).to(dev)
+        n = RMSNorm(C, dtype=tdt, device=dev)
+        n.weight.data.copy_(from_bits(g[f"{tag}_rms{C}_w"], dt).to(dev))
+        assert_ulp_close(to_np(n(x)), to_np(from_bits(g[f"{tag}_rms{C}_y"], dt)), dt, max_frac=2e-3, max_ulps=2)
+        n0 = RMSNorm(C, elementwise_affine=False, eps=1e-5, dtype=tdt, device=dev)
+        assert_ulp_close(to_np(n0(x)), to_np(from_bits(g[f"{tag}_rms{C}_y_noweight"], dt)), dt, max_frac=2e-3, max_ulps=2)
+    with pytest.raises(ValueError):
+        RMSNorm(100, dtype=tdt, device=dev)(torch.zeros(2, 100, dtype=tdt, device=dev))      # not a multiple of 8
+    with pytest.raises(ValueError):
+        RMSNorm(128, dtype=tdt, device=dev)(torch.zeros(2, 256, dtype=tdt, device=dev))      # width mismatch
+
+
 def test_rmsnorm_rope_strided_qkv_vs_oracle(dev):
     """q/k as strided views of a fused QKV projection output, RoPE on the first s_rope tokens only."""
     from jenga_amd import _capi

@@ -172,6 +172,27 @@ def test_rmsnorm_rope_bit_exact(golden_dir, tag, dt):
     assert np.array_equal(rk, to_np(from_bits(g[f"{tag}_rk"], dt)))
 
 
+@pytest.mark.parametrize("tag,dt", [("bf16", "bfloat16"), ("fp16", "float16")])
+def test_other_forms_of_the_pre_ops_are_the_same_arithmetic(golden_dir, tag, dt):
+    """posemb_layers.py:181-229 also accepts head_first=True and a COMPLEX freqs_cis, norm_layers.py any width (no Jenga entry
+    script uses them).  Against the reference's own outputs (rope_forms_cases.npz): the complex form is the real form with
+    cos = Re, sin = Im repeated per pair -- (a + ib)(c + is) = (ac - bs) + i(as + bc), products rounded to fp32, one add, no
+    fma: bit for bit; head_first is a transposed view; RMSNorm over 256 / 3072 channels is the same formula (<= 2 ulp: the order
+    of the mean is free)."""
+    g = np.load(os.path.join(golden_dir, "rope_forms_cases.npz"))
+    xq, xk = to_np(from_bits(g[f"{tag}_xq"], dt)), to_np(from_bits(g[f"{tag}_xk"], dt))
+    cos_c, sin_c = np.repeat(g["cis_real"], 2, axis=1), np.repeat(g["cis_imag"], 2, axis=1)
+    for x, nm in ((xq, "q"), (xk, "k")):
+        assert np.array_equal(onr.apply_rotary_emb(x, cos_c, sin_c, dt), to_np(from_bits(g[f"{tag}_complex_{nm}"], dt)))
+        hf = onr.apply_rotary_emb(x, g["cos"], g["sin"], dt).transpose(0, 2, 1, 3)
+        assert np.array_equal(hf, to_np(from_bits(g[f"{tag}_headfirst_{nm}"], dt)))
+    for C in (256, 3072):
+        x, w = to_np(from_bits(g[f"{tag}_rms{C}_x"], dt)), to_np(from_bits(g[f"{tag}_rms{C}_w"], dt))
+        assert_ulp_close(onr.rmsnorm(x, w, dt), to_np(from_bits(g[f"{tag}_rms{C}_y"], dt)), dt, max_frac=2e-3, max_ulps=2)
+        assert_ulp_close(onr.rmsnorm(x, None, dt, eps=1e-5), to_np(from_bits(g[f"{tag}_rms{C}_y_noweight"], dt)), dt,
+                         max_frac=2e-3, max_ulps=2)
+
+
 def test_rope_table_full_size(golden_dir):
     meta = json.load(open(os.path.join(golden_dir, "norm_rope_cases.json")))
     cos, sin = onr.rope_tables([16, 56, 56], [32, 45, 80], theta=256.0)
