@@ -40,9 +40,8 @@ def parallel_attention(hybrid_seq_parallel_attn, q, k, v, img_q_len, img_kv_len,
     kept for every query block, image AND text rows masked at the valid length), i.e. the rank's heads attend over all
     image tokens and the valid text tokens -- what LongContextAttention computes.  Requirements of that path: hybrid_seq_parallel_attn is a
     jenga_amd.modules.ulysses.UlyssesAttenCarve, the image tokens of all ranks together are whole 128-token blocks, the text
-    length is a multiple of 128.  One stated deviation, the dense path's: the text-PADDING rows
-    (beyond cu_seqlens_q[1]) come back as zeros instead of attending among themselves (the reference's second flash call,
-    :222-247); no valid token reads them.  I2V sequence parallelism WITH AttenCarve is jenga_amd.dit's own path
+    length is a multiple of 128.  The text-PADDING rows (beyond cu_seqlens_q[1]) attend among themselves like the reference's
+    second flash call (:222-247): padding_segment on the rank's heads.  I2V sequence parallelism WITH AttenCarve is jenga_amd.dit's own path
     (JengaHYVideoDiT, i2v_condition_type = "token_replace"; tests/test_gpu_sp_dit.py)."""
     from . import ulysses
     if not isinstance(hybrid_seq_parallel_attn, ulysses.UlyssesAttenCarve):
@@ -59,6 +58,27 @@ def parallel_attention(hybrid_seq_parallel_attn, q, k, v, img_q_len, img_kv_len,
         joint_strategy="rear", cu_seqlens_q=cu_seqlens_q, cu_seqlens_kv=cu_seqlens_kv, dense=True)
     b, s, a, d = attn.shape
     return attn.reshape(b, s, -1)
+
+
+def padding_segment(q, k, v, seqlens, out):
+    """The SECOND segment of the reference's dense varlen call (attenion.py:34-57 builds cu_seqlens = [0, n_valid, S] per
+    sample; flash_attn_varlen_func :108-121, and parallel_attention's second flash call :222-247): the text-PADDING rows
+    [n_valid, S) attend among themselves -- keys of that segment only, softmax scale head_dim ** -0.5.  No valid token ever
+    reads them; they are computed so that the dense path returns what the reference returns, row for row (until round 5 they
+    came back as zeros).  q / k / v [1, S, H, 128], seqlens int32 [1] on the device, out [1, S, H, 128] (rows >= n_valid are
+    overwritten).  Reads n_valid on the host (one synchronisation per call: the dense path is the non-Jenga path)."""
+    S, H, D = q.shape[1], q.shape[2], q.shape[3]
+    n_valid = int(seqlens.reshape(-1)[0].item())
+    L = S - n_valid
+    if L <= 0:
+        return out
+    Lp = -(-L // 128) * 128
+    buf = torch.zeros((3, 1, Lp, H, D), dtype=q.dtype, device=q.device)
+    for i, t in enumerate((q, k, v)):
+        buf[i, :, :L] = t[:, n_valid:]
+    o = _capi.cross_attn_fwd(buf[0], buf[1], buf[2], sm_scale=D ** -0.5, kv_len=L)
+    out[:, n_valid:] = o[:, :L]
+    return out
 
 
 _DENSE_LISTS = {}
@@ -86,8 +106,8 @@ def attention(q, k, v, mode="flash", drop_rate=0, attn_mask=None, causal=False, 
               cu_seqlens_kv=None, max_seqlen_q=None, max_seqlen_kv=None, batch_size=1):
     """Dense path taken when sa_drop_rate == 0 (attenion.py:60-157, mode "flash" = flash_attn_varlen_func over the
     (valid | padding) segments).  Runs the same HIP kernel with every kv block kept and the kv-length mask on, for all
-    query blocks.  Deviation, documented in DESIGN.md: the padding-segment rows (text padding, never read by any valid
-    token) come back as zeros instead of attending among themselves; valid rows are the same softmax.
+    query blocks of the valid segment; the padding segment (text padding attending among itself) is one small dense call
+    (padding_segment): both segments as the reference computes them.
 
     Only what the Jenga entry scripts call is computed: mode "flash" without mask, causality or dropout.  The reference's
     "torch" / "vanilla" modes (attenion.py:102-150: SDPA / explicit softmax with attn_mask, causal, dropout) have other
@@ -115,4 +135,5 @@ def attention(q, k, v, mode="flash", drop_rate=0, attn_mask=None, causal=False, 
     idx, cnt = _dense_lists(q.device, B, H, nb)
     vt = _capi.pack_v(v if v.stride(-1) == 1 else v.contiguous(), nb)
     o = _capi.bsattn_fwd(q, k, vt, seqlens, idx, cnt, nb, D ** -0.5, 0.0, nb)
+    padding_segment(q, k, v, seqlens, o)
     return o.reshape(B, S, H * D)

@@ -155,11 +155,12 @@ def _hip_attend_dense(q_all, k_all, v_all, seqlens):
     """Every kv block kept for EVERY query block, the kv-length mask on for the text rows too: what LongContextAttention
     computes over image + valid text (parallel_attention, attenion.py:198-221).  Same kernel, same lists as
     jenga_amd.modules.attention.attention (the single-rank dense front-end)."""
-    from .attention import _dense_lists
+    from .attention import _dense_lists, padding_segment
     B, S, Hn, D = q_all.shape
     nb = S // 128
     idx, cnt = _dense_lists(q_all.device, B, Hn, nb)
-    return _capi.bsattn_fwd(q_all, k_all, _capi.pack_v(v_all, nb), seqlens, idx, cnt, nb, D ** -0.5, 0.0, nb)
+    o = _capi.bsattn_fwd(q_all, k_all, _capi.pack_v(v_all, nb), seqlens, idx, cnt, nb, D ** -0.5, 0.0, nb)
+    return padding_segment(q_all, k_all, v_all, seqlens, o)      # the text-padding rows among themselves (:222-247)
 
 
 def _hip_attend(q_all, k_all, v_all, idx, cnt, seqlens, text_blocks, text_amp):

@@ -235,9 +235,13 @@ def test_parallel_attention_is_the_dense_sequence_parallel_attention(dev, N):
     for r in range(N):
         got_img = results[r][:, :S_loc]
         got_txt = results[r][:, S_loc:S_loc + n_valid]
+        got_pad = results[r][:, S_loc + n_valid:]            # the text-padding rows among themselves (attenion.py:222-247)
         want_img = single[:, r * S_loc:(r + 1) * S_loc]
         want_txt = single[:, S_img:S_img + n_valid]
-        for got, want, rf in ((got_img, want_img, ref[:, r * S_loc:(r + 1) * S_loc]), (got_txt, want_txt, ref[:, S_img:S_img + n_valid])):
+        want_pad = single[:, S_img + n_valid:]
+        assert got_pad.float().abs().max().item() > 0.05
+        for got, want, rf in ((got_img, want_img, ref[:, r * S_loc:(r + 1) * S_loc]), (got_txt, want_txt, ref[:, S_img:S_img + n_valid]),
+                              (got_pad, want_pad, ref[:, S_img + n_valid:])):
             e1 = (got.float() - want.float()).abs().max().item()
             e2 = np.abs(got.float().cpu().numpy() - rf)
             e3 = np.abs(want.float().cpu().numpy() - rf)

@@ -102,4 +102,18 @@ E)  # the records at HEAD (review item 5): the driver's command, the full 50-ste
 import json;d=json.loads(open('$O/bench_wan14b.json').read().strip().splitlines()[-1]);print('wan14b', d['value'], d['unit'], d['roofline']['frac'], d['config'].get('schedule','')[:80])"
   timeout 2400 bash tools/prof_bench.sh r06_wan14b --workload wan14b --steps 50 --warmup 1 --no-cpu-baseline > $O/prof_wan14b.log 2>&1; head -6 gpurun_out/prof_r06_wan14b/kernel_stats.csv | cut -c1-160
   ;;
+F)  # final: the whole GPU suite at HEAD, smoke, the default bench command, the torch victims on one more box
+  timeout 2400 python -m pytest tests -x -q -m gpu > $O/pytest_gpu.log 2>&1; grep -E "passed|failed|error" $O/pytest_gpu.log | tail -3
+  python __graft_entry__.py --smoke > $O/smoke.log 2>&1; tail -1 $O/smoke.log
+  timeout 1500 python bench.py > $O/bench_default.json 2> $O/bench_default.err; ab $O/bench_default.json; python -c "
+import json;d=json.loads(open('$O/bench_default.json').read().strip().splitlines()[-1]);print('extras_failed', d.get('extras_failed'), 'traffic', d['roofline']['traffic_TBps'], d['roofline']['traffic_provenance'][:30], 'dense', d['dense_reference']['s_per_video'])"
+  DIAG_SECS=8 timeout 400 python tools/diag_torch_victim.py > $O/torch_victim.jsonl 2> $O/torch_victim.err; python - <<PY
+import json
+for l in open("$O/torch_victim.jsonl"):
+    d = json.loads(l)
+    if "skipped" in d: print("skipped", d); continue
+    print(d["load"], "runs", d["runs_per_op"], "bcast bad:", {k[:28]: v for k, v in d["mismatches_broadcast_high_kernels"].items() if v}, "swap-only bad:", sum(d["mismatches_swap_only_kernels"].values()), "control bad:", sum(d["mismatches_control"].values()))
+PY
+  timeout 400 tools/micro/bin/pk_beside_mfma 4000 > $O/pk_beside_mfma.jsonl 2>&1; grep -v '"differing": 0' $O/pk_beside_mfma.jsonl | cut -c1-160
+  ;;
 esac
