@@ -104,22 +104,50 @@ __global__ void rmsnorm_rope_kernel(const uint16_t* __restrict__ x, uint16_t* __
 // values already rounded to the storage dtype, i.e. pooled outputs are bit-identical to pooling the written tensors.
 // The cos / sin row of a token is fetched once for Q and K and all heads (rmsnorm_rope_kernel, called per tensor,
 // fetched the tables twice per layer).  Arithmetic of the norm and the rotation: rmsnorm_rope_kernel's, verbatim.
+// x + its three xor-partners inside a row of 16 lanes, in the order of the __shfl_xor(1, 2, 4, 8) butterfly, as four DPP adds
+// (quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_half_mirror, row_mirror) instead of four ds_bpermute round trips through the
+// LDS crossbar.  Same operands in every add (after the first two steps the lanes of a quad hold one value, so "the mirrored lane"
+// and "the lane 4 / 8 away" carry the same number; fp32 addition commutes): bit-identical (round 6; tools/bench_rowops.py
+// compares the checksums of both builds at the full shape).
+__device__ __forceinline__ float row16_allsum(float x) {
+#define JENGA_DPP_ADD(CTRL_)                                                                                              \
+    x = __fadd_rn(x, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), (CTRL_), 0xf, 0xf, \
+                                                                           false)))
+    JENGA_DPP_ADD(0xB1);
+    JENGA_DPP_ADD(0x4E);
+    JENGA_DPP_ADD(0x141);
+    JENGA_DPP_ADD(0x140);
+#undef JENGA_DPP_ADD
+    return x;
+}
+// a and b rounded to T and back, through ONE packed conversion (v_cvt_pk_bf16_f32 converts two values; written per element the
+// compiler spends one conversion and one shift on each)
+template <typename T>
+__device__ __forceinline__ void round_to2(float& a, float& b) {
+    const uint32_t w = pack2<T>(a, b);
+    a = to_f32<T>((uint16_t)(w & 0xffffu));
+    b = to_f32<T>((uint16_t)(w >> 16));
+}
+
 template <typename T>
 __device__ __forceinline__ void norm_rope_row(float (&f)[8], const float (&wv)[8], bool has_w, float eps, bool rope,
-                                              const float (&c)[8], const float (&sn)[8]) {
+                                              const float (&c)[8], const float (&sn)[8], uint4* packed = nullptr) {
     float ss = 0.f;
 #pragma unroll
     for (int i = 0; i < 8; ++i) ss = __fadd_rn(ss, __fmul_rn(f[i], f[i]));
-    ss += __shfl_xor(ss, 1);
-    ss += __shfl_xor(ss, 2);
-    ss += __shfl_xor(ss, 4);
-    ss += __shfl_xor(ss, 8);
+    ss = row16_allsum(ss);
     const float r = __fdiv_rn(1.0f, __fsqrt_rn(__fadd_rn(__fdiv_rn(ss, 128.0f), eps)));
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        float y = round_to<T>(__fmul_rn(f[i], r));
-        if (has_w) y = round_to<T>(__fmul_rn(y, wv[i]));
-        f[i] = y;
+    for (int i = 0; i < 8; i += 2) {
+        float y0 = __fmul_rn(f[i], r), y1 = __fmul_rn(f[i + 1], r);
+        round_to2<T>(y0, y1);
+        if (has_w) {
+            y0 = __fmul_rn(y0, wv[i]);
+            y1 = __fmul_rn(y1, wv[i + 1]);
+            round_to2<T>(y0, y1);
+        }
+        f[i] = y0;
+        f[i + 1] = y1;
     }
     if (rope) {
         float g[8];
@@ -131,8 +159,15 @@ __device__ __forceinline__ void norm_rope_row(float (&f)[8], const float (&wv)[8
 #pragma unroll
         for (int i = 0; i < 8; ++i) f[i] = g[i];
     }
+    // what the store writes (and what gets pooled): rounded pair by pair; the packed words ARE the store's payload
+    uint32_t pw[4];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) f[i] = round_to<T>(f[i]);   // what the store writes (and what gets pooled)
+    for (int i = 0; i < 8; i += 2) {
+        pw[i >> 1] = pack2<T>(f[i], f[i + 1]);
+        f[i] = to_f32<T>((uint16_t)(pw[i >> 1] & 0xffffu));
+        f[i + 1] = to_f32<T>((uint16_t)(pw[i >> 1] >> 16));
+    }
+    if (packed) *packed = make_uint4(pw[0], pw[1], pw[2], pw[3]);
 }
 
 template <typename T>
@@ -186,10 +221,11 @@ __global__ void __launch_bounds__(128) qk_norm_rope_pool_kernel(const uint16_t* 
                 c[0] = c0.x; c[1] = c0.y; c[2] = c0.z; c[3] = c0.w; c[4] = c1.x; c[5] = c1.y; c[6] = c1.z; c[7] = c1.w;
                 sn[0] = s0.x; sn[1] = s0.y; sn[2] = s0.z; sn[3] = s0.w; sn[4] = s1.x; sn[5] = s1.y; sn[6] = s1.z; sn[7] = s1.w;
             }
-            norm_rope_row<T>(fq, wqv, wq != nullptr, eps, rope, c, sn);
-            norm_rope_row<T>(fk, wkv, wk != nullptr, eps, rope, c, sn);
-            *reinterpret_cast<uint4*>(oq + ooff) = pack8<T>(fq);      // (streaming accesses measured here: 4.81-4.87 against
-            *reinterpret_cast<uint4*>(ok + ooff) = pack8<T>(fk);      //  4.89-5.14 TB/s with ordinary ones -- not used)
+            uint4 pq4, pk4;
+            norm_rope_row<T>(fq, wqv, wq != nullptr, eps, rope, c, sn, &pq4);
+            norm_rope_row<T>(fk, wkv, wk != nullptr, eps, rope, c, sn, &pk4);
+            *reinterpret_cast<uint4*>(oq + ooff) = pq4;      // (streaming accesses measured here: 4.81-4.87 against
+            *reinterpret_cast<uint4*>(ok + ooff) = pk4;      //  4.89-5.14 TB/s with ordinary ones -- not used)
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 aq[e] += fq[e];

@@ -116,4 +116,14 @@ for l in open("$O/torch_victim.jsonl"):
 PY
   timeout 400 tools/micro/bin/pk_beside_mfma 4000 > $O/pk_beside_mfma.jsonl 2>&1; grep -v '"differing": 0' $O/pk_beside_mfma.jsonl | cut -c1-160
   ;;
+G)  # fused norm / RoPE / pool kernel: Q and K in different workgroups (more waves, more loads in flight) against the one-thread-both form
+  for pass in 1 2 3; do
+    for L in base q_old q_ring3; do
+      [ $L = base ] && unset JENGA_LIB || export JENGA_LIB=$PWD/alt_libs/$L.so
+      python tools/bench_rowops.py >> $O/rowops.jsonl 2>> $O/rowops.err; tail -1 $O/rowops.jsonl
+    done
+  done
+  unset JENGA_LIB
+  timeout 900 python -m pytest tests/test_gpu_fused.py tests/test_gpu_pool.py tests/test_gpu_parity.py -x -q -m gpu -k "fused or pool or norm or rope or whole_op" > $O/pytest.log 2>&1; tail -2 $O/pytest.log
+  ;;
 esac
