@@ -135,10 +135,23 @@ def _worker(rank, world, port, ret, mode):
 def test_ulysses_two_ranks_match_oracle_and_single_rank(mode):
     """mode "p2p": Q, K (and V) leave in one grouped send/recv batch; "a2a": one all_to_all_single per tensor."""
     world = 2
-    port = _free_port()
     mgr = mp.Manager()
     ret = mgr.dict()
-    mp.spawn(_worker, args=(world, port, ret, mode), nprocs=world, join=True)
+    for attempt in range(3):
+        # (the rendezvous port is picked by binding port 0 and closing again: another process of the machine can take it before
+        # the two ranks bind it -- seen once in six rounds, with a gpurun client running beside the suite.  A rendezvous failure
+        # is retried on a fresh port; an assertion inside the workers is not)
+        port = _free_port()
+        try:
+            mp.spawn(_worker, args=(world, port, ret, mode), nprocs=world, join=True)
+            break
+        except Exception as e:      # noqa: BLE001
+            msg = str(e)
+            rendezvous = any(w in msg for w in ("Address already in use", "EADDRINUSE", "Connection refused", "Connection reset",
+                                                "connect() timed out", "Socket Timeout", "failed to connect", "timed out"))
+            if attempt == 2 or not rendezvous or "AssertionError" in msg:
+                raise
+            ret.clear()
     from oracle import attention as oa
     from oracle import ulysses as ou
     q, k, v, nbm, nimg, tb = _make_case()
