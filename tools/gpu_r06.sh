@@ -126,4 +126,7 @@ G)  # fused norm / RoPE / pool kernel: Q and K in different workgroups (more wav
   unset JENGA_LIB
   timeout 900 python -m pytest tests/test_gpu_fused.py tests/test_gpu_pool.py tests/test_gpu_parity.py -x -q -m gpu -k "fused or pool or norm or rope or whole_op" > $O/pytest.log 2>&1; tail -2 $O/pytest.log
   ;;
+H)  # the dry run of the first multi-GPU session once more, with the default six steps (every class of the three-stage preset sampled)
+  DRY=1 timeout 3000 bash tools/first_multi_gpu.sh $O/first_multi_gpu_dry > $O/first_multi_gpu_dry.log 2>&1; tail -12 $O/first_multi_gpu_dry.log
+  ;;
 esac
