@@ -156,6 +156,12 @@ int jenga_wan_gate_residual(void* stream, const float* x, const void* y, const f
 #define JENGA_ACT_NONE 0
 #define JENGA_ACT_GELU_TANH 1
 #define JENGA_BIAS_F32 256   /* OR-ed into `act` (ABI 3): bias is float32 [N] -- the gated bias gate * b stays unrounded */
+/* OR-ed into `act` (ABI 4, round 6): res and out are FLOAT32 [M,N] (x, w stay 16-bit) -- the Wan blocks' fp32 residual stream,
+ * `x = x + y * e` with y the 16-bit output of a linear layer (wan/modules/model_mul.py:334-341): out = res + gate * (x W^T) + bias
+ * straight from the fp32 accumulator.  Where the reference rounds y to 16 bits before the multiply, this form does not (one
+ * rounding to fp32 instead of three): closer to exact arithmetic, not bit-comparable -- jenga_wan_gate_residual stays for that.
+ * Not together with an activation. */
+#define JENGA_OUT_F32 512
 int jenga_linear(void* stream, const void* x, const void* w, const void* bias, const void* res, const float* gate,
                  void* out, int64_t M, int64_t N, int64_t K, int64_t x_row_stride, int64_t w_row_stride,
                  int64_t res_row_stride, int64_t out_row_stride, int act, void* workspace, int64_t workspace_bytes,

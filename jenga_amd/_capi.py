@@ -499,7 +499,8 @@ def gelu_tanh(x, out=None):
 
 
 ACT_NONE, ACT_GELU_TANH = 0, 1
-BIAS_F32 = 256      # OR-ed into jenga_linear's `act`: the bias vector is float32
+BIAS_F32 = 256
+OUT_F32 = 512      # OR-ed into jenga_linear's `act`: the bias vector is float32
 _GEMM_WORKSPACE = __import__("collections").OrderedDict()
 _GEMM_WORKSPACE_MAX = 8         # scratch buffers kept per process (64 MiB each), least recently used evicted
 
@@ -553,16 +554,23 @@ def linear(x, weight, bias=None, act=ACT_NONE, gate=None, res=None, out=None):
     N = weight.shape[0]
     if weight.dim() != 2 or weight.shape[1] != K or weight.stride(1) != 1 or weight.dtype != x.dtype:
         raise ValueError("linear: weight must be [N, K] in the input dtype with contiguous rows")
+    # a float32 residual (or out) selects the fp32 C / D form (JENGA_OUT_F32: the Wan blocks' residual stream)
+    out32 = (res is not None and res.dtype == torch.float32) or (out is not None and out.dtype == torch.float32)
+    odt = torch.float32 if out32 else x.dtype
     if out is None:
-        out = torch.empty(tuple(x.shape[:-1]) + (N,), dtype=x.dtype, device=x.device)
+        out = torch.empty(tuple(x.shape[:-1]) + (N,), dtype=odt, device=x.device)
     o2, Mo, No, ors = _rows2d(out)
-    if Mo != M or No != N or out.dtype != x.dtype:
-        raise ValueError("linear: out must be [..., N] with as many rows as x")
+    if Mo != M or No != N or out.dtype != odt:
+        raise ValueError("linear: out must be [..., N] with as many rows as x (float32 when the residual is float32)")
     r2, rrs = None, 0
     if res is not None:
         r2, Mr, Nr, rrs = _rows2d(res)
-        if Mr != M or Nr != N or res.dtype != x.dtype:
+        if Mr != M or Nr != N or res.dtype != odt:
             raise ValueError("linear: res must match out")
+    if out32:
+        if int(act) & 0xff:
+            raise ValueError("linear: the float32 residual form has no activation epilogue")
+        act = int(act) | OUT_F32
     if bias is not None:
         if bias.dtype == torch.float32:     # (the gated bias of proj / fc2 / linear2: kept unrounded)
             act = int(act) | BIAS_F32

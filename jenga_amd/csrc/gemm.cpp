@@ -99,12 +99,20 @@ extern "C" int jenga_linear(void* stream, const void* x, const void* w, const vo
     // act carries the activation in its low byte and JENGA_BIAS_F32 as a flag: the bias vector is float32 (the gated
     // bias gate * b of proj / fc2 / linear2 stays unrounded on its way into the fp32 accumulator)
     const bool bias32 = (act & JENGA_BIAS_F32) != 0;
+    // JENGA_OUT_F32 (round 6): the C (residual) and D (output) matrices are float32 -- the Wan blocks' residual stream
+    // (wan/modules/model_mul.py:334-341: x fp32 + y * e): gate * (x W^T) + b' + res lands in the fp32 stream straight from the
+    // fp32 accumulator, the separate gate + residual pass over 3.9 GB per call is gone
+    const bool out32 = (act & JENGA_OUT_F32) != 0;
     act &= 0xff;
     if (!x || !w || !out || M < 0 || N <= 0 || K <= 0 || x_row_stride < K || w_row_stride < K || out_row_stride < N ||
         (res && res_row_stride < N) || (act != JENGA_ACT_NONE && act != JENGA_ACT_GELU_TANH) || workspace_bytes < 0 ||
         (workspace_bytes > 0 && !workspace)) {
         set_error("jenga_linear: bad arguments (row strides must cover the rows; act in {0, 1})");
         return JENGA_EINVAL;
+    }
+    if (out32 && act != JENGA_ACT_NONE) {
+        set_error("jenga_linear: JENGA_OUT_F32 is for the gate / residual form (no activation epilogue)");
+        return JENGA_EUNSUPPORTED;
     }
     if (act != JENGA_ACT_NONE && (res || gate)) {
         set_error("jenga_linear: the activation epilogue cannot be combined with gate / residual");
@@ -131,7 +139,7 @@ extern "C" int jenga_linear(void* stream, const void* x, const void* w, const vo
     // the workspace size is part of the key: an algorithm chosen with a 64 MiB workspace must not be replayed for a call
     // that brings a smaller one
     const Shape shape{(long long)M, (long long)N, (long long)K, (long long)x_row_stride, (long long)w_row_stride, ldc,
-                      (long long)out_row_stride, epi, mode | (res ? 16 : 0) | (bias32 ? 32 : 0), dtype,
+                      (long long)out_row_stride, epi, mode | (res ? 16 : 0) | (bias32 ? 32 : 0) | (out32 ? 64 : 0), dtype,
                       (long long)workspace_bytes};
     const Key key{dev, shape};
     auto it = g_plans.find(key);
@@ -153,8 +161,9 @@ extern "C" int jenga_linear(void* stream, const void* x, const void* w, const vo
         LT_TRY(hipblasLtMatmulDescSetAttribute(p.desc, HIPBLASLT_MATMUL_DESC_POINTER_MODE, &pm, sizeof(pm)));
         LT_TRY(hipblasLtMatrixLayoutCreate(&p.A, dt, (uint64_t)K, (uint64_t)N, w_row_stride));    // W' [K,N], op = T
         LT_TRY(hipblasLtMatrixLayoutCreate(&p.B, dt, (uint64_t)K, (uint64_t)M, x_row_stride));    // X' [K,M]
-        LT_TRY(hipblasLtMatrixLayoutCreate(&p.C, dt, (uint64_t)N, (uint64_t)M, ldc));             // res' [N,M]
-        LT_TRY(hipblasLtMatrixLayoutCreate(&p.D, dt, (uint64_t)N, (uint64_t)M, out_row_stride));  // out' [N,M]
+        const hipDataType cdt = out32 ? HIP_R_32F : dt;
+        LT_TRY(hipblasLtMatrixLayoutCreate(&p.C, cdt, (uint64_t)N, (uint64_t)M, ldc));             // res' [N,M]
+        LT_TRY(hipblasLtMatrixLayoutCreate(&p.D, cdt, (uint64_t)N, (uint64_t)M, out_row_stride));  // out' [N,M]
         LT_TRY(hipblasLtMatmulPreferenceCreate(&g.pref));
         const uint64_t ws = (uint64_t)workspace_bytes;
         LT_TRY(hipblasLtMatmulPreferenceSetAttribute(g.pref, HIPBLASLT_MATMUL_PREF_MAX_WORKSPACE_BYTES, &ws, sizeof(ws)));

@@ -93,7 +93,9 @@ class WanSelfAttention(nn.Module):
 
     @torch.no_grad()
     def forward(self, x, seq_lens, grid_sizes, freqs, sa_drop_rate=0.0, per_block_tokens=128, p_remain_rates=0.8,
-                freq_remap=None, block_neighbor_list=None):
+                freq_remap=None, block_neighbor_list=None, project=True):
+        """project=False (jenga_amd.wan_dit's blocks): return the attention output BEFORE the output projection `self.o`,
+        which the block then runs with the gate and the fp32 residual in its epilogue."""
         b, s, n, d = *x.shape[:2], self.num_heads, self.head_dim
         num_blocks = math.ceil(s / per_block_tokens)
         dense = sa_drop_rate <= 0.25
@@ -128,7 +130,7 @@ class WanSelfAttention(nn.Module):
             q4, k4, v4 = (qkv[i].view(1, S_pad, n, d) for i in range(3))
             out = _op._combined(q4, k4, v4, top_k, seqlens, 0, 0.0, p, nbm, False, first_frame_blocks=ffb,
                                 context_size=s)
-            return self.o(out.to(x.dtype))
+            return self.o(out.to(x.dtype)) if project else out.to(x.dtype)
         # general path (any batch / head_dim the kernels take): the separate kernels and the padding op
         q = self.norm_q(self.q(x)).view(b, s, n, d)
         k = self.norm_k(self.k(x)).view(b, s, n, d)
@@ -140,4 +142,4 @@ class WanSelfAttention(nn.Module):
         out = _op.block_sparse_attention_wan(qr, kr, v.to(torch.bfloat16), top_k, text_blocks=0,
                                              block_neighbor_list=nbm, p_remain_rates=p, first_frame_blocks=ffb,
                                              kv_lens=seq_lens if dense else None)   # k_lens mask: dense branch only
-        return self.o(out.to(x.dtype).flatten(2))
+        return self.o(out.to(x.dtype).flatten(2)) if project else out.to(x.dtype).flatten(2)

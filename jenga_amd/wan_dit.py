@@ -10,6 +10,7 @@ are hipBLASLt (jenga_linear where an epilogue rides along, torch otherwise); the
 the FLOPs) runs on the LP attention kernel's dense mode (jenga_cross_attn_fwd) -- no library attention kernel anywhere.  Weights are random-initialised here (no checkpoints in this environment);
 state-dict keys follow the reference so that a Wan checkpoint loads with `patch_embedding.weight` flattened."""
 import math
+import os
 
 import torch
 import torch.nn as nn
@@ -56,7 +57,7 @@ class WanT2VCrossAttention(nn.Module):
         self.norm_k = WanRMSNorm(dim, eps=eps).to(device)
 
     @torch.no_grad()
-    def forward(self, x, context, context_lens=None):
+    def forward(self, x, context, context_lens=None, project=True):
         if context_lens is not None:
             raise ValueError("jenga_amd Wan cross-attention: context_lens must be None (the Jenga driver passes None)")
         b, n, d = x.shape[0], self.num_heads, self.head_dim
@@ -86,7 +87,22 @@ class WanT2VCrossAttention(nn.Module):
         # softmax scale d^-0.5, no mask beyond the context length (flash_attention(k_lens=None)): the LP attention kernel in
         # its dense mode, every query block against the context blocks (jenga_cross_attn_fwd)
         o = _capi.cross_attn_fwd(q.view(b, Lp, n, d), kv[0].view(b, Lcp, n, d), kv[1].view(b, Lcp, n, d), kv_len=Lc)
-        return self.o(o[:, :L].flatten(2))
+        return self.o(o[:, :L].flatten(2)) if project else o[:, :L].flatten(2)
+
+
+# Round 6: gate + residual of the Wan blocks in the GEMM epilogue (the HunyuanVideo blocks have had it since round 3).  One
+# rounding (to fp32) where the reference rounds the linear layer's output to 16 bits first; JENGA_WAN_FUSE_GATE=0 is the
+# configuration that is bit-comparable with the reference blocks (tests/test_gpu_wan_dit.py runs both).
+WAN_FUSE_GATE = os.environ.get("JENGA_WAN_FUSE_GATE", "1") != "0"
+
+
+def _linear_into_stream(lin, a, gate, x, out=None):
+    """x (fp32 residual stream) + gate * lin(a): the gate is hipBLASLt's alpha vector, x its C matrix, the gated bias stays fp32."""
+    g = None if gate is None else gate.reshape(-1).float()
+    bias = None
+    if lin.bias is not None:
+        bias = lin.bias.float() * g if g is not None else lin.bias.float()
+    return _capi.linear(a, lin.weight, bias, gate=g, res=x, out=out)
 
 
 class WanAttentionBlock(nn.Module):
@@ -121,6 +137,19 @@ class WanAttentionBlock(nn.Module):
         if x.dtype != torch.float32 or e.dtype != torch.float32 or x.shape[0] != 1:
             raise ValueError("Wan block: x and e are float32 and the batch is 1")
         em = self.modulation.float() + e                                         # [1,6,C]
+        if WAN_FUSE_GATE and x.is_cuda:
+            # the three `x = x + y [* e]` updates of the fp32 residual stream (model_mul.py:334-341) in the epilogue of the
+            # GEMM that produces y (jenga_linear, JENGA_OUT_F32): no separate 3.9 GB gate + residual pass per update
+            h = _capi.wan_ln_modulate(x, shift=em[:, 0], scale=em[:, 1], eps=self.eps, round_ln=x_was_16bit)
+            a = self.self_attn(h, seq_lens, grid_sizes, freqs, sa_drop_rate=sa_drop_rate, freq_remap=freq_remap,
+                               block_neighbor_list=block_neighbor_list, p_remain_rates=p_remain_rates, project=False)
+            x = _linear_into_stream(self.self_attn.o, a, em[:, 2], x)              # new tensor: callers keep their input
+            h = _capi.wan_ln_modulate(x, weight=self.norm3.weight, bias=self.norm3.bias, eps=self.eps) \
+                if self.cross_attn_norm else x.to(context.dtype)
+            _linear_into_stream(self.cross_attn.o, self.cross_attn(h, context, context_lens, project=False), None, x, out=x)
+            h = _capi.wan_ln_modulate(x, shift=em[:, 3], scale=em[:, 4], eps=self.eps)
+            _linear_into_stream(self.ffn[2], self.ffn_hidden(h), em[:, 5], x, out=x)
+            return x
         # self-attention: y = attn(norm1(x) * (1 + e1) + e0);  x = x + y * e2
         h = _capi.wan_ln_modulate(x, shift=em[:, 0], scale=em[:, 1], eps=self.eps, round_ln=x_was_16bit)
         y = self.self_attn(h, seq_lens, grid_sizes, freqs, sa_drop_rate=sa_drop_rate, freq_remap=freq_remap,

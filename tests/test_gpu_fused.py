@@ -192,6 +192,45 @@ def test_linear_epilogues_vs_fp32_reference(dev, dt, M, N, K):
         _capi.linear(x, w, b, act=_capi.ACT_GELU_TANH, res=res)
 
 
+@pytest.mark.parametrize("M,N,K", [(300, 512, 256), (1280, 1536, 1536), (257, 768, 3072)])
+def test_linear_into_a_float32_residual_stream(dev, M, N, K):
+    """jenga_linear with JENGA_OUT_F32 (round 6): res and out float32, x and w bf16 -- the Wan blocks' `x = x + y * e`
+    (wan/modules/model_mul.py:334-341) in the epilogue of the GEMM that produces y.  Against the same expression in float64 on
+    the bf16 operands: the result is ONE fp32 rounding of it plus the fp32 summation order of K products; in place (out is res)
+    and into a new tensor; without gate (the cross-attention update) and without bias.  And against the unfused pair it
+    replaces (16-bit GEMM output, then jenga_wan_gate_residual): that one carries the extra 16-bit rounding of y."""
+    from jenga_amd import _capi
+    from jenga_amd.wan_dit import _linear_into_stream
+    g = torch.Generator(device=dev).manual_seed(M * 7 + N)
+    a = torch.randn(1, M, K, generator=g, device=dev).to(torch.bfloat16)
+    lin = torch.nn.Linear(K, N, dtype=torch.bfloat16, device=dev)
+    with torch.no_grad():
+        lin.weight.copy_((torch.randn(N, K, generator=g, device=dev) * K ** -0.5).to(torch.bfloat16))
+        lin.bias.copy_((torch.randn(N, generator=g, device=dev) * 0.1).to(torch.bfloat16))
+    gate = torch.randn(1, N, generator=g, device=dev) * 0.7
+    x = torch.randn(1, M, N, generator=g, device=dev)
+    y64 = a.double() @ lin.weight.double().t() + lin.bias.double()
+    for gt in (gate, None):
+        exact = x.double() + (y64 * gt.double() if gt is not None else y64)
+        keep = x.clone()
+        got = _linear_into_stream(lin, a, gt, x)
+        assert got.dtype == torch.float32 and got.data_ptr() != x.data_ptr() and torch.equal(x, keep)
+        bound = 2.0 ** -22 * exact.abs().clamp_min(1.0) + 2e-5 * (K / 256) ** 0.5      # an fp32 rounding + summation noise
+        err = (got.double() - exact).abs()
+        assert bool((err <= bound).all()), (err.max().item(), (err / bound).max().item())
+        x2 = x.clone()
+        got2 = _linear_into_stream(lin, a, gt, x2, out=x2)
+        assert got2.data_ptr() == x2.data_ptr() and torch.equal(x2, got)
+        # the unfused pair: y rounded to bf16 first -- further from exact than the fused call, and within that rounding of it
+        unfused = _capi.wan_gate_residual(x, lin(a), gt)
+        e_u = (unfused.double() - exact).abs()
+        assert float(err.mean()) <= float(e_u.mean())
+        ulp_y = torch.exp2(torch.floor(torch.log2(y64.abs().clamp_min(2.0 ** -6))) - 7)
+        assert bool(((got.double() - unfused.double()).abs() <= ulp_y * (gt.double().abs() if gt is not None else 1.0) + 1e-4).all())
+    with pytest.raises((ValueError, _capi.JengaError)):
+        _capi.linear(a, lin.weight, None, act=_capi.ACT_GELU_TANH, res=x)
+
+
 def test_linear_choices_export_import_roundtrip(dev):
     """jenga_linear_export_choices / _import_choices (rank 0's hipBLASLt choices adopted by every rank: the replicated
     text stream must see the same arithmetic everywhere): importing a device's own choices reproduces its results bit

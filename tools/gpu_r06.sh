@@ -129,4 +129,14 @@ G)  # fused norm / RoPE / pool kernel: Q and K in different workgroups (more wav
 H)  # the dry run of the first multi-GPU session once more, with the default six steps (every class of the three-stage preset sampled)
   DRY=1 timeout 3000 bash tools/first_multi_gpu.sh $O/first_multi_gpu_dry > $O/first_multi_gpu_dry.log 2>&1; tail -12 $O/first_multi_gpu_dry.log
   ;;
+I)  # Wan blocks: gate + residual in the GEMM epilogue (fp32 C / D) -- tests, then the Wan2.1-14B loop with and without, one box
+  timeout 1500 python -m pytest tests/test_gpu_fused.py tests/test_gpu_wan_dit.py tests/test_gpu_parity.py -x -q -m gpu -k "linear or wan or dense or other_forms" > $O/pytest.log 2>&1; tail -3 $O/pytest.log
+  for pass in 1 2; do
+    for V in 0 1; do
+      JENGA_WAN_FUSE_GATE=$V timeout 900 python bench.py --workload wan14b --steps 6 --warmup 1 --no-cpu-baseline > $O/wan_fuse${V}_$pass.json 2> $O/wan_fuse${V}_$pass.err
+      python -c "
+import json;d=json.loads(open('$O/wan_fuse${V}_$pass.json').read().strip().splitlines()[-1]);print('fuse=$V pass $pass', d['value'], d['roofline']['frac'], d['config'].get('ms_per_step_by_drop_rate'))"
+    done
+  done
+  ;;
 esac
