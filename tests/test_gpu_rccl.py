@@ -180,7 +180,7 @@ def test_sp_dit_forward_over_rccl_world1_harness():
     assert set(recs[0]["modes"]) == {"p2p", "a2a"}
 
 
-@pytest.mark.parametrize("world", [2, 4])
+@pytest.mark.parametrize("world", [2, 4, 8])      # 8: the degree of BASELINE.json configs 3 and 5 (one head per rank here)
 def test_sp_dit_forward_n_processes_sharing_one_gpu(world):
     """N REAL processes (own library state, own streams, own process-group rank), all on device 0, the product's
     sequence-parallel forward with its HIP local steps (prologue, pack, selection with top_k = N * int(...), attention on the
