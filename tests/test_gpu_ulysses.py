@@ -118,11 +118,12 @@ def test_simulated_ranks_forward_equals_single_rank_op(dev, N, pipeline):
         assert err.mean() <= 2e-3 and (err.max(-1) > 3e-2).mean() <= 0.02, (r, err.max(), err.mean())
 
 
-@pytest.mark.parametrize("tag,grid,drop,amp", [
-    ("config2_full_stage", (32, 45, 80), 0.75, 0.0),          # S_loc 14 400, top_k 8 * int(0.25 * 112) = 224
-    ("config3_turbo_stage0", (32, 33, 60), 0.75, 0.431),     # S_loc 7 920,  top_k 8 * int(0.25 * 61) = 120, text_amp 0.431
+@pytest.mark.parametrize("tag,grid,drop,amp,tb", [
+    ("config2_full_stage", (32, 45, 80), 0.75, 0.0, 2),          # S_loc 14 400, top_k 8 * int(0.25 * 112) = 224
+    ("config3_turbo_stage0", (32, 33, 60), 0.75, 0.431, 2),     # S_loc 7 920,  top_k 8 * int(0.25 * 61) = 120, text_amp 0.431
+    ("config5_i2v_stage0", (32, 22, 40), 0.75, 1.016, 4),       # S_loc 3 520,  top_k 8 * int(0.25 * 27) = 48, four text blocks
 ])
-def test_full_size_rank_share_of_eight_equals_single_rank_op(dev, tag, grid, drop, amp):
+def test_full_size_rank_share_of_eight_equals_single_rank_op(dev, tag, grid, drop, amp, tb):
     """One rank's REAL share of the 8-GPU configurations (BASELINE.json configs 2/3/5: 24 heads -> 3 heads x all 115 456 /
     63 616 keys per rank, S_loc = S_img / 8 not a multiple of 128, top_k = N * int((1 - r) * (S_loc // 128)),
     models_mul_block_gc_ha_multigpu.py:249-251; cu_seqlens rebuilt, xdit_ring_atten.py:105,183-184) through
@@ -132,14 +133,14 @@ def test_full_size_rank_share_of_eight_equals_single_rank_op(dev, tag, grid, dro
     from jenga_amd.modules import ulysses
     from jenga_amd.modules.attention import my_parallel_attention
     from jenga_amd.modules.attention_block_sparse import block_sparse_attention
-    N, H, tb = 8, 24, 2
+    N, H = 8, 24
     t, h, w = grid
     S_img, S_txt = t * h * w, tb * 128
     nimg = S_img // 128
     S_loc = S_img // N
     assert S_img % (128 * 1) == 0 and S_img % N == 0 and S_loc % 128 != 0
     top_k = N * int((1 - drop) * (S_loc // 128))
-    assert top_k == {"config2_full_stage": 224, "config3_turbo_stage0": 120}[tag]
+    assert top_k == {"config2_full_stage": 224, "config3_turbo_stage0": 120, "config5_i2v_stage0": 48}[tag]
     n_valid, p_rate = 70, 0.3
     g = torch.Generator(device=dev).manual_seed(99)
     nb = nimg + tb
