@@ -131,10 +131,11 @@ def _worker(rank, world, port, ret, mode):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("mode", ["p2p", "a2a"])
-def test_ulysses_two_ranks_match_oracle_and_single_rank(mode):
-    """mode "p2p": Q, K (and V) leave in one grouped send/recv batch; "a2a": one all_to_all_single per tensor."""
-    world = 2
+@pytest.mark.parametrize("mode,world", [("p2p", 2), ("a2a", 2), ("p2p", 4), ("a2a", 4)])
+def test_ulysses_two_ranks_match_oracle_and_single_rank(mode, world):
+    """mode "p2p": Q, K (and V) leave in one grouped send/recv batch; "a2a": one all_to_all_single per tensor.
+    world 4 (round 6): with two ranks every rank has ONE peer; four ranks exercise the peer loop of the grouped send/recv and
+    the chunk order of the all-to-all for real (one head and two 128-token blocks per rank)."""
     mgr = mp.Manager()
     ret = mgr.dict()
     for attempt in range(3):
@@ -171,4 +172,12 @@ def test_ulysses_two_ranks_match_oracle_and_single_rank(mode):
         got = ret[r].reshape(1, S_loc + tb * 128, H, 128)
         assert np.array_equal(got, sim[r]), f"rank {r}: exchange differs from the oracle simulation"
         want = np.concatenate([single[:, r * S_loc:(r + 1) * S_loc], single[:, S_img:]], axis=1)
-        assert np.array_equal(got, want), f"rank {r}: SP result differs from the single-rank op"
+        if world == 2:
+            assert np.array_equal(got, want), f"rank {r}: SP result differs from the single-rank op"
+        else:
+            # with ONE head per rank numpy's einsum takes another summation path for the [1, 1, ...] operands than for the
+            # [1, 4, ...] ones of the single-rank call: 14 of 655 360 values of the replicated text rows land on the neighbouring
+            # bf16 value (the ORACLE's float order, not the exchange: `got` equals the oracle's N-rank simulation bit for bit
+            # above).  The HIP op has no such shape dependence: tests/test_gpu_ulysses.py demands bit-equality for N = 2, 4, 8.
+            from helpers import assert_ulp_close
+            assert_ulp_close(got, want, "bfloat16", max_frac=1e-4, max_ulps=1)
