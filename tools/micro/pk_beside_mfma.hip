@@ -128,6 +128,50 @@ __global__ void __launch_bounds__(256) victim(const uint32_t* __restrict__ in, f
                 asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0]" : "=v"(d) : "v"(v), "v"(m));
                 acc = acc + d;
             }
+            // round 6, narrowing the condition (torch kernels with these selections ran clean): is it the DISTANCE between the producer
+            // of the source pair and the packed consumer?  17 = form 9 with 16 idle wait states between the two; 18 = form 9 with the
+            // pair produced by two SCALAR multiplies; 19 = form 9 with the pair read back from memory (no VALU producer at all)
+            if (FORM == 17) {
+                f2 m = acc * (f2){0.5f, 0.25f};
+                f2 d;
+                asm volatile("s_nop 7\n\ts_nop 7\n\tv_pk_add_f32 %0, %1, %2 op_sel:[0,1]" : "=v"(d) : "v"(v), "v"(m));
+                acc = acc + d;
+            }
+            if (FORM == 18) {
+                f2 m;
+                asm volatile("v_mul_f32 %0, 0.5, %2\n\tv_mul_f32 %1, 0.25, %3" : "=&v"(m.x), "=&v"(m.y) : "v"(acc.x), "v"(acc.y));
+                f2 d;
+                asm volatile("v_pk_add_f32 %0, %1, %2 op_sel:[0,1]" : "=v"(d) : "v"(v), "v"(m));
+                acc = acc + d;
+            }
+            if (FORM == 19) {
+                const f2 m = {__uint_as_float(w[(k + 1) & 3] << 16), __uint_as_float(w[(k + 2) & 3] & 0xffff0000u)};
+                f2 mm = m;
+                asm volatile("s_nop 7\n\ts_nop 7" : "+v"(mm));      // (settled registers: nothing in flight)
+                f2 d;
+                asm volatile("v_pk_add_f32 %0, %1, %2 op_sel:[0,1]" : "=v"(d) : "v"(v), "v"(mm));
+                acc = acc + d;
+            }
+            // is it the DESTINATION overlapping a source?  (an asm output without early-clobber may be given a source's registers.)
+            // 20 = form 9 with a destination that overlaps NO source (early-clobber); 21 = destination IS the second source pair
+            // (the one whose high half the low lane reads); 22 = destination IS the first source pair
+            if (FORM == 20) {
+                const f2 m = acc * (f2){0.5f, 0.25f};
+                f2 d;
+                asm volatile("v_pk_add_f32 %0, %1, %2 op_sel:[0,1]" : "=&v"(d) : "v"(v), "v"(m));
+                acc = acc + d;
+            }
+            if (FORM == 21) {
+                f2 m = acc * (f2){0.5f, 0.25f};
+                asm volatile("v_pk_add_f32 %0, %1, %0 op_sel:[0,1]" : "+v"(m) : "v"(v));
+                acc = acc + m;
+            }
+            if (FORM == 22) {
+                const f2 m = acc * (f2){0.5f, 0.25f};
+                f2 vv = v;
+                asm volatile("v_pk_add_f32 %0, %0, %1 op_sel:[0,1]" : "+v"(vv) : "v"(m));
+                acc = acc + vv;
+            }
             // 8: the mirror image: (v.lo - m.lo, v.hi - m.lo)
             if (FORM == 8) {
                 const f2 m = acc * (f2){0.5f, 0.25f};
@@ -152,15 +196,19 @@ int main(int argc, char** argv) {
     hipStream_t sv, sl;
     CHECK(hipStreamCreate(&sv)); CHECK(hipStreamCreate(&sl));
     std::vector<float> first(n), cur(n);
-    const char* names[17] = {"packed mul+add (SLP form)", "scalar", "packed fma", "packed mul", "packed add",
+    const char* names[23] = {"packed mul+add (SLP form)", "scalar", "packed fma", "packed mul", "packed add",
                             "packed sub of a broadcast HIGH half (op_sel:[0,1])", "packed sub of a broadcast LOW half (op_sel_hi:[1,0])",
                             "asm v_pk_add_f32 op_sel:[0,1] neg (x - mean, the LayerNorm instruction)", "asm v_pk_add_f32 op_sel_hi:[1,0] neg",
                             "asm v_pk_add_f32 op_sel:[0,1] (no neg)", "asm v_pk_mul_f32 op_sel:[0,1]",
                             "asm v_pk_fma_f32 op_sel:[0,1,0]", "asm v_pk_add_f16 op_sel:[0,1]", "asm v_pk_mul_f16 op_sel:[0,1]",
                             "asm v_pk_add_f32 op_sel:[0,1] op_sel_hi:[1,0] (SWAP on src1)", "asm v_pk_add_f32 op_sel:[1,0] (HIGH half of src0 broadcast)",
-                            "asm v_pk_mul_f32 op_sel:[0,1] op_sel_hi:[1,0] (SWAP on src1)"};
+                            "asm v_pk_mul_f32 op_sel:[0,1] op_sel_hi:[1,0] (SWAP on src1)",
+                            "form 9 with 16 wait states between the pair's producer and the packed add",
+                            "form 9 with the pair produced by two scalar v_mul_f32", "form 9 with the pair taken from settled registers (loaded data)",
+                            "form 9, destination overlaps NO source (early-clobber)", "form 9, destination IS the second source pair",
+                            "form 9, destination IS the first source pair"};
     for (int with_load = 2; with_load >= 0; --with_load) {      // 2: 16x16x32 MFMAs beside it, 1: 32x32x16, 0: nothing
-        for (int form = 0; form < 17; ++form) {
+        for (int form = 0; form < 23; ++form) {
             int bad = 0;
             for (int l = 0; l < launches; ++l) {
                 if (with_load == 2 && (l % 4) == 0) hipLaunchKernelGGL(mfma_load<1>, dim3(2048), dim3(256), 0, sl, dsink, 4000);
@@ -182,7 +230,13 @@ int main(int argc, char** argv) {
                     case 13: hipLaunchKernelGGL(victim<13>, dim3(n / 256), dim3(256), 0, sv, din, dout, n); break;
                     case 14: hipLaunchKernelGGL(victim<14>, dim3(n / 256), dim3(256), 0, sv, din, dout, n); break;
                     case 15: hipLaunchKernelGGL(victim<15>, dim3(n / 256), dim3(256), 0, sv, din, dout, n); break;
-                    default: hipLaunchKernelGGL(victim<16>, dim3(n / 256), dim3(256), 0, sv, din, dout, n); break;
+                    case 16: hipLaunchKernelGGL(victim<16>, dim3(n / 256), dim3(256), 0, sv, din, dout, n); break;
+                    case 17: hipLaunchKernelGGL(victim<17>, dim3(n / 256), dim3(256), 0, sv, din, dout, n); break;
+                    case 18: hipLaunchKernelGGL(victim<18>, dim3(n / 256), dim3(256), 0, sv, din, dout, n); break;
+                    case 19: hipLaunchKernelGGL(victim<19>, dim3(n / 256), dim3(256), 0, sv, din, dout, n); break;
+                    case 20: hipLaunchKernelGGL(victim<20>, dim3(n / 256), dim3(256), 0, sv, din, dout, n); break;
+                    case 21: hipLaunchKernelGGL(victim<21>, dim3(n / 256), dim3(256), 0, sv, din, dout, n); break;
+                    default: hipLaunchKernelGGL(victim<22>, dim3(n / 256), dim3(256), 0, sv, din, dout, n); break;
                 }
                 if (l == 0 || (l % 16) == 15) {          // check every 16th launch (and the first)
                     CHECK(hipMemcpyAsync(cur.data(), dout, n * 4, hipMemcpyDeviceToHost, sv));
